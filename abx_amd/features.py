@@ -1,0 +1,199 @@
+"""Per-sample feature construction run once before the reverse loop (host plumbing on torch tensors, any device).
+
+Mirrors the seven transforms of the reference's config/config_data_feature.json as far as the sampling path reads
+their outputs:
+  make_restype_atom_constants  abx/model/features.py:52-66
+  make_gt_frames               abx/model/features.py:88-96  -> abx/common/geometry.py:9-63
+  make_torsion_angles          abx/model/features.py:107-115 -> abx/common/geometry.py:115-211
+  make_pseudo_beta             abx/model/features.py:78-86
+  make_diffuser_features       abx/model/features.py:130-212  (mask logic, t, noise initialisation)
+Loss-only outputs (alt positions, calpha3 frames) are not produced.
+"""
+import torch
+import torch.nn.functional as F
+
+from abx_amd import residue_constants as rc
+
+
+def _t(a, device, dtype=None):
+    return torch.as_tensor(a, device=device) if dtype is None else torch.as_tensor(a, device=device).to(dtype)
+
+
+def gather_rows(params, idx):
+    """params (B,L,A,...) , idx (B,L,K) -> params[b,l,idx[b,l,k],...]  (reference batched_select, batch_dims=2)."""
+    B, L, K = idx.shape
+    tail = params.shape[3:]
+    ix = idx.long().reshape(B, L, K, *([1] * len(tail))).expand(B, L, K, *tail)
+    return torch.gather(params, 2, ix)
+
+
+def make_restype_atom_constants(batch):
+    dev = batch['seq'].device
+    seq = batch['seq'].long()
+    batch['atom14_atom_exists'] = _t(rc.restype_atom14_mask, dev)[seq]
+    if 'residx_atom37_to_atom14' not in batch:
+        batch['residx_atom37_to_atom14'] = _t(rc.restype_atom37_to_atom14, dev)[seq]
+    if 'atom37_atom_exists' not in batch:
+        batch['atom37_atom_exists'] = _t(rc.restype_atom37_mask, dev)[seq]
+    return batch
+
+
+def make_atom37_positions(batch):
+    batch['atom37_gt_positions'] = gather_rows(batch['atom14_gt_positions'], batch['residx_atom37_to_atom14'])
+    batch['atom37_gt_exists'] = torch.logical_and(
+        gather_rows(batch['atom14_gt_exists'], batch['residx_atom37_to_atom14']), batch['atom37_atom_exists'])
+    return batch
+
+
+def _robust_normalize(v, eps=1e-8):
+    return v / torch.sqrt(torch.sum(v * v, dim=-1, keepdim=True) + eps)
+
+
+def rigids_from_3_points(p_neg_x, origin, p_xy):
+    """Gram-Schmidt frame, columns (e0,e1,e2) (reference abx/model/r3.py:89-109)."""
+    e0 = _robust_normalize(origin - p_neg_x)
+    e1u = p_xy - origin
+    c = torch.sum(e1u * e0, dim=-1, keepdim=True)
+    e1 = _robust_normalize(e1u - c * e0)
+    e2 = torch.stack([e0[..., 1] * e1[..., 2] - e0[..., 2] * e1[..., 1],
+                      e0[..., 2] * e1[..., 0] - e0[..., 0] * e1[..., 2],
+                      e0[..., 0] * e1[..., 1] - e0[..., 1] * e1[..., 0]], dim=-1)
+    return torch.stack((e0, e1, e2), dim=-1), origin
+
+
+def atom37_to_frames(aatype, pos37, mask37):
+    dev = aatype.device
+    aa = aatype.long()
+    base_idx = _t(rc.restype_rigidgroup_base_atom37_idx, dev).long()[aa]          # (B,L,8,3)
+    B, L = aa.shape
+    flat = base_idx.reshape(B, L, 24)
+    base = gather_rows(pos37, flat).reshape(B, L, 8, 3, 3)
+    rots, trans = rigids_from_3_points(base[..., 0, :], base[..., 1, :], base[..., 2, :])
+    group_exists = _t(rc.restype_rigidgroup_mask, dev)[aa]
+    atoms_exist = gather_rows(mask37, flat).reshape(B, L, 8, 3)
+    gt_exists = torch.logical_and(torch.all(atoms_exist, dim=-1), group_exists)
+    flip = torch.eye(3, dtype=rots.dtype, device=dev).repeat(8, 1, 1)
+    flip[0, 0, 0] = -1
+    flip[0, 2, 2] = -1
+    rots = torch.einsum('...rd,...dm->...rm', rots, flip)
+    return {'rigidgroups_gt_frames': (rots, trans), 'rigidgroups_gt_exists': gt_exists,
+            'rigidgroups_group_exists': group_exists}
+
+
+def invert_apply(rots, trans, pts):
+    """R^T (p - t)  ==  invert_rigids then rigids_mul_vecs (r3.py:54-59,18-25)."""
+    return torch.einsum('...dr,...d->...r', rots, pts) - torch.einsum('...dr,...d->...r', rots, trans)
+
+
+def atom37_to_torsion_angles(aatype, pos, mask):
+    dev = aatype.device
+    B, L = aatype.shape
+    aa = aatype.long()
+    prev_pos = F.pad(pos[:, :-1], [0, 0, 0, 0, 1, 0])
+    prev_mask = F.pad(mask[:, :-1], [0, 0, 1, 0])
+    pre_omega = torch.cat([prev_pos[:, :, 1:3], pos[:, :, 0:2]], dim=-2)
+    phi = torch.cat([prev_pos[:, :, 2:3], pos[:, :, 0:3]], dim=-2)
+    psi = torch.cat([pos[:, :, 0:3], pos[:, :, 4:5]], dim=-2)
+    pre_omega_mask = torch.logical_and(torch.all(prev_mask[:, :, 1:3], dim=-1), torch.all(mask[:, :, 0:2], dim=-1))
+    phi_mask = torch.logical_and(prev_mask[:, :, 2], torch.all(mask[:, :, 0:3], dim=-1))
+    psi_mask = torch.logical_and(torch.all(mask[:, :, 0:3], dim=-1), mask[:, :, 4])
+    atom_idx = _t(rc.chi_angles_atom_indices, dev).long()[aa]                     # (B,L,4,4)
+    chis_pos = gather_rows(pos, atom_idx.reshape(B, L, 16)).reshape(B, L, 4, 4, 3)
+    chis_mask = _t(rc.chi_angles_mask, dev)[aa]
+    chi_atoms_mask = torch.all(gather_rows(mask, atom_idx.reshape(B, L, 16)).reshape(B, L, 4, 4), dim=-1)
+    chis_mask = torch.logical_and(chis_mask, chi_atoms_mask)
+    tors_pos = torch.cat([pre_omega[:, :, None], phi[:, :, None], psi[:, :, None], chis_pos], dim=2)
+    tors_mask = torch.cat([pre_omega_mask[:, :, None], phi_mask[:, :, None], psi_mask[:, :, None], chis_mask], dim=2)
+    rots, trans = rigids_from_3_points(tors_pos[:, :, :, 1], tors_pos[:, :, :, 2], tors_pos[:, :, :, 0])
+    rel = invert_apply(rots, trans, tors_pos[:, :, :, 3])
+    sc = torch.stack([rel[..., 2], rel[..., 1]], dim=-1)
+    sc = sc / torch.sqrt(torch.sum(sc * sc, dim=-1, keepdim=True) + 1e-8)
+    sc = sc * torch.tensor([1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 1.0], device=dev)[..., None]
+    amb = _t(rc.chi_pi_periodic, dev)[aa]
+    mirror = torch.cat([torch.ones([B, L, 3], device=dev), 1.0 - 2.0 * amb], dim=-1)
+    return {'torsion_angles_sin_cos': sc, 'alt_torsion_angles_sin_cos': sc * mirror[..., None],
+            'torsion_angles_mask': tors_mask}
+
+
+def pseudo_beta_fn(aatype, pos37, mask37):
+    is_gly = aatype == rc.restype_order['G']
+    ca, cb = rc.atom_order['CA'], rc.atom_order['CB']
+    pb = torch.where(is_gly[..., None], pos37[..., ca, :], pos37[..., cb, :])
+    pm = torch.where(is_gly, mask37[..., ca].float(), mask37[..., cb].float())
+    return pb, pm
+
+
+def _sqrt_pos(x):
+    return torch.sqrt(torch.clamp(x, min=0.0)) * (x > 0)
+
+
+def rot_to_quat(m):
+    """Best-conditioned-candidate rotation->quaternion (reference quat_affine.py:181-231)."""
+    b = m.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(m.reshape(b + (9,)), dim=-1)
+    q_abs = _sqrt_pos(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22,
+                                   1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    cand = cand / (2.0 * torch.clamp(q_abs[..., None], min=0.1))
+    best = q_abs.argmax(dim=-1)
+    return torch.gather(cand, -2, best[..., None, None].expand(b + (1, 4))).squeeze(-2)
+
+
+def make_diffuser_features(batch, generate_area, diffuser, diff_conf=None, opt_step=None, noise=None):
+    """Inference branch of the reference's make_diffuser_features (features.py:130-212, is_training=False).
+
+    diffused residues of CDR c with anchors at a<b:  [a+1, b-1)  — the last CDR residue stays fixed (features.py:166).
+    design/trajectory (opt_step None): t=1, FullDiffuser.sample_ref ; optimize: t=opt_step/inference_step,
+    FullDiffuser.forward_marginal.  `noise`: optional recorded draws (parity mode), see FullDiffuser.
+    """
+    dev = batch['seq'].device
+    anchor_flag = batch['anchor_flag'].int()
+    Lab = anchor_flag.shape[1]
+    B = batch['seq'].shape[0]
+    rots, trans = batch['rigidgroups_gt_frames']
+    rigids_0 = torch.cat([rot_to_quat(rots[:, :, 0]), trans[:, :, 0]], dim=-1)
+    seq_0 = batch['seq']
+    if generate_area == 'cdr':
+        cdrs = sorted(set(anchor_flag[anchor_flag > 0].tolist()))
+    else:
+        cdrs = [rc.cdr_str_to_enum[generate_area]]
+    diffused = torch.zeros_like(batch['mask'], dtype=torch.int32)
+    ab_loss_mask = torch.zeros_like(anchor_flag, dtype=torch.int32)
+    struc_loss_mask = batch['mask'].to(torch.int32).clone()
+    for c in cdrs:
+        idx = torch.nonzero(anchor_flag == c).tolist()
+        for i in range(0, len(idx) - 1, 2):
+            b, right = idx[i]
+            left = idx[i + 1][1]
+            diffused[b, right + 1:left - 1] = 1
+            ab_loss_mask[b, max(right - 1, 0):min(left + 1, diffused.shape[1] - 1)] = 1
+    struc_loss_mask[:, :Lab] = ab_loss_mask
+    fixed_mask = 1 - diffused
+    if opt_step is None:
+        t = torch.ones((B,), device=dev, dtype=torch.float32)
+        feats = diffuser.sample_ref(n_samples=rigids_0.shape[:2], impute_rigids=rigids_0, impute_seq=seq_0,
+                                    diffuse_mask=diffused, noise=noise)
+    else:
+        step = (diff_conf or diffuser._diff_conf)['inference_step']
+        t = torch.full((B,), fill_value=opt_step / step, device=dev, dtype=torch.float32)
+        feats = diffuser.forward_marginal(rigids_0=rigids_0, seq_0=seq_0, t=t, diffuse_mask=diffused, noise=noise)
+    batch.update(feats)
+    batch.update(t=t, struc_loss_mask=struc_loss_mask, fixed_mask=fixed_mask, rigids_0=rigids_0)
+    return batch
+
+
+def build_features(batch, diffuser, generate_area='H3', opt_step=None, noise=None, device=None):
+    """The whole inference feature pipeline on a collated batch (config_data_feature.json order)."""
+    if device is not None:
+        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    batch = make_restype_atom_constants(batch)
+    batch = make_atom37_positions(batch)
+    batch.update(atom37_to_frames(batch['seq'], batch['atom37_gt_positions'], batch['atom37_gt_exists']))
+    batch.update(atom37_to_torsion_angles(batch['seq'], batch['atom37_gt_positions'], batch['atom37_gt_exists']))
+    batch['pseudo_beta'], batch['pseudo_beta_mask'] = pseudo_beta_fn(
+        batch['seq'], batch['atom37_gt_positions'], batch['atom37_gt_exists'])
+    return make_diffuser_features(batch, generate_area, diffuser, opt_step=opt_step, noise=noise)

@@ -1,0 +1,204 @@
+"""Pins the oracle (oracle/abx_oracle.py) and the host feature pipeline against vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, tt, feat_batch_from_golden
+from oracle import abx_oracle as O
+
+
+def close(a, b, atol, rtol=0.0, name=''):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    tol = atol + rtol * np.abs(b.astype(np.float64))
+    assert np.all(err <= tol), f'{name}: max err {err.max():.3e} (tol {atol}+{rtol}*|x|), max|x| {np.abs(b).max():.3e}'
+
+
+def test_features_match_reference(oracle_diffuser):
+    from abx_amd import features, synthetic
+    g = load_npz('feat_tiny.npz')
+    raw = {k[4:]: tt(v) for k, v in g.items() if k.startswith('raw.')}
+    # the synthetic builder is deterministic: the committed raw batch is what it produces today
+    w = synthetic.WORKLOADS['tiny']
+    again = synthetic.collate([synthetic.make_complex(seed=11, **w), synthetic.make_complex(seed=12, n_masked_tail=1, **w)])
+    for k in raw:
+        assert torch.equal(raw[k], again[k]), k
+    noise = {k[6:]: tt(v) for k, v in g.items() if k.startswith('noise.')}
+    out = features.build_features(dict(raw), oracle_diffuser, generate_area='H3', noise=noise)
+    for k in ('atom14_atom_exists', 'residx_atom37_to_atom14', 'atom37_atom_exists', 'atom37_gt_exists',
+              'rigidgroups_gt_exists', 'torsion_angles_mask', 'fixed_mask', 'struc_loss_mask', 'seq_t'):
+        assert np.array_equal(out[k].numpy(), g['feat.' + k]), k
+    close(out['atom37_gt_positions'], g['feat.atom37_gt_positions'], 0, name='atom37')
+    close(out['rigidgroups_gt_frames'][0], g['feat.rigidgroups_gt_frames.0'], 2e-6, name='frames R')
+    close(out['rigidgroups_gt_frames'][1], g['feat.rigidgroups_gt_frames.1'], 0, name='frames t')
+    close(out['torsion_angles_sin_cos'], g['feat.torsion_angles_sin_cos'], 2e-6, name='torsions')
+    close(out['pseudo_beta'], g['feat.pseudo_beta'], 0, name='pseudo_beta')
+    close(out['rigids_0'], g['feat.rigids_0'], 2e-6, name='rigids_0')
+    close(out['rigids_t'], g['feat.rigids_t'], 1e-5, rtol=1e-6, name='rigids_t')
+    close(out['t'], g['feat.t'], 0, name='t')
+    assert out['rigids_t'].dtype == torch.float32 and out['seq_t'].dtype == torch.int64
+
+
+def test_igso3_tables(oracle_diffuser):
+    g = load_npz('igso3_small.npz')
+    so3 = oracle_diffuser.so3
+    close(so3.discrete_sigma, g['big_sigma'], 0, name='sigma grid')
+    close(so3.discrete_omega, g['big_omega'], 0, name='omega grid')
+    i, j = g['spot_i'], g['spot_j']
+    close(so3._pdf[i, j], g['spot_pdf'], 1e-5, 1e-4, 'pdf spots')
+    close(so3._cdf[i, j], g['spot_cdf'], 1e-5, 1e-4, 'cdf spots')
+    rows = g['rows']
+    # score norms are a quotient of two cancelling 1000-term series: compare with an absolute floor
+    close(so3._score_norms[rows], g['rows_score_norms'], 2e-2, 1e-3, 'score_norm rows')
+    close(so3._score_scaling, g['big_score_scaling'], 1e-4, 1e-4, 'score scaling')
+    small = O.OracleSO3(dict(min_sigma=0.1, max_sigma=1.5, num_sigma=40, num_omega=40))
+    close(small._pdf, g['small_pdf'], 1e-5, 1e-4, 'small pdf')
+    close(small._cdf, g['small_cdf'], 1e-5, 1e-4, 'small cdf')
+    close(small._score_norms, g['small_score_norms'], 2e-2, 1e-3, 'small score norms')
+
+
+@pytest.fixture(scope='module')
+def pinned_diffuser(oracle_diffuser):
+    """Oracle diffuser whose score-norm/cdf rows used by the tiny tests are the REFERENCE's rows, so that the
+    piecewise-constant lookup (SURVEY §7 hard part 1) is compared on identical tables."""
+    g = load_npz('igso3_small.npz')
+    so3 = oracle_diffuser.so3
+    so3._score_norms = so3._score_norms.clone()
+    so3._cdf = so3._cdf.clone()
+    so3._score_norms[g['rows']] = tt(g['rows_score_norms'])
+    so3._cdf[g['rows']] = tt(g['rows_cdf'])
+    return oracle_diffuser
+
+
+def _state(m, feat):
+    b = dict(feat)
+    for k in ('seq_t', 'rigids_t', 't', 'prev_pos', 'prev_seq', 'prev_pair', 'rot_score_scaling', 'trans_score_scaling'):
+        b[k] = tt(m['in.' + k])
+    return b
+
+
+def test_modules_match_reference(params, cfg, pinned_diffuser):
+    m = load_npz('modules_tiny.npz')
+    feat = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    p = params
+    # final-pass inputs as the reference had them (after two recycles)
+    b = _state(m, feat)
+    b.update(seq_t=tt(m['final.seq_t_after']), prev_pos=tt(m['final.prev_pos_in']), prev_seq=tt(m['final.prev_seq_in']),
+             prev_pair=tt(m['final.prev_pair_in']))
+    mask = b['mask']
+    with torch.no_grad():
+        close(O.residue_embedding(p, b), m['enc_residue.out'], 2e-5, 1e-5, 'residue embedding')
+        close(O.pair_embedding(p, b, dict(cfg.model.embeddings_and_seqformer.prev_pos)), m['enc_pair.out'], 2e-5, 1e-5,
+              'pair embedding')
+        seq, pair = tt(m['block.seq_in']), tt(m['block.pair_in'])
+        s2, p2 = O.embed_and_seqformer(p, b, cfg)
+        d = O.seq_attention(p, seq, pair, mask)
+        close(d, m['seq_attn.out'], 2e-5, 1e-5, 'seq_attn')
+        seq = seq + tt(m['seq_attn.out'])
+        close(O.transition(p, O.P_BLK + 'seq_transition', seq), m['seq_transition.out'], 2e-5, 1e-5, 'seq_transition')
+        seq = seq + tt(m['seq_transition.out'])
+        close(O.outer_product_mean(p, seq, mask), m['opm.out'], 2e-5, 1e-5, 'opm')
+        pair = pair + tt(m['opm.out'])
+        close(O.triangle_multiplication(p, 'triangle_multiplication_outgoing', pair, mask, True), m['trimul_out.out'],
+              5e-5, 1e-5, 'trimul out')
+        pair = pair + tt(m['trimul_out.out'])
+        close(O.triangle_multiplication(p, 'triangle_multiplication_incoming', pair, mask, False), m['trimul_in.out'],
+              5e-5, 1e-5, 'trimul in')
+        pair = pair + tt(m['trimul_in.out'])
+        close(O.triangle_attention(p, 'triangle_attention_starting_node', pair, mask, True), m['triattn_start.out'],
+              2e-5, 1e-5, 'triattn start')
+        pair = pair + tt(m['triattn_start.out'])
+        close(O.triangle_attention(p, 'triangle_attention_ending_node', pair, mask, False), m['triattn_end.out'],
+              2e-5, 1e-5, 'triattn end')
+        pair = pair + tt(m['triattn_end.out'])
+        close(O.transition(p, O.P_BLK + 'pair_transition', pair), m['pair_transition.out'], 2e-5, 1e-5, 'pair_transition')
+        close(s2, m['out.seq'], 1e-4, 1e-5, 'trunk seq')
+        close(p2, m['out.pair'], 2e-4, 1e-5, 'trunk pair')
+        ipa = O.ipa_attention(p, tt(m['ipa0.in_1d']), tt(m['ipa0.in_2d']), mask.float(), tt(m['ipa0.rots']),
+                              tt(m['ipa0.trans']), cfg.model.heads.diffusion_module.IPA)
+        close(ipa, m['ipa0.out'], 5e-5, 1e-5, 'ipa layer 0')
+
+
+def test_full_call_matches_reference(params, cfg, pinned_diffuser):
+    """One in-loop ScoreNetwork call (2 recycles + final, fp64 t) incl. in-place batch mutation and get_prev."""
+    m = load_npz('modules_tiny.npz')
+    b = _state(m, feat_batch_from_golden(load_npz('feat_tiny.npz')))
+    assert b['t'].dtype == torch.float64
+    ret = O.score_network(params, b, cfg, pinned_diffuser)
+    f = ret['heads']['folding']
+    assert torch.equal(b['seq_t'], tt(m['final.seq_t_after']))
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'], tt(m['out.seq_0']))
+    close(f['rigids'], m['out.rigids'], 2e-4, 1e-5, 'rigids')
+    close(f['representations']['structure_module'], m['out.structure_module'], 2e-4, 1e-5, 'structure_module')
+    close(f['angles_sin_cos'], m['out.angles'], 2e-4, 0, 'angles')
+    close(f['final_atom14_positions'], m['out.atom14'], 5e-4, 1e-5, 'atom14')
+    close(f['final_atom_positions'], m['out.atom37'], 5e-4, 1e-5, 'atom37')
+    close(ret['heads']['sequence_module']['logits'], m['out.logits'], 2e-4, 1e-5, 'logits')
+    close(ret['heads']['predicted_lddt']['pLDDT'], m['out.pLDDT'], 2e-3, 1e-5, 'pLDDT')
+    assert f['trans_score'].dtype == torch.float64 and f['rot_score'].dtype == torch.float32
+    close(f['trans_score'], m['out.trans_score'], 2e-4, 1e-5, 'trans_score')
+    # rot_score is a piecewise-constant table lookup: allow the (rare) one-bucket disagreement
+    rs, rs_ref = f['rot_score'].numpy(), m['out.rot_score']
+    bad = np.abs(rs - rs_ref) > (2e-4 + 1e-4 * np.abs(rs_ref))
+    assert bad.reshape(-1, 3).any(axis=1).mean() <= 0.02, f'rot_score mismatches {bad.mean()}'
+    prev = O.get_prev(b, ret, cfg)
+    assert (prev['prev_pos'].numpy() != m['out.prev_pos']).mean() < 1e-3
+
+
+def test_warmup_call_fp32_t(params, cfg, pinned_diffuser):
+    """The self-conditioning warm-up call sees fp32 t and no prev_* (inference.py:209-211)."""
+    m = load_npz('modules_tiny.npz')
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    ones = torch.ones(b['seq'].shape[0])
+    b = O.set_t_feats(b, pinned_diffuser, np.linspace(0.01, 1.0, 100)[::-1][0], ones)
+    assert b['t'].dtype == torch.float32
+    ret = O.score_network(params, b, cfg, pinned_diffuser)
+    assert ret['heads']['folding']['trans_score'].dtype == torch.float32
+    close(ret['heads']['folding']['rigids'], m['warm.rigids'], 2e-4, 1e-5, 'warm rigids')
+    close(ret['heads']['sequence_module']['logits'], m['warm.logits'], 2e-4, 1e-5, 'warm logits')
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'], tt(m['warm.seq_0']))
+    close(ret['heads']['folding']['trans_score'], m['warm.trans_score'], 2e-4, 1e-4, 'warm trans_score')
+    b.update(O.get_prev(b, ret, cfg))
+    assert (b['prev_pos'].numpy() != m['warm.prev_pos']).mean() < 1e-3
+
+
+def test_reverse_step_matches_reference(cfg, pinned_diffuser):
+    s = load_npz('step_tiny.npz')
+    dm = tt(s['diffuse_mask'])
+    for i in range(3):
+        g = lambda k: tt(s[f's{i}.{k}'])
+        noise = dict(z_rot=g('z_rot'), z_trans=g('z_trans'), jumps=g('jumps'))
+        rig, seq = pinned_diffuser.reverse(rigid_t=g('rigid_in'), seq_t=g('seq_in'), rot_score=g('rot_score'),
+                                           trans_score=g('trans_score'), logits_t=g('logits'), t=g('t'), dt=tt(s['dt']),
+                                           diffuse_mask=dm, noise=noise)
+        assert rig.dtype == torch.float64 and seq.dtype == torch.int64
+        assert torch.equal(seq, g('seq_out')), f'step {i}: tokens differ'
+        close(rig, s[f's{i}.rigid_out'], 1e-9, 1e-9, f'step {i} rigids (fp64)')
+        rs, ts = pinned_diffuser.score_scaling(g('t'))
+        close(rs, s[f's{i}.rot_score_scaling'], 1e-4, 1e-4, 'rot score scaling')
+        close(ts, s[f's{i}.trans_score_scaling'], 1e-12, 1e-12, 'trans score scaling')
+        # Poisson rates: the closed-form transition matrix vs the reference's fp32 eigen-decomposition
+        rates, _ = pinned_diffuser.seq.reverse_rates(g('seq_in'), g('logits'), g('t'))
+        assert torch.all(rates >= 0)
+
+
+def test_short_trajectory_matches_reference(params, cfg, pinned_diffuser):
+    """The reference's own sample_fn (num_t=4, trajectory mode) vs the oracle driver under injected noise."""
+    tj = load_npz('traj_tiny.npz')
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+
+    def noise_fn(k):
+        return dict(z_rot=tt(tj[f'n{k}.z_rot']), z_trans=tt(tj[f'n{k}.z_trans']), jumps=tt(tj[f'n{k}.jumps']))
+
+    traj = O.sample_fn(params, b, cfg, pinned_diffuser, mode='trajectory', num_t=4, noise_fn=noise_fn)
+    assert len(traj) == 4
+    for k, d in enumerate(traj):
+        assert float(d['time']) == float(tj[f'k{k}.time'])
+        same = (d['seq'].numpy() == tj[f'k{k}.seq']).mean()
+        assert same == 1.0, f'step {k}: token agreement {same}'
+        close(d['atom14_results'], tj[f'k{k}.atom14'], 5e-3, 1e-4, f'step {k} atom14')
+        close(d['pLDDT'], tj[f'k{k}.pLDDT'], 1e-2, 1e-4, f'step {k} pLDDT')
+    close(traj[-1]['rigids_t'], tj['final.rigids_t'], 2e-3, 1e-4, 'final rigids')
