@@ -1,0 +1,139 @@
+"""ctypes binding of libabx_hip.so (C ABI declared in include/abx_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libabx_hip.so')
+
+c_f = C.c_void_p          # device pointers travel as integers
+LL = C.c_longlong
+I = C.c_int
+F = C.c_float
+
+
+class AbxGemm(C.Structure):
+    _fields_ = [
+        ('A', c_f), ('sAb', LL), ('sAm', LL), ('sAk', LL),
+        ('B', c_f), ('sBb', LL), ('sBk', LL), ('sBn', LL),
+        ('C', c_f), ('sCb', LL), ('sCm', LL),
+        ('M', I), ('N', I), ('K', I), ('batch', I),
+        ('c_transposed', I),
+        ('ln_stats', c_f), ('sSb', LL),
+        ('ln_gamma', c_f), ('ln_beta', c_f),
+        ('a_relu', I),
+        ('bias', c_f),
+        ('alpha', F),
+        ('act', I),
+        ('rowscale', c_f), ('sRSb', LL),
+        ('gate', c_f), ('sGb', LL), ('sGm', LL), ('gate_sigmoid', I),
+        ('resid', c_f), ('sRb', LL), ('sRm', LL),
+        ('a_vec_ok', I), ('b_vec_ok', I), ('c_vec_ok', I), ('force_a_mcontig', I),
+    ]
+
+
+class AbxTriAttn(C.Structure):
+    _fields_ = [
+        ('q', c_f), ('k', c_f), ('v', c_f), ('gate', c_f),
+        ('sb', LL), ('ss', LL), ('sl', LL),
+        ('bias', c_f), ('bias_sb', LL), ('bias_sh', LL), ('bias_sq', LL), ('bias_sk', LL),
+        ('keymask', c_f), ('km_sb', LL),
+        ('out', c_f), ('ob', LL), ('os', LL), ('ol', LL),
+        ('B', I), ('S', I), ('L', I), ('H', I), ('D', I),
+        ('scale', F),
+    ]
+
+
+class AbxScoreArgs(C.Structure):
+    _fields_ = [
+        ('init_q', c_f), ('init_t', c_f), ('delta_q', c_f), ('cur_t', c_f), ('fixed_mask', c_f),
+        ('t', c_f), ('t_is_f32', I),
+        ('score_norms', c_f), ('num_sigma', I), ('num_omega', I), ('discrete_sigma', c_f), ('discrete_omega', c_f),
+        ('exp_max_sigma', F), ('exp_min_sigma', F),
+        ('min_b', F), ('bdiff', F),
+        ('coord_scale', F),
+        ('position_scale', F),
+        ('rot_score', c_f), ('trans_score', c_f), ('rigids', c_f),
+        ('B', I), ('L', I),
+    ]
+
+
+class AbxReverseArgs(C.Structure):
+    _fields_ = [
+        ('rigid_in', c_f), ('rigid_is_f64', I),
+        ('seq_in', c_f),
+        ('rot_score', c_f), ('trans_score', c_f), ('ts_is_f32', I), ('logits', c_f),
+        ('diffuse_mask', c_f), ('t', c_f), ('dt', F),
+        ('z_rot', c_f), ('z_trans', c_f), ('jumps', c_f),
+        ('seed', C.c_ulonglong), ('sample_ids', c_f), ('step', I),
+        ('exp_max_sigma', F), ('exp_min_sigma', F), ('min_b', F), ('bdiff', F), ('coord_scale', F), ('rate_const', F),
+        ('noise_scale', F), ('center', I),
+        ('rigid_out', c_f), ('seq_out', c_f), ('rates_out', c_f),
+        ('B', I), ('L', I),
+    ]
+
+
+_S = c_f   # hipStream_t
+
+_PROTOS = {
+    'abx_version': (I, []),
+    'abx_last_error_string': (C.c_char_p, []),
+    'abx_init': (I, [I]),
+    'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
+    'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),
+    'abx_layernorm': (I, [c_f, LL, LL, I, c_f, c_f, F, c_f, LL, c_f, LL, _S]),
+    'abx_tri_attn_fwd': (I, [C.POINTER(AbxTriAttn), _S]),
+    'abx_seq_attn_fwd': (I, [c_f, c_f, c_f, c_f, c_f, I, I, I, I, F, _S]),
+    'abx_ipa_pack': (I, [c_f, c_f, c_f, c_f, c_f, c_f, I, I, F, _S]),
+    'abx_ipa_attn': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
+    'abx_timestep_embedding': (I, [c_f, I, I, c_f, _S]),
+    'abx_assemble_seq': (I, [c_f, LL, c_f, c_f, I, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
+    'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
+    'abx_opm_features': (I, [c_f, c_f, LL, c_f, I, I, I, _S]),
+    'abx_pair_mask': (I, [c_f, c_f, I, I, _S]),
+    'abx_pair_embed_features': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
+    'abx_relpos_block': (I, [c_f, c_f, c_f, I, I, I, I, I, _S]),
+    'abx_gather_rows': (I, [c_f, c_f, c_f, c_f, LL, LL, I, _S]),
+    'abx_frames_init': (I, [c_f, I, c_f, c_f, c_f, c_f, c_f, c_f, I, F, _S]),
+    'abx_rigid_update': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, F, _S]),
+    'abx_scores': (I, [C.POINTER(AbxScoreArgs), _S]),
+    'abx_torsion_finalize': (I, [c_f, c_f, c_f, c_f, I, _S]),
+    'abx_seq_head_atoms': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, _S]),
+    'abx_prev_pos': (I, [c_f, c_f, I, c_f, I, I, _S]),
+    'abx_plddt': (I, [c_f, c_f, I, I, _S]),
+    'abx_igso3_tables': (I, [c_f, c_f, I, I, I, c_f, c_f, c_f, _S]),
+    'abx_reverse_step': (I, [C.POINTER(AbxReverseArgs), _S]),
+}
+
+EXPORTED = tuple(_PROTOS)
+_lib = None
+
+
+class AbxHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (raises if it has not been built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AbxHipError(f'{LIB_PATH} not found: build it with `make -C abx_amd/csrc` (no CPU fallback exists)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.abx_version() != 1:
+        raise AbxHipError('libabx_hip ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().abx_last_error_string()
+        raise AbxHipError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')

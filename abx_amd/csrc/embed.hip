@@ -1,0 +1,304 @@
+// Embedding assembly and the small gather/elementwise stages around the pair stack.
+// Reference sites: abx/model/seqformer.py:49-119 (timestep embedding, Embedder), :170-223 (EmbeddingAndSeqformer.forward),
+// :400-409 (OuterProductMean features), abx/model/encoder.py:123-269 (Residue/PairEmbedding gathers).
+#include "common.h"
+#include "abx_hip.h"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const double* __restrict__ t, int B, int dim, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx % half;
+    // seqformer.py:56-62: timesteps * 10000 in t's own dtype (double in the loop), THEN .float(); frequencies in fp32
+    const float tt = (float)(t[b] * 10000.0);
+    const float e = (float)(9.210340371976184 / (double)(half - 1));     // math.log(10000) / (half - 1), then fp32 mul
+    const float f = expf((float)i * -e);
+    const float arg = tt * f;
+    out[b * dim + i] = sinf(arg);
+    out[b * dim + half + i] = cosf(arg);
+}
+
+// one wave per (b,l) row; C = static channels (512), E = time-embedding width (32); LN over C+E of prev_seq.
+__global__ __launch_bounds__(256) void assemble_seq_kernel(const float* __restrict__ seq_static, long long ss_b,
+                                                           const float* __restrict__ aa_table,
+                                                           const long long* __restrict__ seq_t, int Lab,
+                                                           const float* __restrict__ temb, const float* __restrict__ prev,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ out, int B, int L, int C, int E) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * L) return;
+    const int b = (int)(row / L), l = (int)(row % L);
+    const int W = C + E;
+    float mean = 0.f, rstd = 0.f;
+    const float* pr = prev ? prev + row * W : nullptr;
+    if (pr) {
+        float s = 0.f;
+        for (int k = lane; k < W; k += 64) s += pr[k];
+        mean = wave_sum(s) / (float)W;
+        float q = 0.f;
+        for (int k = lane; k < W; k += 64) {
+            const float d = pr[k] - mean;
+            q += d * d;
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+    }
+    const float* st = seq_static + (long long)b * ss_b + (long long)l * C;
+    const float* aa = (l < Lab) ? aa_table + seq_t[row] * C : nullptr;
+    for (int k = lane; k < W; k += 64) {
+        float v;
+        if (k < C) {
+            v = st[k];
+            if (aa) v = v + aa[k];
+        } else {
+            v = temb[b * E + (k - C)];
+        }
+        if (pr) v += (pr[k] - mean) * rstd * gamma[k] + beta[k];
+        out[row * W + k] = v;
+    }
+}
+
+// one wave per (b,i,j) row; W = C + 2E = 192 handled as W/64 = 3 elements per lane.
+__global__ __launch_bounds__(256) void assemble_pair_kernel(const float* __restrict__ pair_static, long long ps_b,
+                                                            const float* __restrict__ temb, const float* __restrict__ prev,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const long long* __restrict__ prev_pos,
+                                                            const float* __restrict__ pos_table, float* __restrict__ out,
+                                                            long long rows, long long LL, int C, int E) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / LL);
+    const long long ij = row % LL;
+    const int W = C + 2 * E;
+    float x[4];                                   // W <= 256
+    const float* pr = prev ? prev + row * W : nullptr;
+    float mean = 0.f, rstd = 0.f;
+    if (pr) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + u * 64;
+            x[u] = k < W ? pr[k] : 0.f;
+            s += x[u];
+        }
+        mean = wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + u * 64;
+            const float d = k < W ? x[u] - mean : 0.f;
+            q += d * d;
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-5f);
+    }
+    const float* st = pair_static + (long long)b * ps_b + ij * C;
+    const float* pt = prev_pos ? pos_table + prev_pos[row] * W : nullptr;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = lane + u * 64;
+        if (k >= W) continue;
+        float v = k < C ? st[k] : temb[b * E + ((k - C) % E)];
+        if (pr) v += (x[u] - mean) * rstd * gamma[k] + beta[k];
+        if (pt) v += pt[k];
+        out[row * W + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void opm_features_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                           long long ld, float* __restrict__ feat, int B, int L, int C) {
+    // thread per (b,i,j,c): feat[...,c] = left[b,j,c]*right[b,i,c]; feat[...,C+c] = left[b,j,c]-right[b,i,c]
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * L * L * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long p = idx / C;
+    const int j = (int)(p % L);
+    const long long bi = p / L;
+    const int b = (int)(bi / L);
+    const float lv = left[((long long)b * L + j) * ld + c], rv = right[bi * ld + c];
+    feat[p * 2 * C + c] = lv * rv;
+    feat[p * 2 * C + C + c] = lv - rv;
+}
+
+__global__ void pair_mask_kernel(const float* __restrict__ mask, float* __restrict__ out, int B, int L) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * L * L) return;
+    const int j = (int)(idx % L);
+    const long long bi = idx / L;
+    const int b = (int)(bi / L);
+    out[idx] = mask[bi] * mask[(long long)b * L + j];
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx,
+                                                          const float* __restrict__ rowscale, float* __restrict__ out,
+                                                          long long s_out, long long n, int C) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * C) return;
+    const long long r = t / C;
+    const int c = (int)(t % C);
+    float v = table[idx[r] * C + c];
+    if (rowscale) v *= rowscale[r];
+    out[r * s_out + c] = v;
+}
+
+// relative-position block embedding (seqformer.py:181-206): antibody x antibody and antigen x antigen blocks, zero off-block.
+__global__ __launch_bounds__(256) void relpos_block_kernel(const int* __restrict__ residx, const float* __restrict__ table,
+                                                           float* __restrict__ out, int B, int L, int Lab, int C, int max_rel) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * L * L * C) return;
+    const int c = (int)(t % C);
+    const long long p = t / C;
+    const int j = (int)(p % L);
+    const long long bi = p / L;
+    const int i = (int)(bi % L), b = (int)(bi / L);
+    float v = 0.f;
+    if ((i < Lab) == (j < Lab)) {
+        int off = residx[(long long)b * L + j] - residx[(long long)b * L + i] + max_rel;
+        off = min(max(off, 0), 2 * max_rel) + 1;
+        v = table[(long long)off * C + c];
+    }
+    out[t] = v;
+}
+
+__device__ __forceinline__ void pseudo_beta(const float* n, const float* ca, const float* c, float* cb) {
+    const float bx = ca[0] - n[0], by = ca[1] - n[1], bz = ca[2] - n[2];
+    const float cx = c[0] - ca[0], cy = c[1] - ca[1], cz = c[2] - ca[2];
+    const float ax = by * cz - bz * cy, ay = bz * cx - bx * cz, az = bx * cy - by * cx;
+    cb[0] = -0.58273431f * ax + 0.56802827f * bx - 0.54067466f * cx + ca[0];
+    cb[1] = -0.58273431f * ay + 0.56802827f * by - 0.54067466f * cy + ca[1];
+    cb[2] = -0.58273431f * az + 0.56802827f * bz - 0.54067466f * cz + ca[2];
+}
+
+// PairEmbedding gather stage (encoder.py:231-262): one workgroup per (b,i,j).
+//  feat512[0:128]   = aa_pair_embed[aa_i*23 + aa_j]
+//  feat512[128:256] = relpos_embed[clamp(residx_i - residx_j, -32, 32) + 32] * same_chain
+//  feat512[256:384] : left for the distance MLP (written by abx_gemm)
+//  feat512[384:512] = dgram_embed[bin(|CB_i - CB_j|^2)]
+//  dist196[a*14+a'] = exp(-softplus(coef[aa_pair][a*14+a']) * (|x_ia - x_ja'| / 10)^2) * CA_i_exists * CA_j_exists
+__global__ __launch_bounds__(256) void pair_embed_features_kernel(
+    const long long* __restrict__ aa, const int* __restrict__ chain_id, const int* __restrict__ residx,
+    const float* __restrict__ atom14, const unsigned char* __restrict__ exists, const float* __restrict__ aa_pair_embed,
+    const float* __restrict__ relpos_embed, const float* __restrict__ distcoef, const float* __restrict__ dgram_embed,
+    const float* __restrict__ sq_breaks, float* __restrict__ feat512, float* __restrict__ dist196, int B, int L) {
+    const long long p = blockIdx.x;                       // (b*L + i)*L + j
+    const int j = (int)(p % L);
+    const long long bi = p / L;
+    const int b = (int)(bi / L);
+    const long long bj = (long long)b * L + j;
+    const int tid = threadIdx.x;
+    const long long aap = aa[bi] * 23 + aa[bj];
+    __shared__ float xi[42], xj[42];
+    if (tid < 42) xi[tid] = atom14[bi * 42 + tid];
+    else if (tid >= 64 && tid < 106) xj[tid - 64] = atom14[bj * 42 + (tid - 64)];
+    __syncthreads();
+    float* f = feat512 + p * 512;
+    if (tid < 128) {
+        f[tid] = aa_pair_embed[aap * 128 + tid];
+    } else {
+        const int c = tid - 128;
+        int rel = residx[bi] - residx[bj];
+        rel = min(max(rel, -32), 32) + 32;
+        const float same = chain_id[bi] == chain_id[bj] ? 1.f : 0.f;
+        f[128 + c] = relpos_embed[rel * 128 + c] * same;
+        float cbi[3], cbj[3];
+        pseudo_beta(xi, xi + 3, xi + 6, cbi);
+        pseudo_beta(xj, xj + 3, xj + 6, cbj);
+        const float dx = cbi[0] - cbj[0], dy = cbi[1] - cbj[1], dz = cbi[2] - cbj[2];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        int bin = 0;
+        // sq_breaks = square(linspace(3.375, 21.375, 14)) as torch computes it on the host (common_modules.py:108-109)
+#pragma unroll
+        for (int k = 0; k < 14; ++k) bin += d2 > sq_breaks[k] ? 1 : 0;
+        f[384 + c] = dgram_embed[bin * 128 + c];
+    }
+    if (tid < 196) {
+        const int a = tid / 14, a2 = tid % 14;
+        const float dx = xi[a * 3] - xj[a2 * 3], dy = xi[a * 3 + 1] - xj[a2 * 3 + 1], dz = xi[a * 3 + 2] - xj[a2 * 3 + 2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz) / 10.0f;
+        const float w = distcoef[aap * 196 + tid];
+        const float sp = w > 20.f ? w : log1pf(expf(w));            // torch softplus (beta 1, threshold 20)
+        const float m = (exists[bi * 14 + 1] && exists[bj * 14 + 1]) ? 1.f : 0.f;
+        dist196[p * 196 + tid] = expf(-1.0f * sp * (d * d)) * m;
+    }
+}
+
+}  // namespace
+
+extern "C" int abx_timestep_embedding(const double* t, int B, int dim, float* out, hipStream_t st) {
+    ABX_REQUIRE(t && out && B > 0 && dim >= 4 && dim % 2 == 0, "abx_timestep_embedding: bad args");
+    const int n = B * dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 127) / 128), dim3(128), 0, st, t, B, dim, out);
+    return abx_check_launch("abx_timestep_embedding");
+}
+
+extern "C" int abx_assemble_seq(const float* seq_static, long long ss_b, const float* aa_table, const long long* seq_t, int Lab,
+                                const float* temb, const float* prev_seq, const float* gamma, const float* beta, float* out,
+                                int B, int L, int C, int E, hipStream_t st) {
+    ABX_REQUIRE(seq_static && aa_table && seq_t && temb && out && B > 0 && L > 0, "abx_assemble_seq: bad args");
+    ABX_REQUIRE(!prev_seq || (gamma && beta), "abx_assemble_seq: LN params missing");
+    const long long rows = (long long)B * L;
+    hipLaunchKernelGGL(assemble_seq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, seq_static, ss_b, aa_table, seq_t,
+                       Lab, temb, prev_seq, gamma, beta, out, B, L, C, E);
+    return abx_check_launch("abx_assemble_seq");
+}
+
+extern "C" int abx_assemble_pair(const float* pair_static, long long ps_b, const float* temb, const float* prev_pair,
+                                 const float* gamma, const float* beta, const long long* prev_pos, const float* pos_table,
+                                 float* out, int B, int L, int C, int E, hipStream_t st) {
+    ABX_REQUIRE(pair_static && temb && out && B > 0 && L > 0, "abx_assemble_pair: bad args");
+    ABX_REQUIRE(C + 2 * E <= 256, "abx_assemble_pair: width > 256");
+    ABX_REQUIRE(!prev_pair || (gamma && beta), "abx_assemble_pair: LN params missing");
+    ABX_REQUIRE(!prev_pos || pos_table, "abx_assemble_pair: pos table missing");
+    const long long rows = (long long)B * L * L;
+    hipLaunchKernelGGL(assemble_pair_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pair_static, ps_b, temb,
+                       prev_pair, gamma, beta, prev_pos, pos_table, out, rows, (long long)L * L, C, E);
+    return abx_check_launch("abx_assemble_pair");
+}
+
+extern "C" int abx_opm_features(const float* left, const float* right, long long ld, float* feat, int B, int L, int C,
+                                hipStream_t st) {
+    ABX_REQUIRE(left && right && feat && B > 0 && L > 0 && C > 0, "abx_opm_features: bad args");
+    const long long total = (long long)B * L * L * C;
+    hipLaunchKernelGGL(opm_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, left, right, ld, feat, B, L, C);
+    return abx_check_launch("abx_opm_features");
+}
+
+extern "C" int abx_pair_mask(const float* mask, float* out, int B, int L, hipStream_t st) {
+    ABX_REQUIRE(mask && out && B > 0 && L > 0, "abx_pair_mask: bad args");
+    const long long total = (long long)B * L * L;
+    hipLaunchKernelGGL(pair_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mask, out, B, L);
+    return abx_check_launch("abx_pair_mask");
+}
+
+extern "C" int abx_gather_rows(const float* table, const long long* idx, const float* rowscale, float* out, long long s_out,
+                               long long n, int C, hipStream_t st) {
+    ABX_REQUIRE(table && idx && out && n > 0 && C > 0, "abx_gather_rows: bad args");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * C + 255) / 256)), dim3(256), 0, st, table, idx, rowscale, out,
+                       s_out, n, C);
+    return abx_check_launch("abx_gather_rows");
+}
+
+extern "C" int abx_relpos_block(const int* residx, const float* table, float* out, int B, int L, int Lab, int C, int max_rel,
+                                hipStream_t st) {
+    ABX_REQUIRE(residx && table && out && B > 0 && L > 0, "abx_relpos_block: bad args");
+    const long long total = (long long)B * L * L * C;
+    hipLaunchKernelGGL(relpos_block_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, residx, table, out, B, L,
+                       Lab, C, max_rel);
+    return abx_check_launch("abx_relpos_block");
+}
+
+extern "C" int abx_pair_embed_features(const long long* aa, const int* chain_id, const int* residx, const float* atom14,
+                                       const unsigned char* atom14_exists, const float* aa_pair_embed, const float* relpos_embed,
+                                       const float* distcoef, const float* dgram_embed, const float* sq_breaks, float* feat512,
+                                       float* dist196, int B, int L, hipStream_t st) {
+    ABX_REQUIRE(aa && chain_id && residx && atom14 && atom14_exists && aa_pair_embed && relpos_embed && distcoef && dgram_embed &&
+                    sq_breaks && feat512 && dist196 && B > 0 && L > 0, "abx_pair_embed_features: bad args");
+    const long long blocks = (long long)B * L * L;
+    ABX_REQUIRE(blocks < (1ll << 31), "abx_pair_embed_features: too many pairs");
+    hipLaunchKernelGGL(pair_embed_features_kernel, dim3((unsigned)blocks), dim3(256), 0, st, aa, chain_id, residx, atom14,
+                       atom14_exists, aa_pair_embed, relpos_embed, distcoef, dgram_embed, sq_breaks, feat512, dist196, B, L);
+    return abx_check_launch("abx_pair_embed_features");
+}

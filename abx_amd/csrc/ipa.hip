@@ -1,0 +1,258 @@
+// Invariant Point Attention core (reference abx/model/folding.py:47-132), the kernel BASELINE's north_star names:
+// coalesced streaming of the (B, L, L, 128) pair slab, LDS-resident logits, wavefront-shuffle softmax reductions.
+//
+//  abx_ipa_pack : one thread per (residue, head): local points -> global frame (r3.rigids_apply, r3.py:9-16) and repack
+//                 the fused projection row into per-head contiguous records so the attention kernel reads them coalesced:
+//                    Q[b][i][h][28] = [ q_scalar*w_s (16) | q_point_global (4x3) ]
+//                    K[b][h][j][28] = [ k_scalar (16)     | k_point_global (4x3) ]
+//                    V[b][h][j][40] = [ v_scalar (16)     | v_point_global (8x3) ]
+//  abx_ipa_attn : one workgroup per (b, group of IQ=4 query residues).
+//     phase A  logits[iq][h][j] = q.k + pw[h] * sum|q_pt - k_pt|^2 + bias2d[b,i,j,h]  (direct (q-k)^2 as the reference,
+//              not the expanded form: no cancellation at |x| ~ 10), mask fill finfo.min, into LDS laid out [iq][j][13]
+//     softmax  one wave per (iq, h) row: shuffle max / sum
+//     phase B1 scalar + point outputs: thread per (h, c<40), 4 accumulators (iq)
+//     phase B2 attention over the pair slab: thread per (channel c, head half): streams z[b,i,j,0:128] exactly once per
+//              query residue (512 B coalesced per j), 6 FMAs per loaded float -> HBM-bound (33.6 MB / sample / layer at L=256)
+//     tail     points back to the local frame (r3.invert_rigids, r3.py:54-59), norms sqrt(sum^2 + 1e-8), concat
+//              [scalar 192 | points '(r n)' 288 | norms 96 | pair 1536] = 2112 floats per residue.
+#include "common.h"
+#include "abx_hip.h"
+
+namespace {
+
+constexpr int H = 12, SQK = 16, SV = 16, PQK = 4, PV = 8, CZ = 128;
+constexpr int QREC = SQK + 3 * PQK;          // 28
+constexpr int VREC = SV + 3 * PV;            // 40
+constexpr int NPROJ = H * SQK + H * (SQK + SV) + 3 * H * PQK + 3 * H * (PQK + PV);   // 1152
+constexpr int OFF_KV = H * SQK;              // 192
+constexpr int OFF_QP = OFF_KV + H * (SQK + SV);      // 576
+constexpr int OFF_KVP = OFF_QP + 3 * H * PQK;        // 720
+constexpr int NFEAT = H * SV + 3 * H * PV + H * PV + H * CZ;   // 2112
+constexpr int IQ = 4;
+constexpr int LDH = 13;                      // logits row stride over heads: odd -> lane<->j accesses are conflict-free
+
+__global__ __launch_bounds__(256) void ipa_pack_kernel(const float* __restrict__ proj, const float* __restrict__ rots,
+                                                       const float* __restrict__ trans, float* __restrict__ qpack,
+                                                       float* __restrict__ kpack, float* __restrict__ vpack, int B, int L,
+                                                       float w_s) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * L * H) return;
+    const int h = (int)(idx % H);
+    const long long row = idx / H;              // b*L + l
+    const int b = (int)(row / L), l = (int)(row % L);
+    const float* p = proj + row * NPROJ;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = rots[row * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = trans[row * 3 + i];
+    float* q = qpack + (row * H + h) * QREC;
+    float* k = kpack + (((long long)b * H + h) * L + l) * QREC;
+    float* v = vpack + (((long long)b * H + h) * L + l) * VREC;
+#pragma unroll
+    for (int c = 0; c < SQK; ++c) {
+        q[c] = p[h * SQK + c] * w_s;
+        k[c] = p[OFF_KV + h * (SQK + SV) + c];
+        v[c] = p[OFF_KV + h * (SQK + SV) + SQK + c];
+    }
+    // points: channel layout '(r n)': r*N + n, n = h*P + pt
+#pragma unroll
+    for (int pt = 0; pt < PQK; ++pt) {
+        float x[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) x[r] = p[OFF_QP + r * (H * PQK) + h * PQK + pt];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) q[SQK + pt * 3 + r] = t[r] + (R[r * 3 + 0] * x[0] + R[r * 3 + 1] * x[1] + R[r * 3 + 2] * x[2]);
+    }
+#pragma unroll
+    for (int pt = 0; pt < PQK + PV; ++pt) {
+        float x[3], y[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) x[r] = p[OFF_KVP + r * (H * (PQK + PV)) + h * (PQK + PV) + pt];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) y[r] = t[r] + (R[r * 3 + 0] * x[0] + R[r * 3 + 1] * x[1] + R[r * 3 + 2] * x[2]);
+        if (pt < PQK) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) k[SQK + pt * 3 + r] = y[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) v[SV + (pt - PQK) * 3 + r] = y[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ipa_attn_kernel(const float* __restrict__ qpack, const float* __restrict__ kpack,
+                                                       const float* __restrict__ vpack, const float* __restrict__ bias2d,
+                                                       const float* __restrict__ z, const float* __restrict__ mask,
+                                                       const float* __restrict__ rots, const float* __restrict__ trans,
+                                                       const float* __restrict__ pw, float* __restrict__ feat, int B, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lg = smem;                                   // [IQ][L][LDH]
+    float* qs = smem + (size_t)IQ * L * LDH;            // [IQ][H][QREC]
+    float* opt = qs + IQ * H * QREC;                    // [IQ][H][VREC] scalar+point outputs (global frame)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int i0 = blockIdx.x * IQ;
+    const int niq = min(IQ, L - i0);
+
+    for (int idx = tid; idx < IQ * H * QREC; idx += 256) {
+        const int iq = idx / (H * QREC);
+        qs[idx] = iq < niq ? qpack[((long long)b * L + i0) * H * QREC + idx] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- phase A: logits -------------------------------------------------------------------------------------
+    float pwh[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) pwh[h] = pw[h];
+    for (int j = tid; j < L; j += 256) {
+        const float mj = mask[(long long)b * L + j];
+        for (int h = 0; h < H; ++h) {
+            const float* kr = kpack + (((long long)b * H + h) * L + j) * QREC;
+            float kv[QREC];
+#pragma unroll
+            for (int c4 = 0; c4 < QREC / 4; ++c4) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(kr + c4 * 4);
+                kv[c4 * 4] = t4[0]; kv[c4 * 4 + 1] = t4[1]; kv[c4 * 4 + 2] = t4[2]; kv[c4 * 4 + 3] = t4[3];
+            }
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) {
+                const float* qr = qs + (iq * H + h) * QREC;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < SQK; ++c) s = fmaf(qr[c], kv[c], s);
+                float d2 = 0.f;
+#pragma unroll
+                for (int c = SQK; c < QREC; ++c) {
+                    const float d = qr[c] - kv[c];
+                    d2 = fmaf(d, d, d2);
+                }
+                float v = s + pwh[h] * d2;
+                if (iq < niq) {
+                    v += bias2d[(((long long)b * L + i0 + iq) * L + j) * H + h];
+                    const float mi = mask[(long long)b * L + i0 + iq];
+                    if (mi * mj == 0.f) v = ABX_NEG_MAX;
+                }
+                lg[((size_t)iq * L + j) * LDH + h] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax over j for each (iq, h): 48 rows over 4 waves ------------------------------------------------
+    for (int row = wave; row < IQ * H; row += 4) {
+        const int iq = row / H, h = row % H;
+        float* r = lg + (size_t)iq * L * LDH + h;
+        float mx = -INFINITY;
+        for (int j = lane; j < L; j += 64) mx = fmaxf(mx, r[(size_t)j * LDH]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int j = lane; j < L; j += 64) {
+            const float e = expf(r[(size_t)j * LDH] - mx);
+            r[(size_t)j * LDH] = e;
+            sm += e;
+        }
+        sm = wave_sum(sm);
+        const float inv = 1.0f / sm;
+        for (int j = lane; j < L; j += 64) r[(size_t)j * LDH] *= inv;
+    }
+    __syncthreads();
+    // ---- phase B1: scalar + point outputs, item = (h, c) ----------------------------------------------------------
+    for (int item = tid; item < H * VREC; item += 256) {
+        const int h = item / VREC, c = item % VREC;
+        float acc[IQ] = {0.f, 0.f, 0.f, 0.f};
+        const float* vb = vpack + ((long long)b * H + h) * L * VREC + c;
+        for (int j = 0; j < L; ++j) {
+            const float vv = vb[(long long)j * VREC];
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) acc[iq] = fmaf(lg[((size_t)iq * L + j) * LDH + h], vv, acc[iq]);
+        }
+#pragma unroll
+        for (int iq = 0; iq < IQ; ++iq) opt[(iq * H + h) * VREC + c] = acc[iq];
+    }
+    // ---- phase B2: attention over the pair slab ---------------------------------------------------------------------
+    {
+        const int c = tid & (CZ - 1), hg = tid >> 7;       // heads hg*6 .. hg*6+5
+        for (int iq = 0; iq < niq; ++iq) {
+            const float* zr = z + (((long long)b * L + i0 + iq) * L) * CZ + c;
+            const float* ar = lg + (size_t)iq * L * LDH + hg * 6;
+            float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int j = 0;
+            for (; j + 4 <= L; j += 4) {
+                float zv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) zv[u] = zr[(long long)(j + u) * CZ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* a6 = ar + (size_t)(j + u) * LDH;
+#pragma unroll
+                    for (int hh = 0; hh < 6; ++hh) acc[hh] = fmaf(a6[hh], zv[u], acc[hh]);
+                }
+            }
+            for (; j < L; ++j) {
+                const float zv = zr[(long long)j * CZ];
+                const float* a6 = ar + (size_t)j * LDH;
+#pragma unroll
+                for (int hh = 0; hh < 6; ++hh) acc[hh] = fmaf(a6[hh], zv, acc[hh]);
+            }
+            float* fo = feat + ((long long)b * L + i0 + iq) * NFEAT + (H * SV + 4 * H * PV);
+#pragma unroll
+            for (int hh = 0; hh < 6; ++hh) fo[(hg * 6 + hh) * CZ + c] = acc[hh];
+        }
+    }
+    __syncthreads();
+    // ---- tail: scalar copy, points to the local frame, norms ----------------------------------------------------------
+    for (int idx = tid; idx < IQ * H * SV; idx += 256) {
+        const int iq = idx / (H * SV), r = idx % (H * SV);
+        if (iq < niq) feat[((long long)b * L + i0 + iq) * NFEAT + r] = opt[(iq * H + r / SV) * VREC + (r % SV)];
+    }
+    for (int idx = tid; idx < IQ * H * PV; idx += 256) {
+        const int iq = idx / (H * PV), n = idx % (H * PV);
+        if (iq >= niq) continue;
+        const int h = n / PV, pt = n % PV;
+        const long long row = (long long)b * L + i0 + iq;
+        const float* R = rots + row * 9;
+        const float* t = trans + row * 3;
+        const float* g = opt + (iq * H + h) * VREC + SV + pt * 3;
+        // invert_rigids: R^T, -R^T t ; apply: R^T g + (-R^T t)   (same association as the reference)
+        float loc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float it = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
+            loc[r] = it + (R[0 * 3 + r] * g[0] + R[1 * 3 + r] * g[1] + R[2 * 3 + r] * g[2]);
+        }
+        float* fo = feat + row * NFEAT;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) fo[H * SV + r * (H * PV) + n] = loc[r];
+        fo[H * SV + 3 * H * PV + n] = sqrtf(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2] + 1e-8f);
+    }
+}
+
+}  // namespace
+
+extern "C" int abx_ipa_pack(const float* proj, const float* rots, const float* trans, float* qpack, float* kpack,
+                            float* vpack, int B, int L, float scalar_weight, hipStream_t st) {
+    ABX_REQUIRE(proj && rots && trans && qpack && kpack && vpack && B > 0 && L > 0, "abx_ipa_pack: bad args");
+    const long long n = (long long)B * L * H;
+    hipLaunchKernelGGL(ipa_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, proj, rots, trans, qpack, kpack,
+                       vpack, B, L, scalar_weight);
+    return abx_check_launch("abx_ipa_pack");
+}
+
+extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
+                            const float* mask, const float* rots, const float* trans, const float* point_weights, float* feat,
+                            int B, int L, hipStream_t st) {
+    ABX_REQUIRE(qpack && kpack && vpack && bias2d && z && mask && rots && trans && point_weights && feat, "abx_ipa_attn: null");
+    ABX_REQUIRE(B > 0 && L > 0 && B <= 65535, "abx_ipa_attn: bad sizes");
+    const size_t lds = ((size_t)IQ * L * LDH + IQ * H * QREC + IQ * H * VREC) * sizeof(float);
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_attn: L too large for LDS-resident logits");
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) { abx_set_error("abx_ipa_attn: hipFuncSetAttribute failed"); return (int)e; }
+        configured = true;
+    }
+    hipLaunchKernelGGL(ipa_attn_kernel, dim3((L + IQ - 1) / IQ, B), dim3(256), lds, st, qpack, kpack, vpack, bias2d, z, mask,
+                       rots, trans, point_weights, feat, B, L);
+    return abx_check_launch("abx_ipa_attn");
+}

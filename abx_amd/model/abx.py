@@ -1,0 +1,149 @@
+"""Drop-in for the reference's `abx.model.abx` (abx/model/abx.py:17-104): `ScoreNetwork` and `get_prev` with the same
+constructor, call signature, batch keys read / mutated in place, output dictionary and state_dict layout — computed by the
+HIP kernels of libabx_hip.so (no PyTorch/CPU fallback: a missing library raises).
+
+Extensions (all optional, default = reference behaviour):
+  batch['_shared_context'] = True   the B samples are copies of ONE complex -> trajectory-invariant embeddings are built once
+  ScoreNetwork.max_chunk            samples processed per pass through the pair stack (workspace size)
+"""
+import torch
+from torch import nn
+
+from abx_amd import _lib
+from abx_amd.model.modules import ScoreNetworkIteration
+from abx_amd.model.forward import Engine, Packed
+
+
+def get_prev(batch, value, config):
+    """abx.py:17-26.  The distogram of the virtual C-beta atoms is produced by the network pass itself
+    (abx_prev_pos kernel) and travels in `value['_prev_pos']`; representations are returned by reference, as upstream."""
+    return {
+        'prev_pos': value['_prev_pos'],
+        'prev_seq': value['representations']['seq'],
+        'prev_pair': value['representations']['pair'],
+    }
+
+
+class ScoreNetwork(nn.Module):
+    def __init__(self, model_conf, diffuser):
+        super().__init__()
+        self._model_conf = model_conf
+        c = model_conf.embeddings_and_seqformer
+        self.num_in_seq_channel = c.seq_channel
+        self.num_in_pair_channel = c.pair_channel
+        self.index_embed_size = c.index_embed_size
+        self.impl = ScoreNetworkIteration(model_conf)
+        self.diffuser = diffuser
+        self.max_chunk = 16
+        self._engine = None
+        self._engine_key = None
+        self._static = None
+        self._static_key = None
+        self._flip = 0
+        self._bufs = {}
+
+    # ---- engine / packing ----------------------------------------------------------------------------------------
+    def _get_engine(self, device):
+        key = (str(device), tuple(p._version for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if self._engine is None or self._engine_key != key:
+            _lib.load()                                    # raises if the HIP library is missing
+            self._engine = Engine(self._model_conf, Packed(self.state_dict(), device), device)
+            self._engine_key = key
+            self._static = None
+        return self._engine
+
+    def invalidate_static(self):
+        self._static = None
+
+    def _buf(self, name, shape, dtype, device):
+        b = self._bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype or b.device != device:
+            b = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[name] = b
+        return b
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    def forward(self, input_feats, compute_loss=True):
+        batch = input_feats
+        device = batch['seq'].device
+        if device.type != 'cuda':
+            raise RuntimeError('abx_amd.ScoreNetwork runs on an MI355X only (no CPU path); use oracle/ for CPU checks')
+        B, L = batch['seq'].shape[:2]
+        c = self._model_conf.embeddings_and_seqformer
+        WS_, WZ = c.seq_channel + c.index_embed_size, c.pair_channel + 2 * c.index_embed_size
+        eng = self._get_engine(device)
+        if 'prev_seq' not in batch:
+            batch.update(prev_pos=torch.zeros([B, L, L], device=device, dtype=torch.int64),
+                         prev_seq=torch.zeros([B, L, WS_], device=device),
+                         prev_pair=torch.zeros([B, L, L, WZ], device=device))
+        shared = bool(batch.get('_shared_context', False)) or B == 1
+        skey = (B, L, shared, batch['seq'].data_ptr(), batch['fixed_mask'].data_ptr(), batch['atom14_gt_positions'].data_ptr())
+        if self._static is None or self._static_key != skey:
+            self._static = eng.static_embeddings(batch, shared)
+            self._static_key = skey
+        num_recycle = self._model_conf.num_recycle
+        with torch.no_grad():
+            batch.update(is_recycling=True)
+            for _ in range(num_recycle):
+                ret = self._pass(eng, batch, final=False)
+                prev = get_prev(batch, ret, self._model_conf)
+                batch.update(seq_t=ret['heads']['sequence_module']['seq_0'])
+                batch.update(prev)
+            batch.update(is_recycling=False)
+            ret = self._pass(eng, batch, final=bool(compute_loss))
+        return ret
+
+    def _pass(self, eng, batch, final):
+        device = batch['seq'].device
+        B, L = batch['seq'].shape[:2]
+        c = self._model_conf.embeddings_and_seqformer
+        WS_, WZ = c.seq_channel + c.index_embed_size, c.pair_channel + 2 * c.index_embed_size
+        NC = self._model_conf.heads.diffusion_module.IPA.num_channel
+        # ping-pong representation buffers: the output never aliases prev_* (self-conditioning input)
+        self._flip ^= 1
+        tag = str(self._flip)
+        f32, i64 = torch.float32, torch.int64
+        t = batch['t']
+        t_is_f32 = t.dtype != torch.float64
+        st = dict(
+            L=L, Lab=batch['anchor_flag'].shape[1], diffuser=self.diffuser, static=self._static,
+            seq_t=batch['seq_t'].to(i64).contiguous(), mask_f=batch['mask'].to(f32).contiguous(),
+            fixed_i32=batch['fixed_mask'].to(torch.int32).contiguous(), rigids_t=batch['rigids_t'],
+            torsion_gt=batch['torsion_angles_sin_cos'].to(f32), a37to14=batch['residx_atom37_to_atom14'].to(i64),
+            prev_seq=batch.get('prev_seq'), prev_pair=batch.get('prev_pair'), prev_pos=batch.get('prev_pos'),
+            t64=t.to(torch.float64).contiguous(), t_is_f32=t_is_f32,
+            rep_seq_out=self._buf('rep_seq' + tag, (B, L, WS_), f32, device),
+            rep_pair_out=self._buf('rep_pair' + tag, (B, L, L, WZ), f32, device),
+            prev_pos_out=self._buf('prev_pos' + tag, (B, L, L), i64, device),
+            structure_module=torch.empty(B, L, NC, device=device),
+            angles=torch.empty(B, L, 7, 2, device=device),
+            rot_score=torch.empty(B, L, 3, device=device),
+            trans_score=torch.empty(B, L, 3, device=device, dtype=f32 if t_is_f32 else torch.float64),
+            rigids=torch.empty(B, L, 7, device=device),
+            logits=torch.empty(B, L, 20, device=device), seq_0=torch.empty(B, L, device=device, dtype=i64),
+            atom14=torch.empty(B, L, 14, 3, device=device), atom37=torch.empty(B, L, 37, 3, device=device),
+            pLDDT=torch.empty(B, L, device=device),
+        )
+        for k in ('prev_seq', 'prev_pair', 'prev_pos'):
+            if st[k] is not None:
+                st[k] = st[k].contiguous()
+                assert st[k].data_ptr() != st['rep_seq_out'].data_ptr() and st[k].data_ptr() != st['rep_pair_out'].data_ptr() \
+                    and st[k].data_ptr() != st['prev_pos_out'].data_ptr(), 'self-conditioning buffer aliasing'
+        st['temb'] = torch.empty(B, c.index_embed_size, device=device)
+        from abx_amd import ops
+        ops.timestep_embedding(st['t64'], c.index_embed_size, st['temb'])
+        chunk = max(1, min(self.max_chunk, B))
+        for b0 in range(0, B, chunk):
+            eng.run_chunk(st, b0, min(B, b0 + chunk), final)
+        folding = {
+            'rot_score': st['rot_score'], 'trans_score': st['trans_score'], 'rigids': st['rigids'],
+            'final_atom14_positions': st['atom14'], 'final_atom_positions': st['atom37'],
+            'representations': {'structure_module': st['structure_module']},
+            'sidechains': [{'angles_sin_cos': st['angles']}],
+        }
+        ret = {'representations': {'seq': st['rep_seq_out'], 'pair': st['rep_pair_out']},
+               'heads': {'folding': folding, 'sequence_module': {'logits': st['logits'], 'seq_0': st['seq_0']}},
+               '_prev_pos': st['prev_pos_out']}
+        if final:
+            ret['heads']['predicted_lddt'] = {'pLDDT': st['pLDDT']}
+        return ret

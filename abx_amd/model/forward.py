@@ -1,0 +1,363 @@
+"""Score-network forward on libabx_hip kernels (host orchestration only: buffer views, strides, launch order).
+
+Follows the reference's ScoreNetworkIteration.forward (abx/model/abx.py:42-63): EmbeddingAndSeqformer
+(abx/model/seqformer.py:170-226, block :569-606) -> IpaScore (abx/model/score_network.py:83-196) -> SequenceHead
+(abx/model/head.py:162-201) -> PredictedLDDTHead (:222-226), plus get_prev's distogram (abx/model/abx.py:17-26).
+Distogram / metric / TM-score heads are not computed (unused by sampling).
+
+Memory plan for B samples of one complex (fp32): two ping-pong (B,L,L,192) pair representations (the previous one is the
+self-conditioning input), and a per-chunk workspace of L^2 * 1187 floats per sample that is reused by every stage.
+"""
+import math
+
+import numpy as np
+import torch
+
+from abx_amd import ops
+from abx_amd import residue_constants as rc
+
+P_SEQF = 'impl.seqformer.'
+P_BLK = 'impl.seqformer.seqformer.blocks.0.'
+P_IPA = 'impl.diffusion_module.ScoreNetwork.'
+
+
+class Packed:
+    """Kernel-ready copies of the parameters: Linear weights transposed to [K][N] (n-contiguous B operand), fused
+    projection groups concatenated, embeddings as gather tables."""
+
+    def __init__(self, sd, device):
+        f = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        self.sd = {k: f(k) for k in sd}
+        g = self.sd
+        self.wt, self.b = {}, {}
+
+        def lin(name, key=None):
+            key = key or name
+            self.wt[key] = g[name + '.weight'].t().contiguous()
+            self.b[key] = g.get(name + '.bias')
+
+        def fused(key, names):
+            self.wt[key] = torch.cat([g[n + '.weight'] for n in names], dim=0).t().contiguous()
+            bs = [g.get(n + '.bias') for n in names]
+            if any(b is not None for b in bs):
+                self.b[key] = torch.cat([b if b is not None else torch.zeros(g[n + '.weight'].shape[0], device=device)
+                                         for b, n in zip(bs, names)]).contiguous()
+            else:
+                self.b[key] = None
+
+        for name in list(g):
+            if name.endswith('.weight') and g[name].dim() == 2 and not any(e in name for e in (
+                    'embed.weight', 'proj_aa_type', 'proj_rel_pos', 'proj_prev_pos', 'aapair_to_distcoef')):
+                lin(name[:-7])
+        for tm in ('triangle_multiplication_outgoing', 'triangle_multiplication_incoming'):
+            fused(P_BLK + tm + '.gates', [P_BLK + tm + s for s in ('.left_gate', '.right_gate', '.final_gate')])
+        for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
+            fused(P_BLK + ta + '.qkvg', [P_BLK + ta + s for s in ('.attn.proj_q', '.attn.proj_k', '.attn.proj_v', '.attn.gate')])
+        fused(P_BLK + 'outer_product_mean.lr', [P_BLK + 'outer_product_mean.left_proj', P_BLK + 'outer_product_mean.right_proj'])
+        fused(P_IPA + 'attention_module.proj', [P_IPA + 'attention_module.' + s for s in (
+            'proj_q_scalar', 'proj_kv_scalar', 'proj_q_point_local', 'proj_kv_point_local')])
+        # IPA point weights: -0.5 * sqrt(1/(3*4*9/2)) * softplus(w)   (folding.py:59-66,96)
+        w_p = float(np.sqrt(1.0 / (3 * 4 * 9. / 2)))
+        self.ipa_pw = (-0.5 * w_p * torch.nn.functional.softplus(g[P_IPA + 'attention_module.trainable_point_weights'])).contiguous()
+        self.ipa_ws = float(np.sqrt(1.0 / (3 * 16 * 1.)))
+        self.ipa_w2d = float(np.sqrt(1.0 / 3))
+        # residue tables
+        self.default_frames = torch.as_tensor(rc.restype_rigid_group_default_frame, device=device).contiguous()
+        self.group_idx = torch.as_tensor(rc.restype_atom14_to_rigid_group, device=device).to(torch.int32).contiguous()
+        self.lit_pos = torch.as_tensor(rc.restype_atom14_rigid_group_positions, device=device).contiguous()
+
+    def ln(self, name):
+        return self.sd[name + '.weight'], self.sd[name + '.bias']
+
+
+class Workspace:
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32):
+        n = int(np.prod(shape))
+        buf = self.bufs.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = torch.empty(max(n, 1), device=self.device, dtype=dtype)
+            self.bufs[name] = buf
+        return buf[:n].view(*shape)
+
+
+def _lin(P, name, x, out, **kw):
+    return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), **kw)
+
+
+class Engine:
+    def __init__(self, cfg_model, packed, device):
+        self.cfg = cfg_model
+        self.P = packed
+        self.dev = device
+        self.ws = Workspace(device)
+        c = cfg_model.embeddings_and_seqformer
+        pp = c.prev_pos
+        # squared distogram breaks exactly as torch computes them on the host (common_modules.py:108-109)
+        self.sq_breaks = torch.square(torch.linspace(pp.min_bin, pp.max_bin, steps=pp.num_bins - 1)).to(device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # trajectory-invariant encoders (encoder.py:123-269 + seqformer.py:177-206)
+    # ------------------------------------------------------------------------------------------------------------
+    def static_embeddings(self, batch, shared):
+        P, ws = self.P, self.ws
+        sl = slice(0, 1) if shared else slice(None)
+        seq_t = batch['seq_t'][sl].long().contiguous()
+        seq = batch['seq'][sl].long().contiguous()
+        B, L = seq.shape
+        Lab = batch['anchor_flag'].shape[1]
+        mask = torch.logical_and(batch['mask'][sl], batch['fixed_mask'][sl].bool())
+        mask_f = mask.float().contiguous()
+        chain = batch['chain_id'][sl].to(torch.int32).contiguous()
+        residx = batch['residx'][sl].to(torch.int32).contiguous()
+        atom14 = batch['atom14_gt_positions'][sl].float().contiguous()
+        exists = batch['atom14_gt_exists'][sl].to(torch.uint8).contiguous()
+        M1, M2 = B * L, B * L * L
+        dev = self.dev
+        # ---- ResidueEmbedding
+        pre = P_SEQF + 'encode_residue_emb.'
+        h = torch.empty(M1, 1538, device=dev)
+        ops.gather_rows(P.sd[pre + 'aatype_embed.weight'], seq_t, h[:, 0:512], rowscale=mask_f.reshape(-1))
+        h[:, 512] = chain.reshape(-1).float()
+        h[:, 513] = residx.reshape(-1).float()
+        ops.gather_rows(P.sd[pre + 'cdr_embed.weight'], batch['cdr_def'][sl].long().contiguous(), h[:, 514:1026])
+        cx = torch.cat([atom14.reshape(M1, 42), batch['torsion_angles_sin_cos'][sl].float().reshape(M1, 14)], dim=-1).contiguous()
+        c1 = torch.empty(M1, 512, device=dev)
+        _lin(P, pre + 'coordinate_embed.0', cx, c1, act=1)
+        _lin(P, pre + 'coordinate_embed.2', c1, h[:, 1026:1538])
+        a1 = torch.empty(M1, 1024, device=dev)
+        _lin(P, pre + 'mlp.0', h, a1, act=1)
+        a2 = torch.empty(M1, 512, device=dev)
+        _lin(P, pre + 'mlp.2', a1, a2, act=1)
+        a3 = torch.empty(M1, 512, device=dev)
+        _lin(P, pre + 'mlp.4', a2, a3, act=1)
+        seq_static = torch.empty(M1, 512, device=dev)
+        _lin(P, pre + 'mlp.6', a3, seq_static, rowscale=mask_f.reshape(-1))
+        # antigen rows: + aa_proj(proj_aa_type[seq])   (seqformer.py:199-201)
+        if L > Lab:
+            ag_idx = seq[:, Lab:].contiguous()
+            n_ag = ag_idx.numel()
+            e = torch.empty(n_ag, 512, device=dev)
+            ops.gather_rows(P.sd[P_SEQF + 'proj_aa_type.weight'], ag_idx, e)
+            st = ops.row_stats(e)
+            e1 = torch.empty(n_ag, 512, device=dev)
+            _lin(P, P_SEQF + 'aa_proj.1', e, e1, ln=(st,) + P.ln(P_SEQF + 'aa_proj.0'), act=1)
+            ss = seq_static.view(B, L, 512)
+            # rows of the antigen are not contiguous over the batch: one GEMM per sample keeps the C ABI simple
+            for b in range(B):
+                tgt = ss[b, Lab:]
+                _lin(P, P_SEQF + 'aa_proj.3', e1[b * (L - Lab):(b + 1) * (L - Lab)], tgt, resid=tgt)
+        # ---- PairEmbedding
+        pre = P_SEQF + 'encode_pair_emb.'
+        feat = torch.empty(M2, 512, device=dev)
+        dist = torch.empty(M2, 196, device=dev)
+        ops.pair_embed_features(seq_t, chain, residx, atom14, exists, P.sd[pre + 'aa_pair_embed.weight'],
+                                P.sd[pre + 'relpos_embed.weight'], P.sd[pre + 'aapair_to_distcoef.weight'],
+                                P.sd[pre + 'dgram_embed.weight'], self.sq_breaks, feat, dist, B, L)
+        d1 = torch.empty(M2, 128, device=dev)
+        _lin(P, pre + 'distance_embed.0', dist, d1, act=1)
+        _lin(P, pre + 'distance_embed.2', d1, feat[:, 256:384], act=1)
+        o1 = torch.empty(M2, 128, device=dev)
+        _lin(P, pre + 'out_mlp.0', feat, o1, act=1)
+        _lin(P, pre + 'out_mlp.2', o1, d1, act=1)
+        pmask = torch.empty(M2, device=dev)
+        ops.pair_mask(mask_f, pmask, B, L)
+        rel = torch.empty(M2, 128, device=dev)
+        ops.relpos_block(residx, P.sd[P_SEQF + 'proj_rel_pos.weight'], rel, B, L, Lab, self.cfg.embeddings_and_seqformer.max_relative_feature)
+        pair_static = torch.empty(M2, 128, device=dev)
+        _lin(P, pre + 'out_mlp.4', d1, pair_static, rowscale=pmask, resid=rel)
+        return seq_static.view(B, L, 512), pair_static.view(B, L, L, 128)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # one network pass over samples [b0, b1)
+    # ------------------------------------------------------------------------------------------------------------
+    def run_chunk(self, st, b0, b1, final):
+        """st: per-call state (full-batch tensors).  Writes outputs for samples b0:b1 in place."""
+        P, ws, cfg = self.P, self.ws, self.cfg
+        c = cfg.embeddings_and_seqformer
+        Bc = b1 - b0
+        L, Lab = st['L'], st['Lab']
+        M1, M2, LL = Bc * L, Bc * L * L, L * L
+        CS, CZ, E = c.seq_channel, c.pair_channel, c.index_embed_size
+        WS_, WZ = CS + E, CZ + 2 * E
+        seq_t = st['seq_t'][b0:b1]
+        mask_f = st['mask_f'][b0:b1]
+        fixed = st['fixed_i32'][b0:b1]
+        sstat, pstat = st['static']
+        if sstat.shape[0] != 1:
+            sstat, pstat = sstat[b0:b1], pstat[b0:b1]
+        temb = st['temb'][b0:b1]
+        seq_act = st['rep_seq_out'][b0:b1]                   # (Bc,L,544) view, contiguous
+        pair_act = st['rep_pair_out'][b0:b1]                 # (Bc,L,L,192)
+        prev_seq = st['prev_seq'][b0:b1] if st['prev_seq'] is not None else None
+        prev_pair = st['prev_pair'][b0:b1] if st['prev_pair'] is not None else None
+        prev_pos = st['prev_pos'][b0:b1] if st['prev_pos'] is not None else None
+        ops.assemble_seq(sstat, P.sd[P_SEQF + 'proj_aa_type.weight'], seq_t, Lab, temb, prev_seq,
+                         *P.ln(P_SEQF + 'prev_seq_norm'), seq_act, Bc, L, CS, E)
+        ops.assemble_pair(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos,
+                          P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E)
+        s2 = seq_act.view(M1, WS_)
+        z2 = pair_act.view(M2, WZ)
+        z3 = pair_act.view(Bc, LL, WZ)
+        w768 = ws.get('w768', (M2, 768))
+        w384 = ws.get('w384', (M2 * 384,))
+        stats2 = ws.get('stats2', (M2, 2))
+        stats1 = ws.get('stats1', (M1, 2))
+        pmask = ws.get('pmask', (M2,))
+        ops.pair_mask(mask_f, pmask, Bc, L)
+
+        # ---------------- seq attention with pair bias (seqformer.py:314-356)
+        pre = P_BLK + 'seq_attn.'
+        H = c.seqformer.seq_attention_with_pair_bias.num_head
+        ops.row_stats(s2, stats1)
+        ops.row_stats(z2, stats2)
+        biasT = ws.get('biasT', (Bc, H, LL))
+        ops.gemm(z3, P.wt[pre + 'proj_pair'], biasT.transpose(1, 2), ln=(stats2,) + P.ln(pre + 'pair_norm'))
+        qkv = ws.get('s_a', (M1, 3 * WS_))
+        sgate = ws.get('s_b', (M1, WS_))
+        so = ws.get('s_c', (M1, WS_))
+        lns = (stats1,) + P.ln(pre + 'seq_norm')
+        _lin(P, pre + 'attn.proj_in', s2, qkv, ln=lns)
+        _lin(P, pre + 'attn.gate', s2, sgate, ln=lns)
+        ops.seq_attn(qkv, biasT, mask_f, sgate, so, Bc, L, H, WS_ // H)
+        _lin(P, pre + 'attn.proj_out', so, s2, resid=s2)
+        # ---------------- seq transition
+        pre = P_BLK + 'seq_transition.transition.'
+        ops.row_stats(s2, stats1)
+        hid = ws.get('s_a', (M1, 4 * WS_))
+        _lin(P, pre + '1', s2, hid, ln=(stats1,) + P.ln(pre + '0'), act=1)
+        _lin(P, pre + '3', hid, s2, resid=s2)
+        # ---------------- outer product mean (seqformer.py:395-411)
+        pre = P_BLK + 'outer_product_mean.'
+        ops.row_stats(s2, stats1)
+        lr = ws.get('s_b', (M1, 128))
+        ops.gemm(s2, P.wt[pre + 'lr'], lr, bias=P.b[pre + 'lr'], ln=(stats1,) + P.ln(pre + 'norm'), rowscale=mask_f.reshape(-1))
+        feat = w384[:M2 * 128].view(M2, 128)
+        ops.opm_features(lr, feat, Bc, L, 64)
+        _lin(P, pre + 'out_proj', feat, z2, resid=z2)
+        # ---------------- triangle multiplication (seqformer.py:443-504)
+        for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
+            pre = P_BLK + name + '.'
+            ops.row_stats(z2, stats2)
+            lnz = (stats2,) + P.ln(pre + 'norm')
+            G = w768[:, :448]
+            ops.gemm(z2, P.wt[pre + 'gates'], G, bias=P.b[pre + 'gates'], ln=lnz)
+            left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
+            right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
+            tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
+            G3 = w768.view(Bc, LL, 768)
+            ops.gemm(z3, P.wt[pre + 'left_proj'], left.transpose(1, 2), bias=P.b[pre + 'left_proj'], ln=lnz,
+                     rowscale=pmask, gate=G3[:, :, 0:128])
+            ops.gemm(z3, P.wt[pre + 'right_proj'], right.transpose(1, 2), bias=P.b[pre + 'right_proj'], ln=lnz,
+                     rowscale=pmask, gate=G3[:, :, 128:256])
+            lz = left.view(Bc * 128, L, L)
+            rz = right.view(Bc * 128, L, L)
+            tz = tt.view(Bc * 128, L, L)
+            if outgoing:      # 'bikc,bjkc->bijc'
+                ops.gemm(lz, rz.transpose(1, 2), tz)
+            else:             # 'bkic,bkjc->bijc'
+                ops.gemm(lz.transpose(1, 2), rz, tz)
+            tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
+            ops.row_stats(tcm, stats2)
+            ops.gemm(tcm, P.wt[pre + 'proj_out'], z3, bias=P.b[pre + 'proj_out'], ln=(stats2,) + P.ln(pre + 'final_norm'),
+                     gate=G3[:, :, 256:448], resid=z3)
+        # ---------------- triangle attention (seqformer.py:506-550)
+        for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
+            pre = P_BLK + name + '.'
+            ops.row_stats(z2, stats2)
+            lnz = (stats2,) + P.ln(pre + 'norm')
+            ops.gemm(z2, P.wt[pre + 'qkvg'], w768, bias=P.b[pre + 'qkvg'], ln=lnz)
+            bT = ws.get('biasT', (Bc, 4, LL))
+            ops.gemm(z3, P.wt[pre + 'proj_pair'], bT.transpose(1, 2), ln=lnz)
+            o = w384[:M2 * 192].view(M2, 192)
+            ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row)
+            _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
+        # ---------------- pair transition
+        pre = P_BLK + 'pair_transition.transition.'
+        ops.row_stats(z2, stats2)
+        _lin(P, pre + '1', z2, w768, ln=(stats2,) + P.ln(pre + '0'), act=1)
+        _lin(P, pre + '3', w768, z2, resid=z2)
+
+        # ================= IpaScore (score_network.py:83-196)
+        ic = cfg.heads.diffusion_module.IPA
+        NC = ic.num_channel
+        s_pre = ws.get('i_a', (M1, NC))
+        _lin(P, P_IPA + 'proj_init_seq_act', s2, s_pre)
+        s0 = ws.get('i_s0', (M1, NC))
+        ops.layernorm(s_pre, *P.ln(P_IPA + 'init_seq_layer_norm'), out=s0)
+        s = ws.get('i_s', (M1, NC))
+        _lin(P, P_IPA + 'proj_seq', s0, s)
+        zi = w384[:M2 * 128].view(M2, 128)
+        _lin(P, P_IPA + 'proj_init_pair_act', z2, zi)
+        ops.layernorm(zi, *P.ln(P_IPA + 'init_pair_layer_norm'), out=zi)
+        bias2d = w384[M2 * 128:M2 * 140].view(M2, 12)
+        _lin(P, P_IPA + 'attention_module.proj_pair', zi, bias2d, alpha=P.ipa_w2d)
+        init_q = ws.get('f_iq', (M1, 4)); init_t = ws.get('f_it', (M1, 3))
+        cur_q = ws.get('f_q', (M1, 4)); cur_t = ws.get('f_t', (M1, 3)); cur_R = ws.get('f_R', (M1, 9))
+        delta_q = ws.get('f_dq', (M1, 4))
+        rig_in = st['rigids_t'][b0:b1].contiguous()
+        ops.frames_init(rig_in, init_q, init_t, cur_q, cur_t, cur_R, delta_q, M1, ic.position_scale)
+        proj = ws.get('i_proj', (M1, 1152))
+        qpack = ws.get('i_qp', (M1 * 12 * 28,)); kpack = ws.get('i_kp', (M1 * 12 * 28,)); vpack = ws.get('i_vp', (M1 * 12 * 40,))
+        ifeat = ws.get('i_feat', (M1, 2112))
+        h1 = ws.get('i_h1', (M1, NC)); h2 = ws.get('i_h2', (M1, NC))
+        upd = ws.get('i_upd', (M1, 6))
+        for _ in range(ic.num_layer):
+            ops.gemm(s, P.wt[P_IPA + 'attention_module.proj'], proj, bias=P.b[P_IPA + 'attention_module.proj'])
+            ops.ipa_pack(proj, cur_R, cur_t, qpack, kpack, vpack, Bc, L, P.ipa_ws)
+            ops.ipa_attn(qpack, kpack, vpack, bias2d, zi, mask_f, cur_R, cur_t, P.ipa_pw, ifeat, Bc, L)
+            _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)
+            ops.layernorm(s, *P.ln(P_IPA + 'attention_layer_norm'), out=s)
+            _lin(P, P_IPA + 'transition_module.0', s, h1, act=1)
+            _lin(P, P_IPA + 'transition_module.2', h1, h2, act=1)
+            _lin(P, P_IPA + 'transition_module.4', h2, s, resid=s)
+            ops.layernorm(s, *P.ln(P_IPA + 'transition_layer_norm'), out=s)
+            _lin(P, P_IPA + 'affine_update', s, upd)
+            ops.rigid_update(upd, fixed.reshape(-1), init_q, init_t, cur_q, cur_t, cur_R, delta_q, M1, ic.position_scale)
+        # torsions (sidechain.py:28-72)
+        pre = P_IPA + 'sidechain_module.torsion_module.'
+        ta = ws.get('t_a', (M1, 128)); tb = ws.get('t_b', (M1, 128))
+        _lin(P, pre + 'proj_act.1', s, ta, a_relu=True)
+        _lin(P, pre + 'proj_init_act.1', s0, ta, a_relu=True, resid=ta)
+        for blk in range(ic.torsion.num_residual_block):
+            _lin(P, pre + f'blocks.{blk}.net.1', ta, tb, a_relu=True)
+            _lin(P, pre + f'blocks.{blk}.net.3', tb, ta, a_relu=True, resid=ta)
+        un = ws.get('t_un', (M1, 14))
+        _lin(P, pre + 'projection', ta, un, a_relu=True)
+        angles = st['angles'][b0:b1]
+        ops.torsion_finalize(un, st['torsion_gt'][b0:b1].contiguous(), fixed.reshape(-1), angles, M1)
+        sm = st['structure_module'][b0:b1]
+        sm.view(M1, NC).copy_(s)
+        t64 = st['t64'][b0:b1].contiguous()
+        D = st['diffuser']
+        ops.scores(init_q=init_q, init_t=init_t, delta_q=delta_q, cur_t=cur_t, fixed_mask=fixed.reshape(-1), t=t64,
+                   t_is_f32=int(st['t_is_f32']), score_norms=D.score_norms, num_sigma=D.num_sigma, num_omega=D.num_omega,
+                   discrete_sigma=D.discrete_sigma_dev, discrete_omega=D.discrete_omega_dev,
+                   exp_max_sigma=D.exp_max_sigma, exp_min_sigma=D.exp_min_sigma, min_b=D.min_b_f32, bdiff=D.bdiff_f32,
+                   coord_scale=D.coord_scale_f32, position_scale=float(ic.position_scale),
+                   rot_score=st['rot_score'][b0:b1], trans_score=st['trans_score'][b0:b1], rigids=st['rigids'][b0:b1],
+                   B=Bc, L=L)
+        # ---------------- sequence head (head.py:162-201)
+        pre = 'impl.sequence_module.net.'
+        hx = ws.get('h_x', (M1, NC))
+        ops.layernorm(s, *P.ln(pre + '0'), out=hx)
+        _lin(P, pre + '1', hx, ta, act=1)
+        _lin(P, pre + '3', ta, tb, act=1)
+        logits = st['logits'][b0:b1]
+        _lin(P, pre + '5', tb, logits.view(M1, 20))
+        ops.seq_head_atoms(logits, fixed.reshape(-1), seq_t.contiguous(), st['rigids'][b0:b1], angles,
+                           st['a37to14'][b0:b1].contiguous(), P.default_frames, P.group_idx, P.lit_pos,
+                           st['seq_0'][b0:b1], st['atom14'][b0:b1], st['atom37'][b0:b1], M1)
+        if final:
+            pre = 'impl.predicted_lddt.net.'
+            ops.layernorm(s, *P.ln(pre + '0'), out=hx)
+            _lin(P, pre + '1', hx, ta, act=1)
+            _lin(P, pre + '3', ta, tb, act=1)
+            pl = ws.get('h_pl', (M1, 50))
+            _lin(P, pre + '5', tb, pl)
+            ops.plddt(pl, st['pLDDT'][b0:b1], M1, 50)
+        # ---------------- self-conditioning distogram for the next call (abx.py:17-26)
+        ops.prev_pos(st['atom37'][b0:b1], self.sq_breaks, st['prev_pos_out'][b0:b1], Bc, L)

@@ -1,0 +1,263 @@
+"""Tensor-level wrappers over the C ABI (abx_amd/_lib.py).  torch is used for device memory and the current
+stream only; every function launches HIP kernels from libabx_hip.so and raises if the library is unavailable."""
+import ctypes as C
+
+import torch
+
+from abx_amd import _lib
+from abx_amd._lib import AbxGemm, AbxTriAttn, AbxScoreArgs, AbxReverseArgs, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, 'libabx_hip works on device memory only'
+    return t.data_ptr()
+
+
+def _f32(t):
+    assert t.dtype == torch.float32, t.dtype
+    return t
+
+
+def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
+         resid=None):
+    """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
+    Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
+    stride is 1) stored transposed.  ln = (stats (rows,2), gamma, beta).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N)."""
+    lib = _lib.load()
+    if A.dim() == 2:
+        A = A.unsqueeze(0)
+    if Cout.dim() == 2:
+        Cout = Cout.unsqueeze(0)
+    nb, M, K = A.shape
+    if B.dim() == 2:
+        B = B.unsqueeze(0)
+    assert B.shape[1] == K, (A.shape, B.shape)
+    N = B.shape[2]
+    assert Cout.shape == (nb, M, N), (Cout.shape, (nb, M, N))
+    _f32(A), _f32(B), _f32(Cout)
+    g = AbxGemm()
+    g.A, g.sAb, g.sAm, g.sAk = _p(A), A.stride(0) if nb > 1 else 0, A.stride(1), A.stride(2)
+    g.B, g.sBb, g.sBk, g.sBn = _p(B), (B.stride(0) if B.shape[0] > 1 else 0), B.stride(1), B.stride(2)
+    g.C = _p(Cout)
+    g.sCb = Cout.stride(0) if nb > 1 else 0
+    if Cout.stride(2) == 1:
+        g.c_transposed, g.sCm = 0, Cout.stride(1)
+    else:
+        assert Cout.stride(1) == 1, 'Cout must be n-contiguous or m-contiguous'
+        g.c_transposed, g.sCm = 1, Cout.stride(2)
+    g.M, g.N, g.K, g.batch = M, N, K, nb
+    if ln is not None:
+        stats, gamma, beta = ln
+        assert stats.numel() == 2 * nb * M, (stats.shape, nb, M)
+        g.ln_stats, g.sSb, g.ln_gamma, g.ln_beta = _p(_f32(stats)), M, _p(_f32(gamma)), _p(_f32(beta))
+    g.a_relu = 1 if a_relu else 0
+    g.bias = _p(bias)
+    g.alpha = float(alpha)
+    g.act = int(act)
+    if rowscale is not None:
+        assert rowscale.numel() == nb * M and rowscale.is_contiguous()
+        g.rowscale, g.sRSb = _p(_f32(rowscale)), M
+    if gate is not None:
+        if gate.dim() == 2:
+            gate = gate.unsqueeze(0)
+        assert gate.shape == (nb, M, N) and gate.stride(2) == 1
+        g.gate, g.sGb, g.sGm, g.gate_sigmoid = _p(_f32(gate)), (gate.stride(0) if nb > 1 else 0), gate.stride(1), int(gate_sigmoid)
+    if resid is not None:
+        if resid.dim() == 2:
+            resid = resid.unsqueeze(0)
+        assert resid.shape == (nb, M, N) and resid.stride(2) == 1
+        g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(1)
+    check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
+    return Cout
+
+
+def row_stats(x, out=None, eps=1e-5):
+    """(mean, rstd) per row.  x (rows,K) k-contiguous (dense rows), or x (b, K, rows) channel-major given as a
+    (b, rows, K) logical view whose row stride is 1."""
+    lib = _lib.load()
+    _f32(x)
+    if x.dim() == 2:
+        rows, K = x.shape
+        assert x.stride(1) == 1
+        if out is None:
+            out = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+        check(lib.abx_row_stats(_p(x), 0, x.stride(0), 1, 1, rows, K, eps, _p(out), _stream()), 'abx_row_stats')
+    else:
+        nb, rows, K = x.shape
+        assert x.stride(1) == 1, 'channel-major layout expected'
+        if out is None:
+            out = torch.empty(nb * rows, 2, device=x.device, dtype=torch.float32)
+        check(lib.abx_row_stats(_p(x), x.stride(0), 1, x.stride(2), nb, rows, K, eps, _p(out), _stream()), 'abx_row_stats')
+    return out
+
+
+def layernorm(x, gamma, beta, out=None, res=None, eps=1e-5):
+    lib = _lib.load()
+    rows, K = x.shape
+    assert x.stride(1) == 1
+    if out is None:
+        out = torch.empty(rows, K, device=x.device, dtype=torch.float32)
+    check(lib.abx_layernorm(_p(_f32(x)), x.stride(0), rows, K, _p(gamma), _p(beta), eps, _p(out), out.stride(0),
+                            _p(res), res.stride(0) if res is not None else 0, _stream()), 'abx_layernorm')
+    return out
+
+
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48):
+    """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor; out (B*L*L, H*D)."""
+    lib = _lib.load()
+    W = qkvg.shape[1]
+    assert W == 4 * H * D and qkvg.is_contiguous() and out.is_contiguous() and biasT.is_contiguous()
+    a = AbxTriAttn()
+    es = qkvg.element_size()
+    base = qkvg.data_ptr()
+    a.q, a.k, a.v, a.gate = base, base + H * D * es, base + 2 * H * D * es, base + 3 * H * D * es
+    a.sb = L * L * W
+    a.ss, a.sl = (L * W, W) if per_row else (W, L * W)
+    a.bias = _p(biasT)
+    a.bias_sb, a.bias_sh = H * L * L, L * L
+    a.bias_sq, a.bias_sk = (L, 1) if per_row else (1, L)
+    if keymask is not None:
+        a.keymask, a.km_sb = _p(_f32(keymask)), L
+    C_ = H * D
+    a.out, a.ob = _p(out), L * L * C_
+    a.os, a.ol = (L * C_, C_) if per_row else (C_, L * C_)
+    a.B, a.S, a.L, a.H, a.D = B, L, L, H, D
+    a.scale = float(D ** (-0.5))
+    check(lib.abx_tri_attn_fwd(C.byref(a), _stream()), 'abx_tri_attn_fwd')
+    return out
+
+
+def seq_attn(qkv, biasT, keymask, gate, out, B, L, H=32, D=17):
+    lib = _lib.load()
+    assert qkv.is_contiguous() and biasT.is_contiguous() and gate.is_contiguous() and out.is_contiguous()
+    check(lib.abx_seq_attn_fwd(_p(qkv), _p(biasT), _p(keymask), _p(gate), _p(out), B, L, H, D, float(D ** (-0.5)), _stream()),
+          'abx_seq_attn_fwd')
+    return out
+
+
+def ipa_pack(proj, rots, trans, qpack, kpack, vpack, B, L, w_s):
+    check(_lib.load().abx_ipa_pack(_p(proj), _p(rots), _p(trans), _p(qpack), _p(kpack), _p(vpack), B, L, float(w_s), _stream()),
+          'abx_ipa_pack')
+
+
+def ipa_attn(qpack, kpack, vpack, bias2d, z, mask, rots, trans, pw, feat, B, L):
+    check(_lib.load().abx_ipa_attn(_p(qpack), _p(kpack), _p(vpack), _p(bias2d), _p(z), _p(mask), _p(rots), _p(trans), _p(pw),
+                                   _p(feat), B, L, _stream()), 'abx_ipa_attn')
+
+
+def timestep_embedding(t64, dim, out):
+    assert t64.dtype == torch.float64
+    check(_lib.load().abx_timestep_embedding(_p(t64), t64.shape[0], dim, _p(out), _stream()), 'abx_timestep_embedding')
+    return out
+
+
+def assemble_seq(seq_static, aa_table, seq_t, Lab, temb, prev_seq, gamma, beta, out, B, L, C_, E):
+    ss_b = 0 if seq_static.shape[0] == 1 else seq_static.stride(0)
+    assert seq_t.dtype == torch.int64 and seq_t.is_contiguous()
+    check(_lib.load().abx_assemble_seq(_p(seq_static), ss_b, _p(aa_table), _p(seq_t), Lab, _p(temb), _p(prev_seq), _p(gamma),
+                                       _p(beta), _p(out), B, L, C_, E, _stream()), 'abx_assemble_seq')
+    return out
+
+
+def assemble_pair(pair_static, temb, prev_pair, gamma, beta, prev_pos, pos_table, out, B, L, C_, E):
+    ps_b = 0 if pair_static.shape[0] == 1 else pair_static.stride(0)
+    if prev_pos is not None:
+        assert prev_pos.dtype == torch.int64 and prev_pos.is_contiguous()
+    check(_lib.load().abx_assemble_pair(_p(pair_static), ps_b, _p(temb), _p(prev_pair), _p(gamma), _p(beta), _p(prev_pos),
+                                        _p(pos_table), _p(out), B, L, C_, E, _stream()), 'abx_assemble_pair')
+    return out
+
+
+def opm_features(lr, feat, B, L, C_=64):
+    """lr (B*L, 2*C) = [left | right] (already masked)."""
+    es = lr.element_size()
+    check(_lib.load().abx_opm_features(lr.data_ptr(), lr.data_ptr() + C_ * es, lr.stride(0), _p(feat), B, L, C_, _stream()),
+          'abx_opm_features')
+    return feat
+
+
+def pair_mask(mask_f, out, B, L):
+    check(_lib.load().abx_pair_mask(_p(mask_f), _p(out), B, L, _stream()), 'abx_pair_mask')
+    return out
+
+
+def gather_rows(table, idx, out, rowscale=None):
+    """out[r, :C] = table[idx[r]] (* rowscale[r]); out may be a column window of a wider buffer."""
+    idx = idx.reshape(-1)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and table.is_contiguous()
+    n, C_ = idx.numel(), table.shape[1]
+    check(_lib.load().abx_gather_rows(_p(table), _p(idx), _p(rowscale), _p(out), out.stride(0), n, C_, _stream()), 'abx_gather_rows')
+    return out
+
+
+def relpos_block(residx, table, out, B, L, Lab, max_rel):
+    assert residx.dtype == torch.int32 and residx.is_contiguous()
+    check(_lib.load().abx_relpos_block(_p(residx), _p(table), _p(out), B, L, Lab, table.shape[1], max_rel, _stream()),
+          'abx_relpos_block')
+    return out
+
+
+def pair_embed_features(aa, chain_id, residx, atom14, exists_u8, aa_pair_embed, relpos_embed, distcoef, dgram_embed, sq_breaks,
+                        feat512, dist196, B, L):
+    assert aa.dtype == torch.int64 and chain_id.dtype == torch.int32 and residx.dtype == torch.int32 and exists_u8.dtype == torch.uint8
+    check(_lib.load().abx_pair_embed_features(_p(aa), _p(chain_id), _p(residx), _p(atom14), _p(exists_u8), _p(aa_pair_embed),
+                                              _p(relpos_embed), _p(distcoef), _p(dgram_embed), _p(sq_breaks), _p(feat512),
+                                              _p(dist196), B, L, _stream()), 'abx_pair_embed_features')
+
+
+def frames_init(rigids_t, init_q, init_t, cur_q, cur_t, cur_R, delta_q, n, pscale):
+    assert rigids_t.is_contiguous() and rigids_t.dtype in (torch.float32, torch.float64)
+    check(_lib.load().abx_frames_init(_p(rigids_t), int(rigids_t.dtype == torch.float64), _p(init_q), _p(init_t), _p(cur_q),
+                                      _p(cur_t), _p(cur_R), _p(delta_q), n, float(pscale), _stream()), 'abx_frames_init')
+
+
+def rigid_update(upd6, fixed_i32, init_q, init_t, cur_q, cur_t, cur_R, delta_q, n, pscale):
+    assert fixed_i32.dtype == torch.int32
+    check(_lib.load().abx_rigid_update(_p(upd6), _p(fixed_i32), _p(init_q), _p(init_t), _p(cur_q), _p(cur_t), _p(cur_R),
+                                       _p(delta_q), n, float(pscale), _stream()), 'abx_rigid_update')
+
+
+def scores(**kw):
+    a = AbxScoreArgs()
+    for k, v in kw.items():
+        setattr(a, k, _p(v) if torch.is_tensor(v) else v)
+    check(_lib.load().abx_scores(C.byref(a), _stream()), 'abx_scores')
+
+
+def torsion_finalize(unnorm, gt, fixed_i32, angles, n):
+    check(_lib.load().abx_torsion_finalize(_p(unnorm), _p(gt), _p(fixed_i32), _p(angles), n, _stream()), 'abx_torsion_finalize')
+
+
+def seq_head_atoms(logits, fixed_i32, seq_t, rigids, angles, a37to14, dframes, gidx, lit, seq_0, atom14, atom37, n):
+    assert seq_t.dtype == torch.int64 and a37to14.dtype == torch.int64 and gidx.dtype == torch.int32
+    check(_lib.load().abx_seq_head_atoms(_p(logits), _p(fixed_i32), _p(seq_t), _p(rigids), _p(angles), _p(a37to14), _p(dframes),
+                                         _p(gidx), _p(lit), _p(seq_0), _p(atom14), _p(atom37), n, _stream()), 'abx_seq_head_atoms')
+
+
+def prev_pos(atom37, sq_breaks, out, B, L):
+    assert out.dtype == torch.int64
+    check(_lib.load().abx_prev_pos(_p(atom37), _p(sq_breaks), sq_breaks.numel(), _p(out), B, L, _stream()), 'abx_prev_pos')
+    return out
+
+
+def plddt(logits, out, n, bins):
+    check(_lib.load().abx_plddt(_p(logits), _p(out), n, bins, _stream()), 'abx_plddt')
+    return out
+
+
+def igso3_tables(sigma, omega, pdf, cdf, score_norms, L_terms=1000):
+    check(_lib.load().abx_igso3_tables(_p(sigma), _p(omega), sigma.numel(), omega.numel(), L_terms, _p(pdf), _p(cdf),
+                                       _p(score_norms), _stream()), 'abx_igso3_tables')
+
+
+def reverse_step(**kw):
+    a = AbxReverseArgs()
+    for k, v in kw.items():
+        setattr(a, k, _p(v) if torch.is_tensor(v) else v)
+    check(_lib.load().abx_reverse_step(C.byref(a), _stream()), 'abx_reverse_step')

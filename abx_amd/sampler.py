@@ -1,0 +1,136 @@
+"""Reverse-time sampling driver — the build's counterpart of the reference's `sample_fn` (inference.py:166-273, identical in
+design.py:182-275) plus the multi-GPU sample sharding the reference only stubs (inference.py:59-82).
+
+Loop semantics reproduced: self-conditioning warm-up call at the first grid point with fp32 `t`;
+100 grid points / 99 reverse steps, `t` float64 inside the loop; `get_prev` after every model call; the model mutates
+`batch['seq_t']` before `diffuser.reverse` reads it; the last grid point takes rigids / seq_0 from the model with the stale
+`batch['t']`; optimize mode keeps grid points <= opt_step/num_t + 1e-8; trajectory mode keeps every step.
+Differences: schedule scalars never leave the device (no `.tolist()` syncs), pLDDT stays on the device until the end.
+"""
+import numpy as np
+import torch
+
+from abx_amd.model.abx import get_prev
+
+
+def set_t_feats(feats, diffuser, t, ones):
+    """inference.py:166-171."""
+    feats['t'] = t * ones
+    rs, ts = diffuser.score_scaling(feats['t'])
+    feats['rot_score_scaling'] = rs * ones
+    feats['trans_score_scaling'] = ts * ones
+    return feats
+
+
+def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_t=0.01, center=True, self_condition=True,
+              noise_scale=1.0, eps=1e-8, noise_fn=None, sample_ids=None, on_step=None):
+    """Returns the trajectory: list of dicts {seq (B,Lab) i64, atom14_results (B,Lab,14,3), pLDDT (B,Lab), time,
+    rigids_t, seq_t}; only the last element unless mode == 'trajectory'.  All tensors stay on the device."""
+    model_conf = config.model
+    sc_conf = model_conf.heads.diffusion_module
+    batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_init.items()}
+    device = batch['rigids_t'].device
+    bb_mask = batch['atom14_gt_exists'][..., 0]
+    diffuse_mask = ((1 - batch['fixed_mask']) * bb_mask).to(torch.int32)
+    Lab = batch['anchor_flag'].shape[1]
+    B = batch['rigids_t'].shape[0]
+    ones = torch.ones(B, device=device, dtype=torch.float32)
+    steps = np.linspace(min_t, 1.0, num_t)[::-1]
+    dt = float(np.float32(1 / num_t))                 # value of torch.tensor(1/num_t) (fp32)
+    if mode == 'optimize':
+        opt_step = float(batch['t'][0])
+        if opt_step < 1.0:
+            steps = steps[steps <= opt_step + eps]
+    if hasattr(model, 'invalidate_static'):
+        model.invalidate_static()
+    traj = []
+    with torch.no_grad():
+        if sc_conf.embed.embed_self_conditioning and self_condition and len(steps) > 0:
+            batch = set_t_feats(batch, diffuser, float(steps[0]), ones)
+            out = model(batch)
+            batch.update(get_prev(batch, out, model_conf))
+        dm_f = diffuse_mask.to(torch.float32)
+        for k, t in enumerate(steps):
+            if t > min_t:
+                t_ = torch.full((B,), float(t), device=device, dtype=torch.float64)
+                batch = set_t_feats(batch, diffuser, t_, ones)
+                out = model(batch)
+                f = out['heads']['folding']
+                if sc_conf.embed.embed_self_conditioning:
+                    batch.update(get_prev(batch, out, model_conf))
+                rigids_t, seq_t = diffuser.reverse(
+                    rigid_t=batch['rigids_t'], seq_t=batch['seq_t'], rot_score=f['rot_score'], trans_score=f['trans_score'],
+                    logits_t=out['heads']['sequence_module']['logits'], diffuse_mask=diffuse_mask, t=t_, dt=dt,
+                    center=center, noise_scale=noise_scale, noise=noise_fn(k) if noise_fn else None,
+                    sample_ids=sample_ids, step=k)
+            else:
+                out = model(batch)
+                rigids_t = out['heads']['folding']['rigids']
+                seq_t = out['heads']['sequence_module']['seq_0']
+            batch['rigids_t'] = rigids_t
+            batch['seq_t'] = seq_t
+            pl = out['heads']['predicted_lddt']['pLDDT']
+            pl = torch.sum(pl * dm_f, dim=1) / torch.sum(dm_f, dim=1)
+            rec = {'seq': torch.clamp(seq_t[:, :Lab], min=0, max=19).long(),
+                   'atom14_results': out['heads']['folding']['final_atom14_positions'][:, :Lab],
+                   'pLDDT': torch.tile(pl[:, None], (1, Lab)), 'time': float(t), 'rigids_t': rigids_t, 'seq_t': seq_t}
+            if mode == 'trajectory' or k == len(steps) - 1:
+                traj.append({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in rec.items()})
+            if on_step is not None:
+                on_step(k, t, batch, out)
+    return traj
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# multi-GPU: independent samples shard over ranks; ONE gather of the final results
+# -------------------------------------------------------------------------------------------------------------------
+def shard_sample_ids(num_samples, rank, world_size):
+    """Contiguous blocks, sizes differing by at most one; returns the global sample ids of this rank."""
+    base, rem = divmod(num_samples, world_size)
+    start = rank * base + min(rank, rem)
+    n = base + (1 if rank < rem else 0)
+    return list(range(start, start + n))
+
+
+def gather_results(local, num_samples, rank, world_size, group=None):
+    """All-gather of per-sample results {name: tensor (n_local, ...)} into tensors (num_samples, ...) ordered by sample id.
+    One collective per field on padded equal-size blocks (RCCL all_gather over xGMI; gloo in the CPU tests)."""
+    import torch.distributed as dist
+    if world_size == 1:
+        return local
+    nmax = -(-num_samples // world_size)
+    out = {}
+    for name, t in local.items():
+        pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(world_size)]
+        dist.all_gather(parts, pad, group=group)
+        rows = []
+        for r in range(world_size):
+            n = len(shard_sample_ids(num_samples, r, world_size))
+            rows.append(parts[r][:n])
+        out[name] = torch.cat(rows, dim=0)
+    return out
+
+
+def design_samples(complex_feats, config, diffuser, model, num_samples, rank=0, world_size=1, mode='design', num_t=100,
+                   seed=0, group=None, features_fn=None):
+    """num_samples independent designs of ONE complex, sharded over ranks, gathered at the end.
+    complex_feats: un-batched raw tensors of the complex on the device (abx_amd.synthetic.make_complex layout).
+    features_fn(batch, sample_ids) builds the per-sample diffusion features (noise initialisation)."""
+    ids = shard_sample_ids(num_samples, rank, world_size)
+    n = len(ids)
+    device = next(iter(v for v in complex_feats.values() if torch.is_tensor(v))).device
+    local = {}
+    if n > 0:
+        batch = {k: v[None].expand(n, *v.shape).contiguous() for k, v in complex_feats.items()}
+        sid = torch.tensor(ids, device=device, dtype=torch.int64)
+        batch = features_fn(batch, sid)
+        batch['_shared_context'] = True
+        diffuser.seed = seed
+        traj = sample_fn(batch, config, diffuser, model, mode=mode, num_t=num_t, sample_ids=sid)
+        last = traj[-1]
+        local = {'rigids': last['rigids_t'].double(), 'seq': last['seq'], 'atom14': last['atom14_results'], 'pLDDT': last['pLDDT']}
+    else:
+        raise ValueError('more ranks than samples')
+    return gather_results(local, num_samples, rank, world_size, group)

@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Benchmark of the AbX reverse-diffusion sampling hot path on MI355X (BASELINE.json metric: diffusion-steps/sec).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one iteration of the reference's reverse loop (inference.py:213-268) for a batch of B samples of ONE complex:
+ScoreNetwork call (2 recycles + final pass = 3 network passes) + get_prev + FullDiffuser.reverse.  All inputs are resident
+in HBM when the timed region starts.  value = (samples on all ranks) * K / max-over-ranks(time)  [sample-steps / s].
+Workload (config.workload): synthetic complex 'L352' (Lab 228 + antigen 124 = 352 residues, BASELINE's "~350-res complex"),
+100 samples per GPU (weak scaling: every rank designs its own 100 samples), seeded random weights (no trained checkpoint
+exists offline), ESM disabled, device Philox noise.  fp32 compute with float64 diffuser state, as the reference.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (measured live with HIP events on the launch stream)
+and "cpu_baseline" (the oracle = CPU port of the same step, B = 1, timed on the host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import OrderedDict, defaultdict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+
+
+def algorithmic_bytes_per_sample_step(L):
+    """3 passes x 9893 channel-passes over the L^2 pair grid x 4 B."""
+    return 3 * 9893 * 4.0 * L * L
+
+
+def algorithmic_flops_per_sample_step(L):
+    return 3 * 2 * (1.064e6 * L * L + 1024.0 * L ** 3 + 12.4e6 * L + 1088.0 * L * L)
+
+
+class OpTimer:
+    """Per-op HIP-event timing on the current (launch) stream, used for ONE instrumented step after the timed region."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []
+        self.saved = {}
+
+    def _sig(self, name, args, kw):
+        if name == 'gemm':
+            A, B, C = args[0], args[1], args[2]
+            nb = A.shape[0] if A.dim() == 3 else 1
+            M, K = A.shape[-2], A.shape[-1]
+            N = B.shape[-1]
+            return f'gemm[{nb}x{M}x{N}x{K}]', 2.0 * nb * M * N * K, 4.0 * nb * (M * K + M * N) + 4.0 * K * N
+        if name == 'tri_attn':
+            Bc, L = args[4], args[5]
+            return f'tri_attn[B{Bc} L{L}]', 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
+        if name == 'ipa_attn':
+            Bc, L = args[-2], args[-1]
+            return f'ipa_attn[B{Bc} L{L}]', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12)
+        return name, 0.0, 0.0
+
+    def __enter__(self):
+        for name in dir(self.ops):
+            fn = getattr(self.ops, name)
+            if callable(fn) and not name.startswith('_') and getattr(fn, '__module__', '') == self.ops.__name__:
+                self.saved[name] = fn
+
+                def wrap(fn=fn, name=name):
+                    def inner(*a, **k):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        r = fn(*a, **k)
+                        e1.record()
+                        self.records.append((self._sig(name, a, k), e0, e1))
+                        return r
+                    return inner
+                setattr(self.ops, name, wrap())
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.ops, name, fn)
+        torch.cuda.synchronize()
+
+    def summary(self):
+        agg = defaultdict(lambda: [0.0, 0, 0.0, 0.0])
+        for (sig, fl, by), e0, e1 in self.records:
+            a = agg[sig]
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+            a[2], a[3] = fl, by
+        return sorted(((k, v[0], v[1], v[2], v[3]) for k, v in agg.items()), key=lambda x: -x[1])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='L352')
+    ap.add_argument('--samples', type=int, default=100, help='samples per GPU')
+    ap.add_argument('--chunk', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-op-profile', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus or world == 1 and args.gpus == 1, f'--gpus {args.gpus} but WORLD_SIZE {world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from abx_amd import synthetic, features, sampler, ops, _lib
+    from abx_amd.config import default_config
+    from abx_amd.model.abx import ScoreNetwork, get_prev
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+
+    lib = _lib.load()
+    rc = lib.abx_init(local_rank)
+    assert rc == 0, lib.abx_last_error_string()
+    cfg = default_config()
+    cfg.diffuser.so3.cache_dir = f'/tmp/abx_bench_cache_{rank}/'
+    keys = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'sd_keys.json')))
+    params = synthetic.random_state_dict(OrderedDict((k, tuple(s)) for k, s in keys), seed=7)
+    D = FullDiffuser(cfg.diffuser).to(dev)                     # IGSO(3) tables by the HIP kernel
+    model = ScoreNetwork(cfg.model, D)
+    model.load_state_dict(params, strict=True)
+    model = model.to(dev).eval()
+    model.max_chunk = args.chunk
+
+    w = synthetic.WORKLOADS[args.workload]
+    B = args.samples
+    cx = synthetic.make_complex(seed=1, **w)
+    L = cx['seq'].shape[0]
+    raw = {k: v.to(dev) for k, v in synthetic.replicate(cx, B).items()}
+    torch.manual_seed(1234 + rank)
+    batch = features.build_features(raw, D)
+    batch['_shared_context'] = True
+    diffuse_mask = ((1 - batch['fixed_mask']) * batch['atom14_gt_exists'][..., 0]).to(torch.int32)
+    ones = torch.ones(B, device=dev)
+    sid = torch.arange(B, device=dev) + rank * B
+    grid = np.linspace(0.01, 1.0, 100)[::-1]
+    dt = float(np.float32(0.01))
+    D.seed = 2024
+
+    def one_step(k):
+        t_ = torch.full((B,), float(grid[k % 99]), device=dev, dtype=torch.float64)
+        sampler.set_t_feats(batch, D, t_, ones)
+        out = model(batch)
+        f = out['heads']['folding']
+        batch.update(get_prev(batch, out, cfg.model))
+        rig, seq = D.reverse(rigid_t=batch['rigids_t'], seq_t=batch['seq_t'], rot_score=f['rot_score'], trans_score=f['trans_score'],
+                             logits_t=out['heads']['sequence_module']['logits'], diffuse_mask=diffuse_mask, t=t_, dt=dt,
+                             sample_ids=sid, step=k)
+        batch['rigids_t'], batch['seq_t'] = rig, seq
+        return out
+
+    with torch.no_grad():
+        # self-conditioning warm-up call of the sampler (untimed set-up, like the IGSO(3) table build)
+        sampler.set_t_feats(batch, D, float(grid[0]), ones)
+        out = model(batch)
+        batch.update(get_prev(batch, out, cfg.model))
+        for k in range(args.warmup):
+            one_step(k)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(args.warmup + k)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        finite = bool(torch.isfinite(batch['rigids_t']).all())
+    if world > 1:
+        tt_ = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        elapsed = float(tt_)
+    value = world * B * args.steps / elapsed
+
+    result = {
+        'metric': 'diffusion-steps/sec (100 samples, ~350-res complex)', 'value': value, 'unit': 'sample-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{args.workload}: L={L} (Lab {w["L_heavy"] + w["L_light"]} + antigen {w["L_antigen"]}), '
+                               f'{B} samples/GPU of one complex, 1 step = ScoreNetwork (3 passes) + get_prev + reverse, '
+                               'seeded random weights, ESM off', 'L': L, 'samples_per_gpu': B, 'chunk': args.chunk},
+        'finite': finite,
+        'step_hbm_frac': value / world * algorithmic_bytes_per_sample_step(L) / 1e9 / HBM_PEAK_GBS,
+        'step_mfma_f32_frac': value / world * algorithmic_flops_per_sample_step(L) / 1e12 / MFMA_F32_PEAK_TF,
+    }
+
+    if rank == 0 and not args.no_op_profile:
+        with torch.no_grad(), OpTimer(ops) as tm:
+            one_step(args.warmup + args.steps)
+        summ = tm.summary()
+        total = sum(s[1] for s in summ)
+        top = summ[0]
+        name, ms, calls, fl, by = top
+        dur = ms / calls / 1e3
+        if name.startswith('ipa_attn'):
+            roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+        else:
+            roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s'}
+        roof.update(frac=roof['achieved'] / roof['peak'], traffic=None, kernel=name, calls_per_step=calls,
+                    avg_launch_ms=ms / calls, share_of_step=ms / total)
+        result['roofline'] = roof
+        result['op_profile_ms'] = [{'op': s[0], 'ms': round(s[1], 3), 'calls': s[2],
+                                    'tflops': (s[3] * s[2] / (s[1] / 1e3) / 1e12 if s[3] else None)} for s in summ[:12]]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import abx_oracle as O
+        so3 = D
+        tables = dict(pdf=so3._pdf.cpu(), cdf=so3._cdf.cpu(), score_norms=so3.score_norms.cpu())
+        od = O.OracleDiffuser(cfg.diffuser, tables)
+        cpu = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                cpu[k] = v[:1].cpu() if v.dim() > 0 and v.shape[0] == B else v.cpu()
+            elif isinstance(v, tuple):
+                cpu[k] = tuple(x[:1].cpu() for x in v)
+        cpu = {k: v for k, v in cpu.items() if not k.startswith('prev_')}
+        cpu['rigids_t'] = cpu['rigids_t'].double()
+        ncore = os.cpu_count() or 1
+        torch.set_num_threads(ncore)
+        tc = torch.full((1,), float(grid[1]), dtype=torch.float64)
+        with torch.no_grad():
+            cpu = O.set_t_feats(cpu, od, tc, torch.ones(1))
+            static = O.static_embeddings(params, cpu, cfg)
+            c0 = time.perf_counter()
+            ro = O.score_network(params, cpu, cfg, od, static)
+            cpu.update(O.get_prev(cpu, ro, cfg))
+            dm = (1 - cpu['fixed_mask']) * cpu['atom14_gt_exists'][..., 0]
+            od.reverse(cpu['rigids_t'], cpu['seq_t'], ro['heads']['folding']['rot_score'], ro['heads']['folding']['trans_score'],
+                       ro['heads']['sequence_module']['logits'], tc, torch.tensor(0.01), dm)
+            ctime = time.perf_counter() - c0
+        result['cpu_baseline'] = {'value': 1.0 / ctime, 'unit': 'sample-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                  'sample': f'1 step of 1 sample at L={L} (same complex, weights and step definition; '
+                                            f'trajectory-invariant embeddings cached as in the HIP path), {ctime:.1f} s'}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

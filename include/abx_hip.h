@@ -1,0 +1,201 @@
+/* libabx_hip — C ABI of the MI355X (gfx950) kernels behind AbX's reverse-diffusion sampling hot path.
+ *
+ * The reference (CarbonMatrixLab/AbX) is pure PyTorch: it has no FFI of its own, so the "binding" a maintainer
+ * adds is a ctypes stub that replaces the ATen op groups listed in SURVEY.md §2.1 / §8(a).
+ * Every entry below cites the reference site (file:line under the reference root) it replaces.
+ *
+ * Conventions:
+ *   - raw DEVICE pointers + explicit sizes/strides (in ELEMENTS) + hipStream_t; no torch types;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library keeps no mutable global state;
+ *   - every entry returns int: 0 = ok, <0 = argument check failed, >0 = hipError_t of the launch;
+ *     abx_last_error_string() gives the thread-local message;
+ *   - asynchronous on the given stream, no internal synchronisation (hipGraph-capturable), re-entrant.
+ */
+#ifndef ABX_HIP_H
+#define ABX_HIP_H
+
+#include <stdint.h>
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#else
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABX_HIP_ABI_VERSION 1
+
+int abx_version(void);
+const char* abx_last_error_string(void);
+/* device properties sanity check: returns 0 when the current device is gfx950 */
+int abx_init(int device);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense contractions.  Replaces every torch Linear / LayerNorm->Linear / einsum on the path:
+ * abx/model/common_modules.py:11-44 (Linear), abx/model/seqformer.py:358-376 (Transition), :380-411 (OPM out_proj),
+ * :443-504 (TriangleMultiplication projections + 'bikc,bjkc->bijc' / 'bkic,bkjc->bijc'), :260-312 (q/k/v/gate/out),
+ * abx/model/score_network.py:117-137, abx/model/folding.py:69-132 (IPA projections), abx/model/head.py:147-160,207-220.
+ *   C[b][m][n] = epi( sum_k A'[b][m][k] * B[b][k][n] ),   A' = relu?(LN?(A))
+ *   epi(v) = ((v + bias[n]) * alpha) -> act -> * rowscale[b][m] -> * (sigmoid?)(gate[b][m][n]) -> + resid[b][m][n]
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct AbxGemm {
+    const float* A; long long sAb, sAm, sAk;       /* one of sAm / sAk must be 1 */
+    const float* B; long long sBb, sBk, sBn;       /* one of sBk / sBn must be 1 */
+    float* C;       long long sCb, sCm;            /* n-contiguous; if c_transposed: (m,n) at C + b*sCb + n*sCm + m */
+    int M, N, K, batch;
+    int c_transposed;
+    const float* ln_stats; long long sSb;          /* (mean,rstd) pairs, row index b*sSb + m; NULL = no LayerNorm */
+    const float* ln_gamma; const float* ln_beta;   /* [K] */
+    int a_relu;
+    const float* bias;                             /* [N] or NULL */
+    float alpha;                                   /* use 1.0f for none */
+    int act;                                       /* 0 none, 1 relu, 2 sigmoid */
+    const float* rowscale; long long sRSb;         /* [b*sRSb + m] or NULL */
+    const float* gate; long long sGb, sGm; int gate_sigmoid;
+    const float* resid; long long sRb, sRm;        /* may alias C */
+    int a_vec_ok, b_vec_ok, c_vec_ok, force_a_mcontig;   /* filled by the library */
+} AbxGemm;
+int abx_gemm(const AbxGemm* desc, hipStream_t stream);
+
+/* LayerNorm statistics (mean, rstd) per row for the LN-on-load GEMM prologue (torch.nn.LayerNorm, eps 1e-5).
+ * s_k == 1: rows dense over batch (row stride s_row); else channel-major: element (b,row,k) at x + b*s_b + k*s_k + row. */
+int abx_row_stats(const float* x, long long s_b, long long s_row, long long s_k, int batch, int rows, int K, float eps,
+                  float* stats, hipStream_t stream);
+/* materialised LayerNorm over contiguous rows, out = (res?) + LN(x)  (seqformer.py:216-221 prev_*_norm, score_network.py:119-133) */
+int abx_layernorm(const float* x, long long s_row, long long rows, int K, const float* gamma, const float* beta, float eps,
+                  float* out, long long s_out, const float* res, long long s_res, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Attention kernels
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Flash-style triangle attention (seqformer.py:506-550 + Attention.forward split_first=True :272-312):
+ * per (b, row s, head h): softmax_k( q.k * scale + bias[b,h,q,k] + keymask ) v, then * sigmoid(gate).
+ * q,k,v,gate: element (b,s,l,h,d) at ptr + b*sb + s*ss + l*sl + h*D + d.  per_column orientation = swapped ss/sl. */
+typedef struct AbxTriAttn {
+    const float* q; const float* k; const float* v; const float* gate;
+    long long sb, ss, sl;
+    const float* bias; long long bias_sb, bias_sh, bias_sq, bias_sk;
+    const float* keymask; long long km_sb;          /* float 0/1 [b*km_sb + k] or NULL */
+    float* out; long long ob, os, ol;               /* out (b,s,l,h*D+d) */
+    int B, S, L, H, D;                              /* D must be 48 */
+    float scale;
+} AbxTriAttn;
+int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);
+
+/* Sequence attention with pair bias (seqformer.py:314-356 + Attention.forward split_first=False :278-312).
+ * qkv: [B*L][H*3*D] with per-head layout [q D | k D | v D]; bias [b][h][q][k]; gate pre-activation [B*L][H*D];
+ * out [B*L][H*D] = softmax(...) v * sigmoid(gate).  D <= 32. */
+int abx_seq_attn_fwd(const float* qkv, const float* bias, const float* keymask, const float* gate, float* out, int B, int L,
+                     int H, int D, float scale, hipStream_t stream);
+
+/* Invariant Point Attention core (folding.py:47-132).  abx_ipa_pack turns the fused projection rows
+ * [q_scalar 192 | kv_scalar 384 | q_point_local 144 | kv_point_local 432] into global-frame packs
+ * (r3.rigids_apply, r3.py:9-16); abx_ipa_attn does logits (scalar + point distance + pair bias), mask, softmax_j and the
+ * three outputs (scalar, points back in the local frame + norms, attention over the pair slab), writing the
+ * 2112-wide concat [scalar | points (r n) | norms | pair] that final_proj consumes. */
+int abx_ipa_pack(const float* proj, const float* rots, const float* trans, float* qpack, float* kpack, float* vpack,
+                 int B, int L, float scalar_weight, hipStream_t stream);
+int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
+                 const float* mask, const float* rots, const float* trans, const float* point_weights /* [12] */,
+                 float* feat, int B, int L, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Embedding assembly (seqformer.py:49-119,170-223) and small pair-stack helpers
+ * ---------------------------------------------------------------------------------------------------------- */
+/* sinusoidal embedding of t*10000 (double product, then float) -> [B][dim] */
+int abx_timestep_embedding(const double* t, int B, int dim, float* out, hipStream_t stream);
+/* seq_act[b,l] = [ seq_static[b,l] (+ aa_table[seq_t[b,l]] for l < Lab) | temb[b] ] + LN(prev_seq[b,l]) */
+int abx_assemble_seq(const float* seq_static, long long ss_b, const float* aa_table, const long long* seq_t, int Lab,
+                     const float* temb, const float* prev_seq, const float* gamma, const float* beta, float* out, int B,
+                     int L, int C, int E, hipStream_t stream);
+/* pair_act[b,i,j] = [ pair_static[b,i,j] | temb[b] | temb[b] ] + LN(prev_pair[b,i,j]) + pos_table[prev_pos[b,i,j]] */
+int abx_assemble_pair(const float* pair_static, long long ps_b, const float* temb, const float* prev_pair,
+                      const float* gamma, const float* beta, const long long* prev_pos, const float* pos_table, float* out,
+                      int B, int L, int C, int E, hipStream_t stream);
+/* OuterProductMean features (seqformer.py:400-409): feat[b,i,j] = [ left[b,j]*right[b,i] | left[b,j]-right[b,i] ];
+ * left/right rows have stride ld floats */
+int abx_opm_features(const float* left, const float* right, long long ld, float* feat, int B, int L, int C,
+                     hipStream_t stream);
+/* pair mask[b,i,j] = mask[b,i]*mask[b,j] */
+int abx_pair_mask(const float* mask, float* out, int B, int L, hipStream_t stream);
+
+/* Trajectory-invariant encoders (encoder.py:123-269, seqformer.py:177-206): gather/concat stages; the MLPs run on abx_gemm. */
+int abx_pair_embed_features(const long long* aa, const int* chain_id, const int* residx, const float* atom14,
+                            const unsigned char* atom14_exists, const float* aa_pair_embed, const float* relpos_embed,
+                            const float* distcoef, const float* dgram_embed, const float* sq_breaks /* [14] */,
+                            float* feat512, float* dist196, int B, int L, hipStream_t stream);
+int abx_relpos_block(const int* residx, const float* table, float* out, int B, int L, int Lab, int C, int max_rel,
+                     hipStream_t stream);
+int abx_gather_rows(const float* table, const long long* idx, const float* rowscale, float* out, long long s_out, long long n,
+                    int C, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Rigid frames, torsions, heads (score_network.py:100-194, quat_affine.py, r3.py, atom.py, sidechain.py:64-90, head.py:162-226)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* rigids_t (B,L,7) f32 or f64 -> init_q, init_t (unscaled), cur_q, cur_t (= init_t/position_scale), cur_R, delta_q = identity */
+int abx_frames_init(const void* rigids_t, int is_f64, float* init_q, float* init_t, float* cur_q, float* cur_t, float* cur_R,
+                    float* delta_q, int n, float position_scale, hipStream_t stream);
+/* one IPA layer tail: quat_precompose_vec on delta and current, translation update with the OLD rotation, fixed-mask restore,
+ * quat_to_rot (score_network.py:137-149) */
+int abx_rigid_update(const float* upd6, const int* fixed_mask, const float* init_q, const float* init_t, float* cur_q,
+                     float* cur_t, float* cur_R, float* delta_q, int n, float position_scale, hipStream_t stream);
+/* final quaternion, igso3 rot score (cached table lookup, so3_diffuser.py:264-297), r3 trans score (r3_diffuser.py:158-164),
+ * rigids (B,L,7).  t is (B,) double; t_is_f32 selects the reference's fp32 arithmetic of the warm-up call.
+ * trans_score is written as double when !t_is_f32 else float. */
+typedef struct AbxScoreArgs {
+    const float* init_q; const float* init_t; const float* delta_q; const float* cur_t; const int* fixed_mask;
+    const double* t; int t_is_f32;
+    const float* score_norms; int num_sigma, num_omega; const float* discrete_sigma; const float* discrete_omega;
+    float exp_max_sigma, exp_min_sigma;     /* fp32 exp(1.5), exp(0.1) as torch computes them */
+    float min_b, bdiff;                     /* fp32 0.1, 19.9 */
+    float coord_scale;                      /* fp32 0.1 */
+    float position_scale;
+    float* rot_score; void* trans_score; float* rigids;
+    int B, L;
+} AbxScoreArgs;
+int abx_scores(const AbxScoreArgs* a, hipStream_t stream);
+/* torsion head tail: l2-normalise (eps 1e-12) and take ground-truth torsions at fixed residues (sidechain.py:67-72) */
+int abx_torsion_finalize(const float* unnorm, const float* gt_sincos, const int* fixed_mask, float* angles, int n,
+                         hipStream_t stream);
+/* SequenceHead tail (head.py:165-199): seq_0 = argmax(logits) merged with seq_t at fixed positions; frames from torsions;
+ * atom14 and atom37 with the seq_0 residue tables. tables: default_frames (21,8,4,4), group_idx (21,14) int, lit_pos (21,14,3) */
+int abx_seq_head_atoms(const float* logits, const int* fixed_mask, const long long* seq_t, const float* rigids,
+                       const float* angles, const long long* atom37_to_atom14, const float* default_frames,
+                       const int* group_idx, const float* lit_pos, long long* seq_0, float* atom14, float* atom37, int n,
+                       hipStream_t stream);
+/* get_prev (abx.py:17-26): virtual C-beta from N,CA,C (common_modules.py:62-83) and 15-bin distogram -> int64 (B,L,L) */
+int abx_prev_pos(const float* atom37, const float* sq_breaks, int num_breaks, long long* prev_pos, int B, int L,
+                 hipStream_t stream);
+/* pLDDT = 100 * sum softmax(logits) * bin centres (utils.py:158-171) */
+int abx_plddt(const float* logits, float* out, int n, int bins, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Diffuser (diffuser/so3_diffuser.py, r3_diffuser.py, discrete_diffuser.py, full_diffuser.py:174-227)
+ * ---------------------------------------------------------------------------------------------------------- */
+/* IGSO(3) series tables (so3_diffuser.py:15-49,72-112,153-166): pdf, cdf, score_norms [num_sigma][num_omega] */
+int abx_igso3_tables(const float* sigma, const float* omega, int num_sigma, int num_omega, int L_terms, float* pdf, float* cdf,
+                     float* score_norms, hipStream_t stream);
+/* One reverse step of all three processes in float64 with injected or device-generated noise, mask merge after all three.
+ * rigid_in f32 or f64 (B,L,7); rot_score f32; trans_score f64 (or f32 when ts_is_f32); logits f32 (B,L,20); t (B,) double.
+ * Noise: z_rot,z_trans f32 (B,L,3), jumps f32 (B,L,20) when given; otherwise Philox4x32-10 keyed by (seed, sample id, step).
+ * Outputs rigid_out f64 (B,L,7), seq_out int64 (B,L).  Also writes the Poisson rates*dt when rates_out != NULL. */
+typedef struct AbxReverseArgs {
+    const void* rigid_in; int rigid_is_f64;
+    const long long* seq_in;
+    const float* rot_score; const void* trans_score; int ts_is_f32; const float* logits;
+    const int* diffuse_mask; const double* t; float dt;
+    const float* z_rot; const float* z_trans; const float* jumps;
+    unsigned long long seed; const long long* sample_ids; int step;
+    float exp_max_sigma, exp_min_sigma, min_b, bdiff, coord_scale, rate_const;
+    float noise_scale; int center;
+    double* rigid_out; long long* seq_out; float* rates_out;
+    int B, L;
+} AbxReverseArgs;
+int abx_reverse_step(const AbxReverseArgs* a, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABX_HIP_H */

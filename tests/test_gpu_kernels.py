@@ -1,0 +1,435 @@
+"""Per-kernel parity: every C-ABI entry of libabx_hip.so (called through abx_amd.ops) against the oracle / an fp64 torch
+restatement of the same op on identical seeded inputs.  Needs an MI355X: run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, tt
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, tol, name):
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    e = rel_err(a, b)
+    assert np.isfinite(e) and e <= tol, f'{name}: rel err {e:.3e} > {tol}'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from abx_amd import ops as _ops, _lib
+    lib = _lib.load()
+    assert lib.abx_init(0) == 0, lib.abx_last_error_string()
+    return _ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 70, 52), (37, 20, 256), (513, 192, 192), (64, 6, 256), (96, 448, 192)])
+def test_gemm_plain_bias_act(ops, M, N, K):
+    A = torch.randn(M, K, generator=g(1))
+    W = torch.randn(N, K, generator=g(2)) / K ** 0.5
+    b = torch.randn(N, generator=g(3))
+    for act in (0, 1, 2):
+        out = torch.full((M, N), float('nan'), device=DEV)
+        ops.gemm(A.to(DEV), W.t().contiguous().to(DEV), out, bias=b.to(DEV), act=act)
+        ref = A.double() @ W.double().t() + b.double()
+        ref = torch.relu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
+        check(out, ref, 2e-6, f'gemm act={act} {M}x{N}x{K}')
+
+
+def test_gemm_ln_gate_resid_rowscale(ops):
+    M, N, K = 300, 192, 192
+    A = torch.randn(M, K, generator=g(4)) * 2 + 0.5
+    W = torch.randn(N, K, generator=g(5)) / K ** 0.5
+    b = torch.randn(N, generator=g(6))
+    ga, be = torch.randn(K, generator=g(7)), torch.randn(K, generator=g(8))
+    gate = torch.randn(M, N + 8, generator=g(9))
+    res = torch.randn(M, N, generator=g(10))
+    rs = (torch.rand(M, generator=g(11)) > 0.3).float()
+    Ad = A.to(DEV)
+    stats = ops.row_stats(Ad)
+    ref_ln = torch.nn.functional.layer_norm(A.double(), (K,), ga.double(), be.double(), 1e-5)
+    mean, rstd = A.double().mean(-1), 1 / torch.sqrt(A.double().var(-1, unbiased=False) + 1e-5)
+    check(stats[:, 0], mean, 1e-6, 'row_stats mean')
+    check(stats[:, 1], rstd, 1e-6, 'row_stats rstd')
+    resd = res.to(DEV).clone()
+    gd = gate.to(DEV)
+    ops.gemm(Ad, W.t().contiguous().to(DEV), resd, bias=b.to(DEV), ln=(stats, ga.to(DEV), be.to(DEV)), alpha=0.5,
+             rowscale=rs.to(DEV), gate=gd[:, :N], resid=resd)
+    ref = ((ref_ln @ W.double().t() + b.double()) * 0.5) * rs.double()[:, None] * torch.sigmoid(gate[:, :N].double()) + res.double()
+    check(resd, ref, 3e-6, 'gemm LN+gate+resid (in place)')
+    # materialised layernorm, in place and with residual
+    x = A.to(DEV).clone()
+    ops.layernorm(x, ga.to(DEV), be.to(DEV), out=x)
+    check(x, ref_ln, 2e-6, 'layernorm in place')
+
+
+def test_gemm_layouts_batched_transposed(ops):
+    nb, M, N, K = 5, 72, 72, 72       # L = 72 triangle contraction shapes (not multiples of the tiles)
+    X = torch.randn(nb, M, K, generator=g(12))
+    Y = torch.randn(nb, N, K, generator=g(13))
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    out = torch.empty(nb, M, N, device=DEV)
+    ops.gemm(Xd, Yd.transpose(1, 2), out)                                    # A k-contig, B k-contig
+    check(out, torch.einsum('bik,bjk->bij', X.double(), Y.double()), 2e-6, 'NT contraction')
+    ops.gemm(Xd.transpose(1, 2), Yd, out)                                    # A m-contig, B n-contig: sum_k X[k,i] Y[k,j]
+    check(out, torch.einsum('bki,bkj->bij', X.double(), Y.double()), 2e-6, 'TN contraction')
+    # odd sizes -> scalar (unaligned) load paths
+    nb, M, N, K = 3, 25, 25, 25
+    X = torch.randn(nb, M, K, generator=g(14)); Y = torch.randn(nb, N, K, generator=g(15))
+    out = torch.empty(nb, M, N, device=DEV)
+    ops.gemm(X.to(DEV), Y.to(DEV).transpose(1, 2), out)
+    check(out, torch.einsum('bik,bjk->bij', X.double(), Y.double()), 2e-6, 'NT odd')
+    ops.gemm(X.to(DEV).transpose(1, 2), Y.to(DEV), out)
+    check(out, torch.einsum('bki,bkj->bij', X.double(), Y.double()), 2e-6, 'TN odd')
+    # transposed store (channel-major output) with LN, rowscale and gate, batched over samples
+    B, LL, C, Cout = 2, 40 * 40, 192, 128
+    Z = torch.randn(B, LL, C, generator=g(16))
+    W = torch.randn(Cout, C, generator=g(17)) / C ** 0.5
+    bias = torch.randn(Cout, generator=g(18))
+    G = torch.randn(B, LL, 448, generator=g(19))
+    pm = (torch.rand(B * LL, generator=g(20)) > 0.2).float()
+    ga, be = torch.randn(C, generator=g(21)), torch.randn(C, generator=g(22))
+    Zd = Z.to(DEV)
+    stats = ops.row_stats(Zd.view(B * LL, C))
+    outT = torch.full((B, Cout, LL), float('nan'), device=DEV)
+    ops.gemm(Zd, W.t().contiguous().to(DEV), outT.transpose(1, 2), bias=bias.to(DEV), ln=(stats, ga.to(DEV), be.to(DEV)),
+             rowscale=pm.to(DEV), gate=G.to(DEV)[:, :, 128:256])
+    ln = torch.nn.functional.layer_norm(Z.double(), (C,), ga.double(), be.double(), 1e-5)
+    ref = (ln @ W.double().t() + bias.double()) * pm.double().view(B, LL, 1) * torch.sigmoid(G[:, :, 128:256].double())
+    check(outT, ref.transpose(1, 2), 3e-6, 'transposed store')
+    # channel-major A (m-contiguous) with channel-major LN stats, back to channel-last with residual
+    T = torch.randn(B, Cout, LL, generator=g(23))
+    Td = T.to(DEV)
+    tcm = Td.transpose(1, 2)
+    st2 = ops.row_stats(tcm)
+    W2 = torch.randn(C, Cout, generator=g(24)) / Cout ** 0.5
+    ga2, be2 = torch.randn(Cout, generator=g(25)), torch.randn(Cout, generator=g(26))
+    res = Zd.clone()
+    ops.gemm(tcm, W2.t().contiguous().to(DEV), res, ln=(st2, ga2.to(DEV), be2.to(DEV)), resid=res)
+    ln2 = torch.nn.functional.layer_norm(T.double().transpose(1, 2), (Cout,), ga2.double(), be2.double(), 1e-5)
+    check(res, ln2 @ W2.double().t() + Z.double(), 3e-6, 'channel-major A + LN')
+
+
+def test_gemm_small_n_and_relu_input(ops):
+    M, K = 150, 128
+    A = torch.randn(M, K, generator=g(27))
+    for N in (4, 12, 14, 32, 50):
+        W = torch.randn(N, K, generator=g(28 + N)) / K ** 0.5
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), W.t().contiguous().to(DEV), out, a_relu=True)
+        check(out, torch.relu(A.double()) @ W.double().t(), 2e-6, f'gemm N={N} a_relu')
+    # unaligned K (1538 = residue-embedding MLP input) and strided output window
+    K = 1538
+    A = torch.randn(40, K, generator=g(90)); W = torch.randn(64, K, generator=g(91)) / K ** 0.5
+    wide = torch.zeros(40, 200, device=DEV)
+    ops.gemm(A.to(DEV), W.t().contiguous().to(DEV), wide[:, 100:164])
+    check(wide[:, 100:164], A.double() @ W.double().t(), 3e-6, 'gemm K=1538 window')
+    assert float(wide[:, :100].abs().max()) == 0 and float(wide[:, 164:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False)])
+def test_tri_attn(ops, L, per_row):
+    from oracle import abx_oracle as O
+    B, H, D = 2, 4, 48
+    C = H * D
+    x = torch.randn(B, L, L, 4 * C, generator=g(30))            # [q|k|v|gate] in natural (i,j) layout
+    P = torch.randn(B, L, L, H, generator=g(31))                # bias projection in natural layout
+    mask = torch.rand(B, L, generator=g(32)) > 0.15
+    mask[:, 0] = True
+    out = torch.full((B * L * L, C), float('nan'), device=DEV)
+    biasT = P.permute(0, 3, 1, 2).contiguous()                 # (B,H,i,j)
+    ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), biasT.to(DEV), mask.float().to(DEV), out, B, L, per_row)
+    xx = x if per_row else x.transpose(1, 2)
+    PP = P if per_row else P.transpose(1, 2)
+    q, k, v, gt = [t.reshape(B, L, L, H, D).permute(0, 1, 3, 2, 4).double() for t in torch.split(xx, C, dim=-1)]
+    o = O._attention(q, k, v, PP.permute(0, 3, 1, 2).double(), mask[:, None, :], D)
+    o = o * torch.sigmoid(xx[..., 3 * C:].double())
+    if not per_row:
+        o = o.transpose(1, 2)
+    check(out.view(B, L, L, C), o, 5e-6, f'tri_attn L={L} per_row={per_row}')
+
+
+def test_tri_attn_all_keys_masked_row_and_spike(ops):
+    """Fully masked keys give the uniform softmax of finfo.min logits; a spiked key forces the online-softmax rescale."""
+    from oracle import abx_oracle as O
+    B, L, H, D = 1, 80, 4, 48
+    C = H * D
+    x = torch.randn(B, L, L, 4 * C, generator=g(33))
+    x[0, 3, 70, C:2 * C] *= 30.0                                # key 70 of row 3 dominates -> max jumps in the 2nd key tile
+    P = torch.zeros(B, L, L, H)
+    for mask in (torch.zeros(B, L, dtype=torch.bool), torch.ones(B, L, dtype=torch.bool)):
+        out = torch.empty(B * L * L, C, device=DEV)
+        ops.tri_attn(x.view(-1, 4 * C).to(DEV), P.permute(0, 3, 1, 2).contiguous().to(DEV), mask.float().to(DEV), out, B, L, True)
+        q, k, v, gt = [t.reshape(B, L, L, H, D).permute(0, 1, 3, 2, 4).double() for t in torch.split(x, C, dim=-1)]
+        o = O._attention(q, k, v, None, mask[:, None, :], D) * torch.sigmoid(x[..., 3 * C:].double())
+        check(out.view(B, L, L, C), o, 5e-6, f'tri_attn mask all={bool(mask.all())}')
+
+
+def test_seq_attn(ops):
+    from oracle import abx_oracle as O
+    B, L, H, D = 2, 52, 32, 17
+    qkv = torch.randn(B, L, H, 3 * D, generator=g(34))
+    bias = torch.randn(B, H, L, L, generator=g(35))
+    gate = torch.randn(B, L, H * D, generator=g(36))
+    mask = torch.rand(B, L, generator=g(37)) > 0.2
+    out = torch.empty(B * L, H * D, device=DEV)
+    ops.seq_attn(qkv.view(B * L, -1).to(DEV), bias.to(DEV), mask.float().to(DEV), gate.view(B * L, -1).to(DEV), out, B, L)
+    t = qkv.permute(0, 2, 1, 3)[:, None].double()
+    q, k, v = torch.chunk(t, 3, dim=-1)
+    o = O._attention(q, k, v, bias.double(), mask[:, None, :], D)[:, 0] * torch.sigmoid(gate.double())
+    check(out.view(B, L, -1), o, 5e-6, 'seq_attn')
+
+
+def test_ipa_core(ops, params, cfg):
+    from oracle import abx_oracle as O
+    B, L = 2, 37
+    c = cfg.model.heads.diffusion_module.IPA
+    s = torch.randn(B, L, 256, generator=g(40))
+    z = torch.randn(B, L, L, 128, generator=g(41))
+    quat = torch.nn.functional.normalize(torch.randn(B, L, 4, generator=g(42)), dim=-1)
+    rots = O.quat_to_rot(quat)
+    trans = torch.randn(B, L, 3, generator=g(43)) * 3
+    mask = (torch.rand(B, L, generator=g(44)) > 0.15).float()
+    p = dict(params)
+    pre = O.P_IPA + 'attention_module.'
+    p[pre + 'final_proj.weight'] = torch.eye(2112)
+    p[pre + 'final_proj.bias'] = torch.zeros(2112)
+    ref = O.ipa_attention(p, s, z, mask, rots, trans, c)                        # (B,L,2112) feature concat
+    from abx_amd.model.forward import Packed
+    P = Packed({k: v for k, v in params.items()}, DEV)
+    M1 = B * L
+    proj = torch.empty(M1, 1152, device=DEV)
+    ops.gemm(s.view(M1, 256).to(DEV), P.wt[pre + 'proj'], proj, bias=P.b[pre + 'proj'])
+    bias2d = torch.empty(B * L * L, 12, device=DEV)
+    ops.gemm(z.view(-1, 128).to(DEV), P.wt[pre + 'proj_pair'], bias2d, bias=P.b[pre + 'proj_pair'], alpha=P.ipa_w2d)
+    qp = torch.empty(M1 * 12 * 28, device=DEV); kp = torch.empty(M1 * 12 * 28, device=DEV); vp = torch.empty(M1 * 12 * 40, device=DEV)
+    Rd, td = rots.reshape(M1, 9).contiguous().to(DEV), trans.reshape(M1, 3).contiguous().to(DEV)
+    ops.ipa_pack(proj, Rd, td, qp, kp, vp, B, L, P.ipa_ws)
+    feat = torch.full((M1, 2112), float('nan'), device=DEV)
+    ops.ipa_attn(qp, kp, vp, bias2d, z.to(DEV).contiguous(), mask.to(DEV), Rd, td, P.ipa_pw, feat, B, L)
+    f, r = feat.view(B, L, 2112).cpu(), ref
+    for name, sl in (('scalar', slice(0, 192)), ('points', slice(192, 480)), ('norms', slice(480, 576)), ('pair', slice(576, 2112))):
+        check(f[..., sl], r[..., sl], 2e-5, 'ipa ' + name)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_embedding_assembly(ops, params):
+    from oracle import abx_oracle as O
+    B, L, Lab = 2, 20, 16
+    t64 = torch.tensor([0.5050505050505051, 0.02], dtype=torch.float64)
+    temb = torch.empty(B, 32, device=DEV)
+    ops.timestep_embedding(t64.to(DEV), 32, temb)
+    check(temb, O.timestep_embedding(t64, 32), 2e-6, 'timestep embedding (fp64 t)')
+    t32 = torch.tensor([1.0, 0.3], dtype=torch.float32)
+    ops.timestep_embedding(t32.double().to(DEV), 32, temb)
+    check(temb, O.timestep_embedding(t32, 32), 2e-6, 'timestep embedding (fp32 t)')
+    seq_static = torch.randn(B, L, 512, generator=g(50))
+    pair_static = torch.randn(B, L, L, 128, generator=g(51))
+    seq_t = torch.randint(0, 20, (B, L), generator=g(52))
+    prev_seq = torch.randn(B, L, 544, generator=g(53)); prev_pair = torch.randn(B, L, L, 192, generator=g(54))
+    prev_pos = torch.randint(0, 15, (B, L, L), generator=g(55))
+    P = {k: v.to(DEV) for k, v in params.items()}
+    so = torch.empty(B, L, 544, device=DEV); po = torch.empty(B, L, L, 192, device=DEV)
+    ops.assemble_seq(seq_static.to(DEV), P[O.P_SEQF + 'proj_aa_type.weight'], seq_t.to(DEV), Lab, temb, prev_seq.to(DEV),
+                     P[O.P_SEQF + 'prev_seq_norm.weight'], P[O.P_SEQF + 'prev_seq_norm.bias'], so, B, L, 512, 32)
+    ops.assemble_pair(pair_static.to(DEV), temb, prev_pair.to(DEV), P[O.P_SEQF + 'prev_pair_norm.weight'],
+                      P[O.P_SEQF + 'prev_pair_norm.bias'], prev_pos.to(DEV), P[O.P_SEQF + 'proj_prev_pos.weight'], po, B, L, 128, 32)
+    te = temb.cpu()
+    sa = seq_static.clone()
+    sa[:, :Lab] += params[O.P_SEQF + 'proj_aa_type.weight'][seq_t[:, :Lab]]
+    sa = torch.cat([sa, te[:, None].expand(B, L, 32)], -1) + O.lnorm(params, O.P_SEQF + 'prev_seq_norm', prev_seq)
+    pa = torch.cat([pair_static, te[:, None, None].expand(B, L, L, 32), te[:, None, None].expand(B, L, L, 32)], -1)
+    pa = pa + O.lnorm(params, O.P_SEQF + 'prev_pair_norm', prev_pair) + params[O.P_SEQF + 'proj_prev_pos.weight'][prev_pos]
+    check(so, sa, 2e-6, 'assemble_seq')
+    check(po, pa, 2e-6, 'assemble_pair')
+    # shared (broadcast) static context
+    ops.assemble_pair(pair_static[:1].contiguous().to(DEV), temb, None, None, None, None, None, po, B, L, 128, 32)
+    check(po[1, ..., :128], pair_static[0], 0, 'assemble_pair broadcast')
+    # OPM features + pair mask
+    lr = torch.randn(B * L, 128, generator=g(56))
+    feat = torch.empty(B * L * L, 128, device=DEV)
+    ops.opm_features(lr.to(DEV), feat, B, L, 64)
+    left, right = lr[:, :64].view(B, L, 64), lr[:, 64:].view(B, L, 64)
+    ref = torch.cat([left[:, None, :, :] * right[:, :, None, :], left[:, None, :, :] - right[:, :, None, :]], -1)
+    check(feat.view(B, L, L, 128), ref, 0, 'opm features')
+    m = (torch.rand(B, L, generator=g(57)) > 0.3).float()
+    pm = torch.empty(B * L * L, device=DEV)
+    ops.pair_mask(m.to(DEV), pm, B, L)
+    check(pm.view(B, L, L), m[:, :, None] * m[:, None, :], 0, 'pair mask')
+
+
+def test_frames_scores_heads(ops, params, cfg, oracle_diffuser):
+    from oracle import abx_oracle as O
+    from abx_amd.model.forward import Packed
+    B, L = 2, 33
+    n = B * L
+    ge = g(60)
+    rig = torch.cat([torch.nn.functional.normalize(torch.randn(B, L, 4, generator=ge), dim=-1), torch.randn(B, L, 3, generator=ge) * 10], -1)
+    fixed = (torch.rand(B, L, generator=ge) > 0.4).int()
+    dev = lambda x: x.contiguous().to(DEV)
+    bufs = [torch.empty(n, k, device=DEV) for k in (4, 3, 4, 3, 9, 4)]
+    init_q, init_t, cur_q, cur_t, cur_R, delta_q = bufs
+    for dt_ in (torch.float32, torch.float64):
+        ops.frames_init(dev(rig.to(dt_)), *bufs, n, 10.0)
+        check(cur_R.view(B, L, 3, 3), O.quat_to_rot(rig[..., :4]), 2e-6, 'frames_init R')
+        check(cur_t.view(B, L, 3), rig[..., 4:] / 10, 1e-7, 'frames_init t')
+    # three rigid updates against the oracle recursion
+    q, t, R, dq = rig[..., :4].clone(), rig[..., 4:] / 10, O.quat_to_rot(rig[..., :4]), torch.zeros(B, L, 4)
+    dq[..., 0] = 1
+    dm = (1 - fixed[..., None]).float()
+    for it in range(3):
+        upd = torch.randn(B, L, 6, generator=ge) * 0.3
+        ops.rigid_update(dev(upd.view(n, 6)), dev(fixed.view(-1)), init_q, init_t, cur_q, cur_t, cur_R, delta_q, n, 10.0)
+        dq = O.quat_precompose_vec(dq, upd[..., :3])
+        q = O.quat_precompose_vec(q, upd[..., :3])
+        t = t + torch.einsum('...rd,...d->...r', R, upd[..., 3:])
+        q = dm * q + (1 - dm) * rig[..., :4]
+        t = dm * t + (1 - dm) * (rig[..., 4:] / 10)
+        R = O.quat_to_rot(q)
+    check(cur_q.view(B, L, 4), q, 3e-6, 'rigid_update q')
+    check(cur_t.view(B, L, 3), t, 3e-6, 'rigid_update t')
+    check(delta_q.view(B, L, 4), dq, 3e-6, 'rigid_update delta')
+    # scores: fp64 t (loop) and fp32 t (warm-up)
+    D = oracle_diffuser
+    so3 = D.so3
+    for tvals in (torch.tensor([0.5050505050505051, 0.02], dtype=torch.float64), torch.tensor([1.0, 0.37], dtype=torch.float32)):
+        is32 = tvals.dtype == torch.float32
+        rot = torch.empty(n, 3, device=DEV)
+        ts = torch.empty(n, 3, device=DEV, dtype=torch.float32 if is32 else torch.float64)
+        rigids = torch.empty(n, 7, device=DEV)
+        ops.scores(init_q=init_q, init_t=init_t, delta_q=delta_q, cur_t=cur_t, fixed_mask=dev(fixed.view(-1)), t=dev(tvals.double()),
+                   t_is_f32=int(is32), score_norms=dev(so3._score_norms), num_sigma=1000, num_omega=1000,
+                   discrete_sigma=dev(so3.discrete_sigma), discrete_omega=dev(so3.discrete_omega),
+                   exp_max_sigma=float(torch.exp(torch.tensor(1.5))), exp_min_sigma=float(torch.exp(torch.tensor(0.1))),
+                   min_b=float(torch.tensor(0.1)), bdiff=float(torch.tensor(19.9)), coord_scale=float(torch.tensor(0.1)),
+                   position_scale=10.0, rot_score=rot, trans_score=ts, rigids=rigids, B=B, L=L)
+        q_fin = dm * O.quat_multiply(rig[..., :4], dq) + (1 - dm) * rig[..., :4]
+        ref_ts = D.calc_trans_score(rig[..., 4:], t * 10, tvals)
+        ref_rs = D.calc_quat_score(rig[..., :4], q_fin, tvals)
+        assert ref_ts.dtype == ts.dtype
+        check(ts.view(B, L, 3), ref_ts, 3e-6, f'trans_score f32={is32}')
+        check(rigids.view(B, L, 7), torch.cat([q_fin, t * 10], -1), 3e-6, 'rigids')
+        bad = ((rot.view(B, L, 3).cpu() - ref_rs).abs() > 1e-4 + 1e-4 * ref_rs.abs()).any(-1).float().mean()
+        assert bad <= 0.03, f'rot_score bucket mismatches {bad}'
+    # torsions
+    un = torch.randn(n, 7, 2, generator=ge); gt = torch.randn(n, 7, 2, generator=ge)
+    ang = torch.empty(n, 7, 2, device=DEV)
+    ops.torsion_finalize(dev(un), dev(gt), dev(fixed.view(-1)), ang, n)
+    ref = torch.where(fixed.view(n, 1, 1).bool(), gt, O.l2_normalize(un))
+    check(ang, ref, 2e-6, 'torsion_finalize')
+    # sequence head tail: argmax + frames + atoms
+    P = Packed(dict(params), DEV)
+    logits = torch.randn(B, L, 20, generator=ge)
+    seq_t = torch.randint(0, 21, (B, L), generator=ge)
+    a37 = torch.as_tensor(__import__('abx_amd.residue_constants', fromlist=['x']).restype_atom37_to_atom14)[torch.randint(0, 20, (B, L), generator=ge)].long()
+    angles = O.l2_normalize(torch.randn(B, L, 7, 2, generator=ge))
+    rg = torch.cat([q_fin, t * 10], -1)
+    seq0 = torch.empty(n, dtype=torch.int64, device=DEV); a14 = torch.empty(n, 14, 3, device=DEV); a37o = torch.empty(n, 37, 3, device=DEV)
+    ops.seq_head_atoms(dev(logits), dev(fixed.view(-1)), dev(seq_t), dev(rg), dev(angles), dev(a37), P.default_frames, P.group_idx,
+                       P.lit_pos, seq0, a14, a37o, n)
+    s0 = logits.argmax(-1) * (1 - fixed) + seq_t * fixed
+    assert torch.equal(seq0.cpu().view(B, L), s0)
+    fR, ft = O.torsion_angles_to_frames(s0, O.quat_to_rot(rg[..., :4]), rg[..., 4:], angles)
+    ref14 = O.frames_to_atom14(s0, fR, ft)
+    check(a14.view(B, L, 14, 3), ref14, 3e-6, 'atom14')
+    check(a37o.view(B, L, 37, 3), O.atom14_to_atom37(ref14, a37), 3e-6, 'atom37')
+    # get_prev distogram
+    pp = cfg.model.embeddings_and_seqformer.prev_pos
+    sq = torch.square(torch.linspace(pp.min_bin, pp.max_bin, steps=pp.num_bins - 1))
+    out = torch.empty(B, L, L, dtype=torch.int64, device=DEV)
+    atoms = O.atom14_to_atom37(ref14, a37)
+    ops.prev_pos(dev(atoms), dev(sq), out, B, L)
+    refb = O.dgram_from_positions(O.pseudo_beta_v2(atoms), **dict(pp))
+    assert (out.cpu() != refb).float().mean() < 2e-3
+    # pLDDT
+    lg = torch.randn(n, 50, generator=ge)
+    pl = torch.empty(n, device=DEV)
+    ops.plddt(dev(lg), pl, n, 50)
+    centers = torch.arange(start=0.01, end=1.0, step=0.02)
+    check(pl, (torch.softmax(lg, -1) * centers).sum(-1) * 100, 2e-6, 'plddt')
+
+
+def test_igso3_tables_kernel(ops):
+    gd = load_npz('igso3_small.npz')
+    sig, om = tt(gd['small_sigma']), tt(gd['small_omega'])
+    pdf = torch.empty(40, 40, device=DEV); cdf = torch.empty(40, 40, device=DEV); sn = torch.empty(40, 40, device=DEV)
+    ops.igso3_tables(sig.to(DEV), om.to(DEV), pdf, cdf, sn)
+    check(pdf, tt(gd['small_pdf']), 1e-4, 'igso3 pdf')
+    check(cdf, tt(gd['small_cdf']), 1e-4, 'igso3 cdf')
+    d = (sn.cpu() - tt(gd['small_score_norms'])).abs()
+    assert float((d > 2e-2 + 1e-3 * tt(gd['small_score_norms']).abs()).float().mean()) == 0.0, 'igso3 score norms'
+    # spot rows of the full 1000x1000 tables
+    big_sig, big_om = tt(gd['big_sigma']), tt(gd['big_omega'])
+    pdf = torch.empty(1000, 1000, device=DEV); cdf = torch.empty(1000, 1000, device=DEV); sn = torch.empty(1000, 1000, device=DEV)
+    ops.igso3_tables(big_sig.to(DEV), big_om.to(DEV), pdf, cdf, sn)
+    i, j = gd['spot_i'], gd['spot_j']
+    check(pdf.cpu()[i, j], tt(gd['spot_pdf']), 1e-4, 'igso3 big pdf spots')
+    check(cdf.cpu()[i, j], tt(gd['spot_cdf']), 1e-4, 'igso3 big cdf spots')
+    rows = gd['rows']
+    d = (sn.cpu()[rows] - tt(gd['rows_score_norms'])).abs()
+    assert float((d > 5e-2 + 2e-3 * tt(gd['rows_score_norms']).abs()).float().mean()) < 1e-3, 'igso3 big score norm rows'
+
+
+def test_reverse_step_golden(ops, cfg):
+    """Reference FullDiffuser.reverse (fp64 state, recorded noise) vs abx_reverse_step: tokens exact, rigids to 1e-9."""
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    s = load_npz('step_tiny.npz')
+    D = FullDiffuser(cfg.diffuser)
+    D.set_tables(torch.zeros(1000, 1000), torch.zeros(1000, 1000), torch.zeros(1000, 1000), DEV)
+    dm = tt(s['diffuse_mask']).to(DEV)
+    for i in range(3):
+        gg = lambda k: tt(s[f's{i}.{k}']).to(DEV)
+        noise = dict(z_rot=gg('z_rot'), z_trans=gg('z_trans'), jumps=gg('jumps'))
+        rig, seq = D.reverse(rigid_t=gg('rigid_in'), seq_t=gg('seq_in'), rot_score=gg('rot_score'), trans_score=gg('trans_score'),
+                             logits_t=gg('logits'), t=gg('t'), dt=float(s['dt']), diffuse_mask=dm, noise=noise)
+        assert rig.dtype == torch.float64 and seq.dtype == torch.int64
+        assert torch.equal(seq.cpu(), tt(s[f's{i}.seq_out'])), f'step {i} tokens'
+        ref = tt(s[f's{i}.rigid_out'])
+        err = (rig.cpu() - ref).abs().max().item()
+        assert err < 1e-9 * max(1.0, ref.abs().max().item()), f'step {i} rigids err {err}'
+        ts = D.score_scaling(gg('t'))[1]
+        assert (ts.cpu() - tt(s[f's{i}.trans_score_scaling'])).abs().max() < 1e-12
+
+
+def test_reverse_step_device_rng_properties(ops, cfg):
+    """Philox path: deterministic, batch-composition invariant (keyed by sample id), fixed residues untouched."""
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    D = FullDiffuser(cfg.diffuser)
+    D.set_tables(torch.zeros(1000, 1000), torch.zeros(1000, 1000), torch.zeros(1000, 1000), DEV)
+    B, L = 4, 50
+    ge = g(70)
+    rig = torch.cat([torch.nn.functional.normalize(torch.randn(B, L, 4, generator=ge), dim=-1), torch.randn(B, L, 3, generator=ge) * 10], -1).double().to(DEV)
+    seq = torch.randint(0, 20, (B, L), generator=ge).to(DEV)
+    rs = torch.randn(B, L, 3, generator=ge).to(DEV); tsx = torch.randn(B, L, 3, generator=ge).double().to(DEV)
+    lg = torch.randn(B, L, 20, generator=ge).to(DEV)
+    dm = (torch.rand(B, L, generator=ge) > 0.5).int().to(DEV)
+    t = torch.full((B,), 0.5, dtype=torch.float64, device=DEV)
+    ids = torch.arange(B, device=DEV) + 10
+    D.seed = 123
+    a = D.reverse(rig, seq, rs, tsx, lg, t, 0.01, dm, sample_ids=ids, step=7)
+    b = D.reverse(rig, seq, rs, tsx, lg, t, 0.01, dm, sample_ids=ids, step=7)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    sub = [2, 0]
+    c = D.reverse(rig[sub], seq[sub], rs[sub], tsx[sub], lg[sub], t[sub], 0.01, dm[sub], sample_ids=ids[sub], step=7, center=False)
+    d = D.reverse(rig, seq, rs, tsx, lg, t, 0.01, dm, sample_ids=ids, step=7, center=False)
+    assert torch.equal(c[0], d[0][sub]) and torch.equal(c[1], d[1][sub])
+    fixed = dm == 0
+    assert torch.equal(a[1][fixed], seq[fixed])
+    assert (a[0][..., 4:][fixed] - rig[..., 4:][fixed]).abs().max() == 0
+    assert torch.isfinite(a[0]).all() and int(a[1].min()) >= 0 and int(a[1].max()) <= 19
+    e = D.reverse(rig, seq, rs, tsx, lg, t, 0.01, dm, sample_ids=ids, step=8)
+    assert not torch.equal(a[0], e[0])

@@ -1,0 +1,242 @@
+"""Model-level parity on an MI355X (`pytest -m gpu`): the HIP ScoreNetwork / FullDiffuser / sampler against
+(1) the committed golden vectors produced by the reference itself, (2) the oracle on larger seeded inputs, and
+(3) size-independent properties at BASELINE-scale lengths."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, tt, feat_batch_from_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(a, b, atol, rtol, name):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = np.abs(a - b)
+    assert np.all(np.isfinite(a)), f'{name}: non-finite output'
+    assert np.all(err <= atol + rtol * np.abs(b)), f'{name}: max err {err.max():.3e} (atol {atol} rtol {rtol}), max|ref| {np.abs(b).max():.3e}'
+
+
+def to_dev(b):
+    out = {}
+    for k, v in b.items():
+        if torch.is_tensor(v):
+            out[k] = v.to(DEV)
+        elif isinstance(v, tuple):
+            out[k] = tuple(x.to(DEV) for x in v)
+        else:
+            out[k] = v
+    return out
+
+
+@pytest.fixture(scope='module')
+def gpu_model(params, cfg, oracle_diffuser):
+    from abx_amd.model.abx import ScoreNetwork
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    g = load_npz('igso3_small.npz')
+    so3 = oracle_diffuser.so3
+    sn, cdf = so3._score_norms.clone(), so3._cdf.clone()
+    sn[g['rows']] = tt(g['rows_score_norms'])
+    cdf[g['rows']] = tt(g['rows_cdf'])
+    so3._score_norms, so3._cdf = sn, cdf                 # oracle and product use identical (reference-pinned) tables
+    D = FullDiffuser(cfg.diffuser)
+    D.set_tables(so3._pdf, cdf, sn, DEV)
+    m = ScoreNetwork(cfg.model, D)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).eval()
+    return m, D
+
+
+def test_full_call_matches_reference_golden(gpu_model, cfg):
+    """One in-loop ScoreNetwork call (2 recycles + final pass, fp64 t): HIP path vs the reference's own outputs."""
+    model, D = gpu_model
+    m = load_npz('modules_tiny.npz')
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    for k in ('seq_t', 'rigids_t', 't', 'prev_pos', 'prev_seq', 'prev_pair', 'rot_score_scaling', 'trans_score_scaling'):
+        b[k] = tt(m['in.' + k])
+    b = to_dev(b)
+    model.invalidate_static()
+    ret = model(b)
+    torch.cuda.synchronize()
+    f = ret['heads']['folding']
+    assert torch.equal(b['seq_t'].cpu(), tt(m['final.seq_t_after']))
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'].cpu(), tt(m['out.seq_0']))
+    close(ret['representations']['seq'], m['out.seq'], 1e-4, 1e-5, 'trunk seq')
+    close(ret['representations']['pair'], m['out.pair'], 2e-4, 1e-5, 'trunk pair')
+    close(f['rigids'], m['out.rigids'], 1e-4, 1e-4, 'rigids')                       # north_star: 1e-4 on frames
+    close(f['representations']['structure_module'], m['out.structure_module'], 2e-4, 1e-5, 'structure_module')
+    close(f['sidechains'][-1]['angles_sin_cos'], m['out.angles'], 2e-4, 0, 'angles')
+    close(f['final_atom14_positions'], m['out.atom14'], 5e-4, 1e-5, 'atom14')
+    close(f['final_atom_positions'], m['out.atom37'], 5e-4, 1e-5, 'atom37')
+    close(ret['heads']['sequence_module']['logits'], m['out.logits'], 2e-4, 1e-5, 'logits')
+    close(ret['heads']['predicted_lddt']['pLDDT'], m['out.pLDDT'], 2e-3, 1e-5, 'pLDDT')
+    assert f['trans_score'].dtype == torch.float64 and f['rot_score'].dtype == torch.float32
+    close(f['trans_score'], m['out.trans_score'], 2e-4, 1e-5, 'trans_score')
+    rs, ref = f['rot_score'].cpu().numpy(), m['out.rot_score']
+    bad = (np.abs(rs - ref) > 2e-4 + 1e-4 * np.abs(ref)).reshape(-1, 3).any(axis=1).mean()
+    assert bad <= 0.02, f'rot_score bucket mismatches {bad}'
+    from abx_amd.model.abx import get_prev
+    prev = get_prev(b, ret, cfg.model)
+    assert (prev['prev_pos'].cpu().numpy() != m['out.prev_pos']).mean() < 1e-3
+    assert prev['prev_pair'].data_ptr() == ret['representations']['pair'].data_ptr()
+
+
+def test_static_embeddings_match_oracle(gpu_model, params, cfg):
+    from oracle import abx_oracle as O
+    model, D = gpu_model
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    ss, ps = O.static_embeddings(params, b, cfg)
+    eng = model._get_engine(torch.device(DEV))
+    s2, p2 = eng.static_embeddings(to_dev(b), shared=False)
+    close(s2, ss, 3e-5, 1e-5, 'static seq')
+    close(p2, ps, 3e-5, 1e-5, 'static pair')
+
+
+def test_warmup_call_fp32_t(gpu_model, cfg):
+    model, D = gpu_model
+    from abx_amd import sampler
+    m = load_npz('modules_tiny.npz')
+    b = to_dev(feat_batch_from_golden(load_npz('feat_tiny.npz')))
+    ones = torch.ones(b['seq'].shape[0], device=DEV)
+    b = sampler.set_t_feats(b, D, float(np.linspace(0.01, 1.0, 100)[::-1][0]), ones)
+    assert b['t'].dtype == torch.float32
+    model.invalidate_static()
+    ret = model(b)
+    assert ret['heads']['folding']['trans_score'].dtype == torch.float32
+    close(ret['heads']['folding']['rigids'], m['warm.rigids'], 1e-4, 1e-4, 'warm rigids')
+    close(ret['heads']['sequence_module']['logits'], m['warm.logits'], 2e-4, 1e-5, 'warm logits')
+    close(ret['heads']['folding']['trans_score'], m['warm.trans_score'], 2e-4, 1e-4, 'warm trans_score')
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'].cpu(), tt(m['warm.seq_0']))
+
+
+def test_short_trajectory_matches_reference_golden(gpu_model, cfg):
+    """The reference's sample_fn (num_t=4, trajectory mode) vs the HIP sampler under the recorded noise:
+    tokens exact at every step, frames / atoms within tolerance."""
+    from abx_amd import sampler
+    model, D = gpu_model
+    tj = load_npz('traj_tiny.npz')
+    b = to_dev(feat_batch_from_golden(load_npz('feat_tiny.npz')))
+
+    def noise_fn(k):
+        return dict(z_rot=tt(tj[f'n{k}.z_rot']).to(DEV), z_trans=tt(tj[f'n{k}.z_trans']).to(DEV), jumps=tt(tj[f'n{k}.jumps']).to(DEV))
+
+    traj = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=4, noise_fn=noise_fn)
+    assert len(traj) == 4
+    for k, d in enumerate(traj):
+        assert float(d['time']) == float(tj[f'k{k}.time'])
+        assert np.array_equal(d['seq'].cpu().numpy(), tj[f'k{k}.seq']), f'step {k}: tokens differ'
+        close(d['atom14_results'], tj[f'k{k}.atom14'], 5e-3, 1e-4, f'step {k} atom14')
+        close(d['pLDDT'], tj[f'k{k}.pLDDT'], 1e-2, 1e-4, f'step {k} pLDDT')
+    close(traj[-1]['rigids_t'], tj['final.rigids_t'], 2e-3, 1e-4, 'final rigids')
+    only_last = sampler.sample_fn(b, cfg, D, model, mode='design', num_t=4, noise_fn=noise_fn)
+    assert len(only_last) == 1 and torch.equal(only_last[0]['seq'], traj[-1]['seq'])
+
+
+def _synthetic_batch(D, name, B, seed=3, n_masked_tail=0, dev=DEV):
+    from abx_amd import synthetic, features
+    w = synthetic.WORKLOADS[name] if isinstance(name, str) else name
+    cx = synthetic.make_complex(seed=seed, n_masked_tail=n_masked_tail, **w)
+    raw = {k: v.to(dev) for k, v in synthetic.replicate(cx, B).items()}
+    torch.manual_seed(11)
+    return features.build_features(raw, D)
+
+
+def test_medium_complex_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
+    """L = 72 (not a multiple of any tile), 3 samples with different noise, chunked 2+1, padded antigen tail:
+    one full call (3 passes) HIP vs oracle."""
+    from oracle import abx_oracle as O
+    model, D = gpu_model
+    w = dict(L_heavy=30, L_light=26, L_antigen=16, cdr=(20, 27))
+    b = _synthetic_batch(D, w, B=3, n_masked_tail=2)
+    t_ = torch.full((3,), 0.6060606060606061, dtype=torch.float64, device=DEV)
+    from abx_amd import sampler
+    b = sampler.set_t_feats(b, D, t_, torch.ones(3, device=DEV))
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else tuple(x.cpu() for x in v) if isinstance(v, tuple) else v) for k, v in b.items()}
+    model.max_chunk = 2
+    model.invalidate_static()
+    ret = model(b)
+    model.max_chunk = 16
+    ref = O.score_network(params, cpu, cfg, oracle_diffuser)
+    f, fr = ret['heads']['folding'], ref['heads']['folding']
+    agree = (ret['heads']['sequence_module']['seq_0'].cpu() == ref['heads']['sequence_module']['seq_0']).float().mean()
+    assert agree == 1.0, f'seq_0 agreement {agree}'
+    close(ret['representations']['pair'], ref['representations']['pair'], 3e-4, 1e-4, 'pair')
+    close(f['rigids'], fr['rigids'], 2e-4, 1e-4, 'rigids')
+    close(f['final_atom14_positions'], fr['final_atom14_positions'], 1e-3, 1e-4, 'atom14')
+    close(ret['heads']['sequence_module']['logits'], ref['heads']['sequence_module']['logits'], 3e-4, 1e-4, 'logits')
+    close(f['trans_score'], fr['trans_score'], 3e-4, 1e-4, 'trans_score')
+    close(ret['heads']['predicted_lddt']['pLDDT'], ref['heads']['predicted_lddt']['pLDDT'], 5e-3, 1e-4, 'pLDDT')
+
+
+def test_full_size_properties(gpu_model, cfg):
+    """BASELINE-scale length (L = 352): finite outputs, sample-permutation equivariance, shared-context == per-sample
+    context, chunking invariance (bit-exact: every kernel is batch-independent)."""
+    model, D = gpu_model
+    from abx_amd import sampler
+    B = 3
+    b = _synthetic_batch(D, 'L352', B=B)
+    t_ = torch.full((B,), 0.5050505050505051, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+
+    def run(batch, chunk, shared):
+        bb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if shared:
+            bb['_shared_context'] = True
+        model.max_chunk = chunk
+        model.invalidate_static()
+        r = model(bb)
+        torch.cuda.synchronize()
+        return {'rigids': r['heads']['folding']['rigids'].clone(), 'logits': r['heads']['sequence_module']['logits'].clone(),
+                'pair': r['representations']['pair'][:, :8, :8].clone(), 'seq_0': r['heads']['sequence_module']['seq_0'].clone()}
+
+    a = run(b, 3, False)
+    for v in a.values():
+        assert torch.isfinite(v.double()).all()
+    c = run(b, 1, True)
+    for k in a:
+        assert torch.equal(a[k], c[k]), f'chunking / shared-context changed {k}'
+    perm = [2, 0, 1]
+    pb = {k: (v[perm] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in b.items()}
+    pb['rigidgroups_gt_frames'] = tuple(x[perm] for x in b['rigidgroups_gt_frames'])
+    d = run(pb, 3, False)
+    for k in a:
+        assert torch.equal(a[k][perm], d[k]), f'sample permutation changed {k}'
+    model.max_chunk = 16
+
+
+def test_device_rng_sampling_is_shard_invariant(gpu_model, cfg):
+    """4 samples run as one batch == the same samples run as two 'ranks' of 2 (per-sample Philox keys): the multi-GPU
+    sharding changes nothing but where a sample runs."""
+    from abx_amd import sampler, synthetic, features
+    model, D = gpu_model
+    cx = {k: v.to(DEV) for k, v in synthetic.make_complex(seed=5, **synthetic.WORKLOADS['tiny']).items()}
+
+    def feats_fn(batch, sid):
+        g = torch.Generator(device='cpu')
+        outs = []
+        for s in sid.tolist():                         # per-sample CPU generator: init noise independent of batching
+            g.manual_seed(1000 + s)
+            L = batch['seq'].shape[1]
+            outs.append(dict(rot_axis=torch.randn(1, L, 3, generator=g), rot_u=torch.rand(1, L, generator=g),
+                             trans_z=torch.randn(1, L, 3, generator=g), seq=torch.randint(0, 20, (1, L), generator=g)))
+        noise = {k: torch.cat([o[k] for o in outs]).to(DEV) for k in outs[0]}
+        return features.build_features(batch, D, noise=noise)
+
+    full = sampler.design_samples(cx, cfg, D, model, num_samples=4, num_t=3, seed=9, features_fn=feats_fn)
+    parts = []
+    for r in range(2):
+        ids = sampler.shard_sample_ids(4, r, 2)
+        batch = {k: v[None].expand(len(ids), *v.shape).contiguous() for k, v in cx.items()}
+        sid = torch.tensor(ids, device=DEV)
+        batch = feats_fn(batch, sid)
+        batch['_shared_context'] = True
+        D.seed = 9
+        parts.append(sampler.sample_fn(batch, cfg, D, model, num_t=3, sample_ids=sid)[-1])
+    seq = torch.cat([p['seq'] for p in parts])
+    atoms = torch.cat([p['atom14_results'] for p in parts])
+    assert torch.equal(full['seq'], seq)
+    assert torch.equal(full['atom14'], atoms)
+    assert len(set(map(tuple, full['seq'].cpu().tolist()))) >= 1

@@ -1,0 +1,151 @@
+"""CPU-only checks of the host side: C-ABI library loads and exports what include/abx_hip.h declares, ctypes structs
+match the C layout, state_dict contract, loud failure without a GPU, sample sharding + gather (gloo, world_size 2)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+HEADER = os.path.join(ROOT, 'include', 'abx_hip.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as ge
+    from abx_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(?:int|const char\*)\s+(abx_\w+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from abx_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in abx_hip.h but not exported by libabx_hip.so'
+        assert n in _lib.EXPORTED, f'{n} has no ctypes prototype'
+    assert set(_lib.EXPORTED) == set(names)
+    assert lib.abx_version() == 1
+
+
+def test_argument_checks_return_codes_without_gpu(lib):
+    """Null / malformed descriptors are rejected before any launch (no GPU needed)."""
+    from abx_amd._lib import AbxGemm
+    g = AbxGemm()
+    assert lib.abx_gemm(ctypes.byref(g), None) < 0
+    assert b'abx_gemm' in lib.abx_last_error_string()
+    assert lib.abx_row_stats(None, 0, 0, 1, 1, 0, 0, 1e-5, None, None) < 0
+    assert lib.abx_prev_pos(None, None, 0, None, 0, 0, None) < 0
+
+
+def test_ctypes_structs_match_c_layout():
+    from abx_amd import _lib
+    structs = {'AbxGemm': _lib.AbxGemm, 'AbxTriAttn': _lib.AbxTriAttn, 'AbxScoreArgs': _lib.AbxScoreArgs,
+               'AbxReverseArgs': _lib.AbxReverseArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(){']
+    for name, st in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f, _ in st._fields_:
+            lines.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines.append('return 0;}')
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, 'l.c'), os.path.join(d, 'l')
+        open(src, 'w').write('\n'.join(lines))
+        subprocess.check_call(['gcc', src, '-o', exe])
+        out = subprocess.check_output([exe]).decode().split('\n')
+    c_layout = dict(l.split() for l in out if l)
+    for name, st in structs.items():
+        assert int(c_layout[name]) == ctypes.sizeof(st), name
+        for f, _ in st._fields_:
+            assert int(c_layout[f'{name}.{f}']) == getattr(st, f).offset, f'{name}.{f}'
+
+
+def test_state_dict_contract(cfg, sd_shapes, params):
+    from abx_amd.model.abx import ScoreNetwork
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    m = ScoreNetwork(cfg.model, FullDiffuser(cfg.diffuser))
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert mine == list(sd_shapes.items())
+    m.load_state_dict(params, strict=True)
+    assert sum(v.numel() for v in m.state_dict().values()) == 10280278
+    # the reference's import paths resolve to the same classes
+    from abx.model.abx import ScoreNetwork as A, get_prev  # noqa: F401
+    from diffuser.full_diffuser import FullDiffuser as Fd
+    assert A is ScoreNetwork and Fd is FullDiffuser
+
+
+def test_product_path_has_no_cpu_fallback(cfg, params):
+    from abx_amd.model.abx import ScoreNetwork
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    from conftest import load_npz, feat_batch_from_golden
+    D = FullDiffuser(cfg.diffuser)
+    m = ScoreNetwork(cfg.model, D)
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    with pytest.raises(RuntimeError, match='MI355X'):
+        m(b)
+    with pytest.raises(RuntimeError, match='MI355X'):
+        D.score_scaling(torch.ones(2))
+    # and nothing under abx_amd/ imports the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'abx_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_shard_sample_ids():
+    from abx_amd.sampler import shard_sample_ids
+    for n in (1, 7, 100):
+        for w in (1, 2, 3, 8):
+            if w > n:
+                continue
+            ids = [shard_sample_ids(n, r, w) for r in range(w)]
+            assert sum(ids, []) == list(range(n))
+            assert max(map(len, ids)) - min(map(len, ids)) <= 1
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from abx_amd.sampler import shard_sample_ids, gather_results
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+n = 7
+ids = shard_sample_ids(n, rank, world)
+# fake per-sample results: value encodes the sample id
+local = {'seq': torch.tensor([[i, i + 1] for i in ids], dtype=torch.int64),
+         'atom14': torch.tensor([[[float(i)] * 3] * 2 for i in ids], dtype=torch.float32),
+         'rigids': torch.tensor([[float(i)] * 7 for i in ids], dtype=torch.float64)}
+out = gather_results(local, n, rank, world)
+assert out['seq'][:, 0].tolist() == list(range(n)), out['seq']
+assert out['rigids'].dtype == torch.float64 and out['rigids'][:, 0].tolist() == [float(i) for i in range(n)]
+assert out['atom14'].shape == (n, 2, 3)
+dist.barrier()
+dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def test_gather_results_gloo_world2():
+    with tempfile.TemporaryDirectory() as d:
+        w = os.path.join(d, 'w.py')
+        open(w, 'w').write(_WORKER)
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+        out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                              '--master-addr', '127.0.0.1', '--master-port', '29541', w, ROOT],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count('OK') == 2
