@@ -88,7 +88,7 @@ _PROTOS = {
     'abx_seq_attn_fwd': (I, [c_f, c_f, c_f, c_f, c_f, I, I, I, I, F, _S]),
     'abx_ipa_pack': (I, [c_f, c_f, c_f, c_f, c_f, c_f, I, I, F, _S]),
     'abx_ipa_attn': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
-    'abx_timestep_embedding': (I, [c_f, I, I, c_f, _S]),
+    'abx_timestep_embedding': (I, [c_f, c_f, I, I, c_f, _S]),
     'abx_assemble_seq': (I, [c_f, LL, c_f, c_f, I, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_opm_features': (I, [c_f, c_f, LL, c_f, I, I, I, _S]),

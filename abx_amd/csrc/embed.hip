@@ -6,16 +6,16 @@
 
 namespace {
 
-__global__ void timestep_embedding_kernel(const double* __restrict__ t, int B, int dim, float* __restrict__ out) {
+__global__ void timestep_embedding_kernel(const double* __restrict__ t, const float* __restrict__ freqs, int B, int dim,
+                                          float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int half = dim / 2;
     if (idx >= B * half) return;
     const int b = idx / half, i = idx % half;
-    // seqformer.py:56-62: timesteps * 10000 in t's own dtype (double in the loop), THEN .float(); frequencies in fp32
+    // seqformer.py:56-62: timesteps * 10000 in t's own dtype (double in the loop), THEN .float(); the fp32 frequency
+    // table exp(arange(half) * -log(10000)/(half-1)) comes from the host so that it is bit-identical to torch's
     const float tt = (float)(t[b] * 10000.0);
-    const float e = (float)(9.210340371976184 / (double)(half - 1));     // math.log(10000) / (half - 1), then fp32 mul
-    const float f = expf((float)i * -e);
-    const float arg = tt * f;
+    const float arg = tt * freqs[i];
     out[b * dim + i] = sinf(arg);
     out[b * dim + half + i] = cosf(arg);
 }
@@ -227,10 +227,10 @@ __global__ __launch_bounds__(256) void pair_embed_features_kernel(
 
 }  // namespace
 
-extern "C" int abx_timestep_embedding(const double* t, int B, int dim, float* out, hipStream_t st) {
-    ABX_REQUIRE(t && out && B > 0 && dim >= 4 && dim % 2 == 0, "abx_timestep_embedding: bad args");
+extern "C" int abx_timestep_embedding(const double* t, const float* freqs, int B, int dim, float* out, hipStream_t st) {
+    ABX_REQUIRE(t && freqs && out && B > 0 && dim >= 4 && dim % 2 == 0, "abx_timestep_embedding: bad args");
     const int n = B * dim / 2;
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 127) / 128), dim3(128), 0, st, t, B, dim, out);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 127) / 128), dim3(128), 0, st, t, freqs, B, dim, out);
     return abx_check_launch("abx_timestep_embedding");
 }
 

@@ -151,9 +151,18 @@ def ipa_attn(qpack, kpack, vpack, bias2d, z, mask, rots, trans, pw, feat, B, L):
                                    _p(feat), B, L, _stream()), 'abx_ipa_attn')
 
 
+_FREQS = {}
+
+
 def timestep_embedding(t64, dim, out):
+    import math
     assert t64.dtype == torch.float64
-    check(_lib.load().abx_timestep_embedding(_p(t64), t64.shape[0], dim, _p(out), _stream()), 'abx_timestep_embedding')
+    key = (dim, str(t64.device))
+    if key not in _FREQS:       # seqformer.py:58-59, computed by torch on the host exactly as the reference does
+        half = dim // 2
+        _FREQS[key] = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).to(t64.device)
+    check(_lib.load().abx_timestep_embedding(_p(t64), _p(_FREQS[key]), t64.shape[0], dim, _p(out), _stream()),
+          'abx_timestep_embedding')
     return out
 
 

@@ -95,6 +95,63 @@ class OpTimer:
         return sorted(((k, v[0], v[1], v[2], v[3]) for k, v in agg.items()), key=lambda x: -x[1])
 
 
+def cpu_baseline(args, D, batch, B, L, t_value):
+    """The oracle (CPU port of the same step definition) for ONE sample of the same complex, in a subprocess with a
+    bounded thread count and a hard timeout so that the default bench run stays within minutes."""
+    import subprocess
+    import tempfile
+    threads = min(32, os.cpu_count() or 1)
+    with tempfile.TemporaryDirectory() as d:
+        blob = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v) and not k.startswith('prev_'):
+                blob[k] = (v[:1] if v.dim() > 0 and v.shape[0] == B else v).cpu()
+        blob['rigids_t'] = blob['rigids_t'].double()
+        blob['_tables'] = dict(pdf=D._pdf.cpu(), cdf=D._cdf.cpu(), score_norms=D.score_norms.cpu())
+        blob['_t'] = t_value
+        torch.save(blob, os.path.join(d, 'in.pt'))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', d], env=env,
+                                 capture_output=True, text=True, timeout=420)
+            line = [x for x in out.stdout.splitlines() if x.startswith('CPU_BASELINE ')]
+            if out.returncode != 0 or not line:
+                return {'value': None, 'unit': 'sample-steps/s', 'cores': threads, 'kind': 'port',
+                        'sample': 'worker failed: ' + out.stderr[-300:]}
+            ctime = float(line[0].split()[1])
+        except subprocess.TimeoutExpired:
+            return {'value': None, 'unit': 'sample-steps/s', 'cores': threads, 'kind': 'port', 'sample': 'timed out after 420 s'}
+    return {'value': 1.0 / ctime, 'unit': 'sample-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 diffusion step of 1 sample at L={L} (same complex, weights, step definition; trajectory-invariant '
+                      f'embeddings cached as in the HIP path; CPU batching does not help, BASELINE.md section 2), {ctime:.1f} s '
+                      f'on {threads} threads of {os.cpu_count()} logical CPUs'}
+
+
+def cpu_baseline_worker(d):
+    from collections import OrderedDict as OD
+    from abx_amd import synthetic
+    from abx_amd.config import default_config
+    from oracle import abx_oracle as O
+    torch.set_num_threads(int(os.environ.get('OMP_NUM_THREADS', '8')))
+    blob = torch.load(os.path.join(d, 'in.pt'))
+    cfg = default_config()
+    keys = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'sd_keys.json')))
+    params = synthetic.random_state_dict(OD((k, tuple(s)) for k, s in keys), seed=7)
+    od = O.OracleDiffuser(cfg.diffuser, blob.pop('_tables'))
+    tc = torch.full((1,), blob.pop('_t'), dtype=torch.float64)
+    cpu = blob
+    with torch.no_grad():
+        cpu = O.set_t_feats(cpu, od, tc, torch.ones(1))
+        static = O.static_embeddings(params, cpu, cfg)
+        c0 = time.perf_counter()
+        ro = O.score_network(params, cpu, cfg, od, static)
+        cpu.update(O.get_prev(cpu, ro, cfg))
+        dm = (1 - cpu['fixed_mask']) * cpu['atom14_gt_exists'][..., 0]
+        od.reverse(cpu['rigids_t'], cpu['seq_t'], ro['heads']['folding']['rot_score'], ro['heads']['folding']['trans_score'],
+                   ro['heads']['sequence_module']['logits'], tc, torch.tensor(0.01), dm)
+        print('CPU_BASELINE', time.perf_counter() - c0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -220,34 +277,7 @@ def main():
                                     'tflops': (s[3] * s[2] / (s[1] / 1e3) / 1e12 if s[3] else None)} for s in summ[:12]]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import abx_oracle as O
-        so3 = D
-        tables = dict(pdf=so3._pdf.cpu(), cdf=so3._cdf.cpu(), score_norms=so3.score_norms.cpu())
-        od = O.OracleDiffuser(cfg.diffuser, tables)
-        cpu = {}
-        for k, v in batch.items():
-            if torch.is_tensor(v):
-                cpu[k] = v[:1].cpu() if v.dim() > 0 and v.shape[0] == B else v.cpu()
-            elif isinstance(v, tuple):
-                cpu[k] = tuple(x[:1].cpu() for x in v)
-        cpu = {k: v for k, v in cpu.items() if not k.startswith('prev_')}
-        cpu['rigids_t'] = cpu['rigids_t'].double()
-        ncore = os.cpu_count() or 1
-        torch.set_num_threads(ncore)
-        tc = torch.full((1,), float(grid[1]), dtype=torch.float64)
-        with torch.no_grad():
-            cpu = O.set_t_feats(cpu, od, tc, torch.ones(1))
-            static = O.static_embeddings(params, cpu, cfg)
-            c0 = time.perf_counter()
-            ro = O.score_network(params, cpu, cfg, od, static)
-            cpu.update(O.get_prev(cpu, ro, cfg))
-            dm = (1 - cpu['fixed_mask']) * cpu['atom14_gt_exists'][..., 0]
-            od.reverse(cpu['rigids_t'], cpu['seq_t'], ro['heads']['folding']['rot_score'], ro['heads']['folding']['trans_score'],
-                       ro['heads']['sequence_module']['logits'], tc, torch.tensor(0.01), dm)
-            ctime = time.perf_counter() - c0
-        result['cpu_baseline'] = {'value': 1.0 / ctime, 'unit': 'sample-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                                  'sample': f'1 step of 1 sample at L={L} (same complex, weights and step definition; '
-                                            f'trajectory-invariant embeddings cached as in the HIP path), {ctime:.1f} s'}
+        result['cpu_baseline'] = cpu_baseline(args, D, batch, B, L, float(grid[1]))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -256,4 +286,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == '--cpu-baseline-worker':
+        cpu_baseline_worker(sys.argv[2])
+    else:
+        main()

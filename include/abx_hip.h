@@ -104,8 +104,8 @@ int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, con
 /* ------------------------------------------------------------------------------------------------------------
  * Embedding assembly (seqformer.py:49-119,170-223) and small pair-stack helpers
  * ---------------------------------------------------------------------------------------------------------- */
-/* sinusoidal embedding of t*10000 (double product, then float) -> [B][dim] */
-int abx_timestep_embedding(const double* t, int B, int dim, float* out, hipStream_t stream);
+/* sinusoidal embedding of t*10000 (double product, then float) -> [B][dim]; freqs [dim/2] = exp(arange * -ln(1e4)/(dim/2-1)) */
+int abx_timestep_embedding(const double* t, const float* freqs, int B, int dim, float* out, hipStream_t stream);
 /* seq_act[b,l] = [ seq_static[b,l] (+ aa_table[seq_t[b,l]] for l < Lab) | temb[b] ] + LN(prev_seq[b,l]) */
 int abx_assemble_seq(const float* seq_static, long long ss_b, const float* aa_table, const long long* seq_t, int Lab,
                      const float* temb, const float* prev_seq, const float* gamma, const float* beta, float* out, int B,

@@ -233,10 +233,10 @@ def test_embedding_assembly(ops, params):
     t64 = torch.tensor([0.5050505050505051, 0.02], dtype=torch.float64)
     temb = torch.empty(B, 32, device=DEV)
     ops.timestep_embedding(t64.to(DEV), 32, temb)
-    check(temb, O.timestep_embedding(t64, 32), 2e-6, 'timestep embedding (fp64 t)')
+    check(temb, O.timestep_embedding(t64, 32), 5e-7, 'timestep embedding (fp64 t)')
     t32 = torch.tensor([1.0, 0.3], dtype=torch.float32)
     ops.timestep_embedding(t32.double().to(DEV), 32, temb)
-    check(temb, O.timestep_embedding(t32, 32), 2e-6, 'timestep embedding (fp32 t)')
+    check(temb, O.timestep_embedding(t32, 32), 5e-7, 'timestep embedding (fp32 t)')
     seq_static = torch.randn(B, L, 512, generator=g(50))
     pair_static = torch.randn(B, L, L, 128, generator=g(51))
     seq_t = torch.randint(0, 20, (B, L), generator=g(52))
@@ -323,8 +323,12 @@ def test_frames_scores_heads(ops, params, cfg, oracle_diffuser):
         assert ref_ts.dtype == ts.dtype
         check(ts.view(B, L, 3), ref_ts, 3e-6, f'trans_score f32={is32}')
         check(rigids.view(B, L, 7), torch.cat([q_fin, t * 10], -1), 3e-6, 'rigids')
-        bad = ((rot.view(B, L, 3).cpu() - ref_rs).abs() > 1e-4 + 1e-4 * ref_rs.abs()).any(-1).float().mean()
+        # fixed residues have q0^-1 q_t == identity: their rot_score is rounding noise / 2e-6 in the reference too and is
+        # discarded by the mask merge of FullDiffuser.reverse -> compare the diffused residues only
+        dif = fixed.bool().logical_not()
+        bad = ((rot.view(B, L, 3).cpu() - ref_rs).abs() > 1e-4 + 1e-4 * ref_rs.abs()).any(-1)[dif].float().mean()
         assert bad <= 0.03, f'rot_score bucket mismatches {bad}'
+        assert torch.isfinite(rot).all()
     # torsions
     un = torch.randn(n, 7, 2, generator=ge); gt = torch.randn(n, 7, 2, generator=ge)
     ang = torch.empty(n, 7, 2, device=DEV)
@@ -363,16 +367,45 @@ def test_frames_scores_heads(ops, params, cfg, oracle_diffuser):
     check(pl, (torch.softmax(lg, -1) * centers).sum(-1) * 100, 2e-6, 'plddt')
 
 
+def _igso3_truth(sig, om, L=1000):
+    """fp64 series + a first-order rounding bound of the fp32 evaluation (the score norm is a quotient of two cancelling
+    1000-term series: where the series ~ 0 the REFERENCE's own fp32 value is rounding noise, so parity is only
+    meaningful up to this condition-aware bound)."""
+    ls = torch.arange(L, dtype=torch.float64)[None, None]
+    e, o = sig.double()[:, None, None], om.double()[None, :, None]
+    w = (2 * ls + 1) * torch.exp(-ls * (ls + 1) * e ** 2 / 2)
+    hi, dhi = torch.sin(o * (ls + 0.5)), (ls + 0.5) * torch.cos(o * (ls + 0.5))
+    lo, dlo = torch.sin(o / 2), 0.5 * torch.cos(o / 2)
+    t1, t2 = w * hi / lo, w * (lo * dhi - hi * dlo) / lo ** 2
+    ex, ds = t1.sum(-1), t2.sum(-1)
+    # argument rounding of sin/cos((l+1/2) omega) in fp32 (|arg| up to ~3e3) dominates: d(arg) ~ eps * arg
+    eps = 6e-8
+    arg = (o * (ls + 0.5)).abs()
+    e1 = (eps * (t1.abs() + (w * dhi / lo).abs() * arg / (ls + 0.5))).sum(-1)
+    e2 = (eps * (t2.abs() + (w / lo ** 2).abs() * ((ls + 0.5) * hi.abs() * lo.abs() + dhi.abs() * dlo.abs()) * arg)).sum(-1)
+    score = ds / (ex + 1e-4)
+    bound = (e2 + score.abs() * e1) / (ex + 1e-4).abs()
+    pdf = ex * (1 - torch.cos(o[..., 0])) / np.pi
+    return pdf, score, bound, e1 * (1 - torch.cos(o[..., 0])) / np.pi
+
+
 def test_igso3_tables_kernel(ops):
     gd = load_npz('igso3_small.npz')
     sig, om = tt(gd['small_sigma']), tt(gd['small_omega'])
     pdf = torch.empty(40, 40, device=DEV); cdf = torch.empty(40, 40, device=DEV); sn = torch.empty(40, 40, device=DEV)
     ops.igso3_tables(sig.to(DEV), om.to(DEV), pdf, cdf, sn)
+    tp, tsn, bound, pb = _igso3_truth(sig, om)
+    for name, got in (('kernel', sn.cpu()), ('reference', tt(gd['small_score_norms']))):
+        viol = ((got.double() - tsn).abs() > 8 * bound + 1e-4 + 2e-5 * tsn.abs()).float().mean()
+        assert viol == 0, f'{name}: score norms outside the rounding bound ({viol})'
+    well = bound < 1e-3                                   # well-conditioned entries: plain parity with the reference
+    assert well.float().mean() > 0.5
+    d = (sn.cpu() - tt(gd['small_score_norms'])).abs()
+    assert float(d[well].max()) < 5e-3, f'well-conditioned score norms differ by {float(d[well].max())}'
+    assert ((pdf.cpu().double() - tp).abs() <= 8 * pb + 1e-6 + 1e-5 * tp.abs()).all()
     check(pdf, tt(gd['small_pdf']), 1e-4, 'igso3 pdf')
     check(cdf, tt(gd['small_cdf']), 1e-4, 'igso3 cdf')
-    d = (sn.cpu() - tt(gd['small_score_norms'])).abs()
-    assert float((d > 2e-2 + 1e-3 * tt(gd['small_score_norms']).abs()).float().mean()) == 0.0, 'igso3 score norms'
-    # spot rows of the full 1000x1000 tables
+    # rows of the full 1000x1000 tables used by the step tests
     big_sig, big_om = tt(gd['big_sigma']), tt(gd['big_omega'])
     pdf = torch.empty(1000, 1000, device=DEV); cdf = torch.empty(1000, 1000, device=DEV); sn = torch.empty(1000, 1000, device=DEV)
     ops.igso3_tables(big_sig.to(DEV), big_om.to(DEV), pdf, cdf, sn)
@@ -380,8 +413,13 @@ def test_igso3_tables_kernel(ops):
     check(pdf.cpu()[i, j], tt(gd['spot_pdf']), 1e-4, 'igso3 big pdf spots')
     check(cdf.cpu()[i, j], tt(gd['spot_cdf']), 1e-4, 'igso3 big cdf spots')
     rows = gd['rows']
+    _, tsn, bound, _ = _igso3_truth(big_sig[rows], big_om)
+    for name, got in (('kernel', sn.cpu()[rows]), ('reference', tt(gd['rows_score_norms']))):
+        viol = ((got.double() - tsn).abs() > 8 * bound + 1e-4 + 2e-5 * tsn.abs()).float().mean()
+        assert viol == 0, f'{name}: big-table score norms outside the rounding bound ({viol})'
+    well = bound < 1e-3
     d = (sn.cpu()[rows] - tt(gd['rows_score_norms'])).abs()
-    assert float((d > 5e-2 + 2e-3 * tt(gd['rows_score_norms']).abs()).float().mean()) < 1e-3, 'igso3 big score norm rows'
+    assert float(d[well].max()) < 5e-3, f'well-conditioned big score norms differ by {float(d[well].max())}'
 
 
 def test_reverse_step_golden(ops, cfg):
@@ -400,7 +438,10 @@ def test_reverse_step_golden(ops, cfg):
         assert torch.equal(seq.cpu(), tt(s[f's{i}.seq_out'])), f'step {i} tokens'
         ref = tt(s[f's{i}.rigid_out'])
         err = (rig.cpu() - ref).abs().max().item()
-        assert err < 1e-9 * max(1.0, ref.abs().max().item()), f'step {i} rigids err {err}'
+        # step 0 starts from float32 rigids (sample_ref): its quaternion <-> rotation-vector maps run in fp32 in the
+        # reference, so parity is at fp32 rounding; later steps carry float64 state and agree to 1e-9
+        tol = 2e-6 if s[f's{i}.rigid_in'].dtype == np.float32 else 1e-9
+        assert err < tol * max(1.0, ref.abs().max().item()), f'step {i} rigids err {err}'
         ts = D.score_scaling(gg('t'))[1]
         assert (ts.cpu() - tt(s[f's{i}.trans_score_scaling'])).abs().max() < 1e-12
 

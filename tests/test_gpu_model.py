@@ -76,7 +76,8 @@ def test_full_call_matches_reference_golden(gpu_model, cfg):
     assert f['trans_score'].dtype == torch.float64 and f['rot_score'].dtype == torch.float32
     close(f['trans_score'], m['out.trans_score'], 2e-4, 1e-5, 'trans_score')
     rs, ref = f['rot_score'].cpu().numpy(), m['out.rot_score']
-    bad = (np.abs(rs - ref) > 2e-4 + 1e-4 * np.abs(ref)).reshape(-1, 3).any(axis=1).mean()
+    dif = (b['fixed_mask'].cpu().numpy() == 0).reshape(-1)      # fixed residues: rot_score is rounding noise, masked out later
+    bad = (np.abs(rs - ref) > 2e-4 + 1e-4 * np.abs(ref)).reshape(-1, 3).any(axis=1)[dif].mean()
     assert bad <= 0.02, f'rot_score bucket mismatches {bad}'
     from abx_amd.model.abx import get_prev
     prev = get_prev(b, ret, cfg.model)
