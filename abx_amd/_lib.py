@@ -22,7 +22,7 @@ class AbxGemm(C.Structure):
         ('M', I), ('N', I), ('K', I), ('batch', I),
         ('c_transposed', I),
         ('ln_stats', c_f), ('sSb', LL),
-        ('ln_gamma', c_f), ('ln_beta', c_f),
+        ('ln_csum', c_f),
         ('a_relu', I),
         ('bias', c_f),
         ('alpha', F),
@@ -30,7 +30,9 @@ class AbxGemm(C.Structure):
         ('rowscale', c_f), ('sRSb', LL),
         ('gate', c_f), ('sGb', LL), ('sGm', LL), ('gate_sigmoid', I),
         ('resid', c_f), ('sRb', LL), ('sRm', LL),
-        ('a_vec_ok', I), ('b_vec_ok', I), ('c_vec_ok', I), ('force_a_mcontig', I),
+        ('stats_out', c_f), ('sSOb', LL), ('stats_eps', F),
+        ('tune', I),
+        ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
     ]
 
 
@@ -90,7 +92,7 @@ _PROTOS = {
     'abx_ipa_attn': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
     'abx_timestep_embedding': (I, [c_f, c_f, I, I, c_f, _S]),
     'abx_assemble_seq': (I, [c_f, LL, c_f, c_f, I, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
-    'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
+    'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_opm_features': (I, [c_f, c_f, LL, c_f, I, I, I, _S]),
     'abx_pair_mask': (I, [c_f, c_f, I, I, _S]),
     'abx_pair_embed_features': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),

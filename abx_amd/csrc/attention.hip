@@ -3,8 +3,9 @@
 // abx_tri_attn_fwd — triangle attention (reference abx/model/seqformer.py:506-550, Attention.forward :272-312) as a
 // flash-style fused kernel: the (B, L, 4, L, L) logits tensor (268 MB / sample at L = 256) is never materialised.
 // One workgroup per (b, row s, head h): K [L][48] and V [L][48] of that row are staged ONCE in LDS (padded strides 50 / 52
-// floats, conflict-free for the MFMA operand reads below); each of the 4 waves walks query tiles of 32 rows with an
-// online softmax over 64-key tiles.  Both contractions run on v_mfma_f32_16x16x4_f32 (exact fp32):
+// floats, conflict-free for the MFMA operand reads below); each of the 8 waves (2 per SIMD, so one wave's softmax VALU runs
+// under the other's MFMAs) walks query tiles of 16 rows with a base-2 online softmax over 64-key tiles; the pair bias of
+// a tile is fetched before its QK^T MFMAs.  Both contractions run on v_mfma_f32_16x16x4_f32 (exact fp32):
 //     S^T[key][q]  = sum_d K[key][d] * Q[q][d]        ("swapped" QK^T: a lane owns 4 keys of ONE query column, so the
 //                                                      softmax row reductions are in-lane + two cross-group shuffles)
 //     O^T[d][q]   += sum_key V[key][d] * P[key][q]    (P fragments feed the B operand straight from registers)
@@ -21,7 +22,10 @@ constexpr int TD = 48;        // head dim of triangle attention
 constexpr int LDK = 50;       // K row stride in LDS (floats): (key*50 + d) mod 32 distinct over 16 keys x 2 d
 constexpr int LDV = 52;       // V row stride: 4*52 mod 32 == 16 -> lane groups g land on disjoint bank halves
 
-__global__ __launch_bounds__(256) void tri_attn_kernel(const AbxTriAttn a) {
+constexpr int TRI_THREADS = 512;      // 8 waves = 2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs
+constexpr float LOG2E = 1.4426950408889634f;
+
+__global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;
     float* Ks = smem;
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void tri_attn_kernel(const AbxTriAttn a) {
 
     const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
     // ---- stage K, V of this (b, s, h) in LDS --------------------------------------------------------------
-    for (int idx = tid; idx < L * (TD / 4); idx += 256) {
+    for (int idx = tid; idx < L * (TD / 4); idx += TRI_THREADS) {
         const int key = idx / (TD / 4), c4 = idx % (TD / 4);
         const long long off = base + (long long)key * a.sl + c4 * 4;
         const f32x4 kv = *reinterpret_cast<const f32x4*>(a.k + off);
@@ -41,94 +45,102 @@ __global__ __launch_bounds__(256) void tri_attn_kernel(const AbxTriAttn a) {
         kd[0] = kv[0]; kd[1] = kv[1]; kd[2] = kv[2]; kd[3] = kv[3];
         *reinterpret_cast<f32x4*>(Vs + key * LDV + c4 * 4) = vv;
     }
+    // additive key mask for every key slot of the padded tiles: 0 (valid), finfo.min marker (masked), -inf (beyond L)
+    float* Ms = Vs + (size_t)L * LDV;
+    {
+        const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
+        for (int key = tid; key < ((L + 63) / 64) * 64; key += TRI_THREADS)
+            Ms[key] = key < L ? ((!km || km[key] != 0.f) ? 0.f : 1.f) : 2.f;
+    }
     __syncthreads();
 
     const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
-    const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
-    const int nqt = (L + 31) / 32, nkt = (L + 63) / 64;
+    const int nqt = (L + 15) / 16, nkt = (L + 63) / 64;
+    const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && (L % 4 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
+    const float qscale = a.scale * LOG2E;                       // softmax evaluated in base 2: exp(x) = exp2(x log2 e)
 
-    for (int qt = wave; qt < nqt; qt += 4) {
-        // ---- Q fragments (B operand of the swapped product): lane holds Q[q][kd*4 + g], pre-scaled
-        float qf[2][12];
-        int qrow[2];
+    for (int qt = wave; qt < nqt; qt += TRI_THREADS / 64) {
+        // ---- Q fragment (B operand of the swapped product): lane holds Q[q][kd*4 + g], pre-scaled
+        const int qrow = qt * 16 + lq;
+        const bool qok = qrow < L;
+        float qf[12];
+        {
+            const float* qp = a.q + base + (long long)(qok ? qrow : 0) * a.sl + g;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            qrow[u] = qt * 32 + u * 16 + lq;
-            const bool ok = qrow[u] < L;
-            const float* qp = a.q + base + (long long)(ok ? qrow[u] : 0) * a.sl + g;
-#pragma unroll
-            for (int kd = 0; kd < 12; ++kd) qf[u][kd] = ok ? qp[kd * 4] * a.scale : 0.f;
+            for (int kd = 0; kd < 12; ++kd) qf[kd] = qok ? qp[kd * 4] * qscale : 0.f;
         }
-        float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-        f32x4 o[2][3];
+        const float* brow = biasb ? biasb + (long long)(qok ? qrow : 0) * a.bias_sq : nullptr;
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4 o[3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) o[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < 3; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int kt = 0; kt < nkt; ++kt) {
-            f32x4 sc[2][4];
+            // ---- bias of this 64-key tile: issued first so the loads fly under the QK^T MFMAs
+            float bz[4][4];
+            if (bias_vec && kt * 64 + 64 <= L) {                 // starting node: 4 consecutive keys per lane -> one 16-B load
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + kt * 64 + sub * 16 + g * 4);
+                    bz[sub][0] = t4[0]; bz[sub][1] = t4[1]; bz[sub][2] = t4[2]; bz[sub][3] = t4[3];
+                }
+            } else {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = min(kt * 64 + sub * 16 + g * 4 + r, L - 1);
+                        bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
+                    }
+            }
+            f32x4 sc[4];
             // ---- S^T tiles: 4 sub-blocks of 16 keys
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
                 const int kb = kt * 64 + sub * 16;
                 const int krow = min(kb + lq, L - 1);
                 const float* kp = Ks + krow * LDK + g;
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kd = 0; kd < 12; ++kd) {
-                    const float kf = kp[kd * 4];
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf[0][kd], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf[1][kd], c1, 0, 0, 0);
-                }
-                // this lane: keys kb + g*4 + r (r = 0..3), query column lq of sub-tile u
+                for (int kd = 0; kd < 12; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kd * 4], qf[kd], c0, 0, 0, 0);
+                sc[sub] = c0;
+            }
+            // this lane: keys kb + g*4 + r (r = 0..3) of query column lq
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + kt * 64 + sub * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kb + g * 4 + r;
-                    const bool kin = key < L;
-                    const bool kok = kin && (!km || km[key] != 0.f);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        float v = u == 0 ? c0[r] : c1[r];
-                        if (biasb && kin && qrow[u] < L)
-                            v += biasb[(long long)qrow[u] * a.bias_sq + (long long)key * a.bias_sk];
-                        v = kin ? (kok ? v : ABX_NEG_MAX) : -INFINITY;
-                        if (u == 0) c0[r] = v; else c1[r] = v;
-                    }
+                    float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                    v = mk[r] == 0.f ? v : (mk[r] == 1.f ? ABX_NEG_MAX : -INFINITY);
+                    sc[sub][r] = v;
+                    mx = fmaxf(mx, v);
                 }
-                sc[0][sub] = c0;
-                sc[1][sub] = c1;
             }
-            // ---- online softmax update per query column
+            // ---- online softmax update of this query column
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // m_run = -inf on the first tile -> 0
+            float rs = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float mx = -INFINITY;
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                for (int sub = 0; sub < 4; ++sub)
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sc[sub][r] - m_new);   // arguments <= 0: raw v_exp_f32
+                    sc[sub][r] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[u][sub][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float m_new = fmaxf(m_run[u], mx);
-                const float alpha = expf(m_run[u] - m_new);     // m_run = -inf on the first tile -> 0
-                float rs = 0.f;
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = expf(sc[u][sub][r] - m_new);
-                        sc[u][sub][r] = p;
-                        rs += p;
-                    }
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
-                l_run[u] = l_run[u] * alpha + rs;
-                m_run[u] = m_new;
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[u][d][r] *= alpha;
-            }
+                for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
             // ---- O^T += V^T P : MFMA step (sub, r) contracts keys {kb + g*4 + r : g = 0..3}
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
@@ -138,25 +150,20 @@ __global__ __launch_bounds__(256) void tri_attn_kernel(const AbxTriAttn a) {
                     const int key = min(kb + g * 4 + r, L - 1);    // p == 0 for keys >= L
                     const float* vp = Vs + key * LDV + lq;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const float vf = vp[d * 16];
-                        o[0][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sc[0][sub][r], o[0][d], 0, 0, 0);
-                        o[1][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sc[1][sub][r], o[1][d], 0, 0, 0);
-                    }
+                    for (int d = 0; d < 3; ++d)
+                        o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[d * 16], sc[sub][r], o[d], 0, 0, 0);
                 }
             }
         }
         // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (qrow[u] >= L) continue;
-            const float inv = 1.0f / l_run[u];
-            const long long go = base + (long long)qrow[u] * a.sl;
-            float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow[u] * a.ol + h * TD;
+        if (qok) {
+            const float inv = 1.0f / l_run;
+            const long long go = base + (long long)qrow * a.sl;
+            float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const int dd = d * 16 + g * 4;
-                f32x4 v = o[u][d];
+                f32x4 v = o[d];
                 if (a.gate) {
                     const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
 #pragma unroll
@@ -236,8 +243,8 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
-    const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV) * sizeof(float);
-    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout (L <= 401)");
+    const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64) * sizeof(float);
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout (L <= 397)");
     static thread_local size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_attn_kernel),
@@ -245,7 +252,7 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
         configured = 160 * 1024;
     }
-    hipLaunchKernelGGL(tri_attn_kernel, dim3(a.H, a.S, a.B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(tri_attn_kernel, dim3(a.H, a.S, a.B), dim3(TRI_THREADS), lds, st, a);
     return abx_check_launch("abx_tri_attn_fwd");
 }
 

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void assemble_pair_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const long long* __restrict__ prev_pos,
                                                             const float* __restrict__ pos_table, float* __restrict__ out,
-                                                            long long rows, long long LL, int C, int E) {
+                                                            float* __restrict__ stats_out, long long rows, long long LL, int C,
+                                                            int E) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -96,14 +97,34 @@ __global__ __launch_bounds__(256) void assemble_pair_kernel(const float* __restr
     }
     const float* st = pair_static + (long long)b * ps_b + ij * C;
     const float* pt = prev_pos ? pos_table + prev_pos[row] * W : nullptr;
+    float y[4];
+    float ys = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = lane + u * 64;
+        y[u] = 0.f;
         if (k >= W) continue;
         float v = k < C ? st[k] : temb[b * E + ((k - C) % E)];
         if (pr) v += (x[u] - mean) * rstd * gamma[k] + beta[k];
         if (pt) v += pt[k];
         out[row * W + k] = v;
+        y[u] = v;
+        ys += v;
+    }
+    if (stats_out) {      // LayerNorm statistics of the assembled row for the first consumer (seq_attn.pair_norm), two-pass
+        const float om = wave_sum(ys) / (float)W;
+        float oq = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + u * 64;
+            const float d = k < W ? y[u] - om : 0.f;
+            oq += d * d;
+        }
+        oq = wave_sum(oq) / (float)W;
+        if (lane == 0) {
+            stats_out[2 * row] = om;
+            stats_out[2 * row + 1] = 1.0f / sqrtf(oq + 1e-5f);
+        }
     }
 }
 
@@ -247,14 +268,14 @@ extern "C" int abx_assemble_seq(const float* seq_static, long long ss_b, const f
 
 extern "C" int abx_assemble_pair(const float* pair_static, long long ps_b, const float* temb, const float* prev_pair,
                                  const float* gamma, const float* beta, const long long* prev_pos, const float* pos_table,
-                                 float* out, int B, int L, int C, int E, hipStream_t st) {
+                                 float* out, float* stats_out, int B, int L, int C, int E, hipStream_t st) {
     ABX_REQUIRE(pair_static && temb && out && B > 0 && L > 0, "abx_assemble_pair: bad args");
     ABX_REQUIRE(C + 2 * E <= 256, "abx_assemble_pair: width > 256");
     ABX_REQUIRE(!prev_pair || (gamma && beta), "abx_assemble_pair: LN params missing");
     ABX_REQUIRE(!prev_pos || pos_table, "abx_assemble_pair: pos table missing");
     const long long rows = (long long)B * L * L;
     hipLaunchKernelGGL(assemble_pair_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pair_static, ps_b, temb,
-                       prev_pair, gamma, beta, prev_pos, pos_table, out, rows, (long long)L * L, C, E);
+                       prev_pair, gamma, beta, prev_pos, pos_table, out, stats_out, rows, (long long)L * L, C, E);
     return abx_check_launch("abx_assemble_pair");
 }
 

@@ -1,28 +1,31 @@
 // Generic batched fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fma chain)
-// with a LayerNorm-on-load prologue and a fused epilogue.  One kernel serves every dense contraction of the
-// score network (reference sites: every abx.model.common_modules.Linear on the hot path, the
-// TriangleMultiplication einsum seqformer.py:490-493, the transitions seqformer.py:358-376).
+// with a fused LayerNorm and a fused epilogue.  One kernel serves every dense contraction of the score network
+// (reference sites: every abx.model.common_modules.Linear on the hot path, the TriangleMultiplication einsum
+// seqformer.py:490-493, the transitions seqformer.py:358-376).
 //
-//   C[b][m][n] = epi( sum_k A'[b][m][k] * B[b][k][n] )
-//   A' = relu?( LN?(A) )           LN uses per-row (mean, rstd) from abx_row_stats and gamma/beta over k
-//   epi(v)  = ((v + bias[n]) * alpha) -> act -> * rowscale[m] -> * (sigmoid?)(gate[m][n]) -> + resid[m][n]
+//   acc[b][m][n] = sum_k A'[b][m][k] * B[b][k][n]                      A' = relu?(A)
+//   LayerNorm over k (when ln_stats != NULL) is applied ALGEBRAICALLY in the epilogue: the caller passes B already scaled by
+//   gamma (B[k][n] = gamma[k] W[n][k]), csum[n] = sum_k B[k][n] and bias[n] = sum_k beta[k] W[n][k] + b[n]; then
+//       LN(A) W^T + b  ==  rstd[m] * (acc - mean[m] * csum[n]) + bias[n]
+//   so the operand loads are plain 16-byte loads that stay in flight under the MFMAs.
+//   epi(v) = ((ln(v) + bias[n]) * alpha) -> act -> * rowscale[m] -> * (sigmoid?)(gate[m][n]) -> + resid[m][n]
 //
-// Layout: A is either k-contiguous (sAk==1) or m-contiguous (sAm==1); B is n-contiguous (sBn==1, the packed
-// weight layout Wt[K][N]) or k-contiguous (sBk==1).  C is n-contiguous, or stored transposed (c_transposed:
-// element (m,n) at C + b*sCb + n*sCm + m) which is how the pair stack is turned channel-major for the
-// triangle-multiplication contraction without a separate transpose pass.
+// Layout: A is k-contiguous (sAk==1) or m-contiguous (sAm==1); B is n-contiguous (sBn==1, the packed weight layout
+// Wt[K][N]) or k-contiguous (sBk==1).  C is n-contiguous, or stored transposed (c_transposed: element (m,n) at
+// C + b*sCb + n*sCm + m): the epilogue stages 32x32 sub-tiles through LDS so the transposed store is made of full 128-byte
+// row segments — this is how the pair stack turns channel-major for the triangle-multiplication contraction without a
+// separate transpose pass.
 //
-// Tiling: 256 threads = 4 waves; block tile BMxBNx16 staged through double-buffered LDS as [k][m] / [k][n]
-// (+4 pad) so the MFMA operand reads (lane -> m, lane>>5 -> k) are conflict-free ds_read_b32; global->register
-// prefetch of tile t+1 overlaps the MFMAs of tile t; one barrier per k-tile.
+// Tiling: 256 threads = 4 waves; block tile BMxBNx16 staged through double-buffered LDS as [k][m] / [k][n] (+4 pad) so the
+// MFMA operand reads (lane -> m, lane>>5 -> k) are conflict-free; tile t+1 is prefetched into registers while tile t is on
+// the matrix cores; one barrier per k-tile.  Interior blocks run a guard-free path; edge blocks a fully predicated one.
+// Block ids are remapped so that the N-tiles of one M-panel run on the same XCD (private L2) back to back.
 #include "common.h"
 #include "abx_hip.h"
 
 namespace {
 
-constexpr int BK = 16;
-
-template <int BMN, bool KC>
+template <int BMN, int BK, bool KC, bool EDGE>
 struct TileLoader {
     static constexpr int NVEC = BMN * BK / 4;            // float4 slots in the tile
     static constexpr int NV = (NVEC + 255) / 256;        // per thread
@@ -30,21 +33,21 @@ struct TileLoader {
     f32x4 v[NV];
 
     // base already offset by batch.  s_mn / s_k: element strides of the (m|n) and k dims.
-    __device__ __forceinline__ void load(const float* __restrict__ base, long long s_mn, long long s_k, int mn0,
-                                         int k0, int MN, int K, bool vec_ok, const float* __restrict__ stats,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         bool relu) {
+    __device__ __forceinline__ void load(const float* __restrict__ base, long long s_mn, long long s_k, int mn0, int k0,
+                                         int MN, int K, bool vec_ok) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (idx < NVEC) {
+            if (NVEC % 256 == 0 || idx < NVEC) {
                 if (KC) {
                     const int row = idx / (BK / 4), kq = idx % (BK / 4);
                     const int mn = mn0 + row, k = k0 + kq * 4;
-                    if (mn < MN && k < K) {
-                        const float* p = base + (long long)mn * s_mn + k;
+                    const float* p = base + (long long)mn * s_mn + k;
+                    if (!EDGE) {
+                        r = *reinterpret_cast<const f32x4*>(p);
+                    } else if (mn < MN && k < K) {
                         if (vec_ok && k + 3 < K) {
                             r = *reinterpret_cast<const f32x4*>(p);
                         } else {
@@ -52,39 +55,20 @@ struct TileLoader {
                             for (int c = 0; c < 4; ++c)
                                 if (k + c < K) r[c] = p[c];
                         }
-                        if (stats) {
-                            const float mean = stats[2 * (long long)mn], rstd = stats[2 * (long long)mn + 1];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (k + c < K) r[c] = (r[c] - mean) * rstd * gamma[k + c] + beta[k + c];
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) r[c] = fmaxf(r[c], 0.f);
-                        }
                     }
                 } else {
                     const int krow = idx / (BMN / 4), mq = idx % (BMN / 4);
                     const int k = k0 + krow, mn = mn0 + mq * 4;
-                    if (k < K && mn < MN) {
-                        const float* p = base + (long long)k * s_k + mn;
+                    const float* p = base + (long long)k * s_k + mn;
+                    if (!EDGE) {
+                        r = *reinterpret_cast<const f32x4*>(p);
+                    } else if (k < K && mn < MN) {
                         if (vec_ok && mn + 3 < MN) {
                             r = *reinterpret_cast<const f32x4*>(p);
                         } else {
 #pragma unroll
                             for (int c = 0; c < 4; ++c)
                                 if (mn + c < MN) r[c] = p[c];
-                        }
-                        if (stats) {
-                            const float ga = gamma[k], be = beta[k];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (mn + c < MN)
-                                    r[c] = (r[c] - stats[2 * (long long)(mn + c)]) * stats[2 * (long long)(mn + c) + 1] * ga + be;
-                        }
-                        if (relu) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) r[c] = fmaxf(r[c], 0.f);
                         }
                     }
                 }
@@ -93,45 +77,43 @@ struct TileLoader {
         }
     }
 
-    __device__ __forceinline__ void store(float* __restrict__ lds) const {
+    __device__ __forceinline__ void store(float* __restrict__ lds, bool relu) const {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
-            if (idx < NVEC) {
+            if (NVEC % 256 == 0 || idx < NVEC) {
+                f32x4 r = v[i];
+                if (relu) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = fmaxf(r[c], 0.f);
+                }
                 if (KC) {
                     const int row = idx / (BK / 4), kq = idx % (BK / 4);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) lds[(kq * 4 + c) * LD + row] = v[i][c];
+                    for (int c = 0; c < 4; ++c) lds[(kq * 4 + c) * LD + row] = r[c];
                 } else {
                     const int krow = idx / (BMN / 4), mq = idx % (BMN / 4);
-                    *reinterpret_cast<f32x4*>(&lds[krow * LD + mq * 4]) = v[i];
+                    *reinterpret_cast<f32x4*>(&lds[krow * LD + mq * 4]) = r;
                 }
             }
         }
     }
 };
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BNC>
-__global__ __launch_bounds__(256) void gemm_kernel(const AbxGemm g) {
+template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool EDGE, bool TS>
+__device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA + 2 * BK * LDB];
     float* As = smem;
     float* Bs = smem + 2 * BK * LDA;
-
-    const int ntn = (g.N + BN - 1) / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
-    const int b = blockIdx.z;
     const int m0 = mt * BM, n0 = nt * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const float* Ab = g.A + (long long)b * g.sAb;
     const float* Bb = g.B + (long long)b * g.sBb;
-    const float* stats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -141,23 +123,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const AbxGemm g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    TileLoader<BM, AKC> la;
-    TileLoader<BN, !BNC> lb;   // B n-contiguous == "row-contiguous" loader; B k-contiguous == KC loader
-    const bool a_vec = g.a_vec_ok != 0, b_vec = g.b_vec_ok != 0;
+    TileLoader<BM, BK, AKC, EDGE> la;
+    TileLoader<BN, BK, !BNC, EDGE> lb;   // B n-contiguous == row-contiguous loader; B k-contiguous == KC loader
+    const bool a_vec = g.a_vec_ok != 0, b_vec = g.b_vec_ok != 0, relu = g.a_relu != 0;
     const long long a_smn = g.sAm, a_sk = g.sAk, b_smn = g.sBn, b_sk = g.sBk;
     const int nk = (g.K + BK - 1) / BK;
 
-    la.load(Ab, a_smn, a_sk, m0, 0, g.M, g.K, a_vec, stats, g.ln_gamma, g.ln_beta, g.a_relu != 0);
-    lb.load(Bb, b_smn, b_sk, n0, 0, g.N, g.K, b_vec, nullptr, nullptr, nullptr, false);
-    la.store(As);
-    lb.store(Bs);
+    la.load(Ab, a_smn, a_sk, m0, 0, g.M, g.K, a_vec);
+    lb.load(Bb, b_smn, b_sk, n0, 0, g.N, g.K, b_vec);
+    la.store(As, relu);
+    lb.store(Bs, false);
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) {
-            la.load(Ab, a_smn, a_sk, m0, (t + 1) * BK, g.M, g.K, a_vec, stats, g.ln_gamma, g.ln_beta, g.a_relu != 0);
-            lb.load(Bb, b_smn, b_sk, n0, (t + 1) * BK, g.N, g.K, b_vec, nullptr, nullptr, nullptr, false);
+            la.load(Ab, a_smn, a_sk, m0, (t + 1) * BK, g.M, g.K, a_vec);
+            lb.load(Bb, b_smn, b_sk, n0, (t + 1) * BK, g.N, g.K, b_vec);
         }
         const float* as = As + cur * BK * LDA + wm * WM + (lane & 31);
         const float* bs = Bs + cur * BK * LDB + wn * WN + (lane & 31);
@@ -176,58 +158,166 @@ __global__ __launch_bounds__(256) void gemm_kernel(const AbxGemm g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < nk) {
-            la.store(As + (cur ^ 1) * BK * LDA);
-            lb.store(Bs + (cur ^ 1) * BK * LDB);
+            la.store(As + (cur ^ 1) * BK * LDA, relu);
+            lb.store(Bs + (cur ^ 1) * BK * LDB, false);
         }
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // LDS is free now: stage the LayerNorm row statistics of this M-panel; transposed store: per-wave 32x33 scratch;
+    // stats_out: per-row partial sums of the two wave columns.
+    float* st_lds = smem;                                   // [BM][2]
+    float* scratch = smem + 2 * BM + wave * (32 * 33);       // 4 waves x 32 x 33
+    float* part = smem + 2 * BM + 4 * 32 * 33;               // [BM][WAVES_N][2]
+    const float* stats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
+    if (stats) {
+        for (int idx = threadIdx.x; idx < 2 * BM; idx += 256) {
+            const int m = m0 + (idx >> 1);
+            st_lds[idx] = (!EDGE || m < g.M) ? stats[2 * (long long)m + (idx & 1)] : 0.f;
+        }
+        __syncthreads();
+    }
     float* Cb = g.C + (long long)b * g.sCb;
     const float* rs = g.rowscale ? g.rowscale + (long long)b * g.sRSb : nullptr;
     const float* gt = g.gate ? g.gate + (long long)b * g.sGb : nullptr;
     const float* rd = g.resid ? g.resid + (long long)b * g.sRb : nullptr;
+    float bias[TN], csum[TN];
+    bool nok[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        nok[j] = !EDGE || n < g.N;
+        bias[j] = (g.bias && nok[j]) ? g.bias[n] : 0.f;
+        csum[j] = (stats && nok[j]) ? g.ln_csum[n] : 0.f;
+    }
+    auto epi = [&](float v, int ml, int m, int n, int j, bool ok) -> float {
+        if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
+        v = (v + bias[j]) * g.alpha;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+        if (ok) {
+            if (rs) v *= rs[m];
+            if (gt) {
+                const float gv = gt[(long long)m * g.sGm + n];
+                v *= g.gate_sigmoid ? 1.0f / (1.0f + expf(-gv)) : gv;
+            }
+            if (rd) v += rd[(long long)m * g.sRm + n];
+        }
+        return v;
+    };
+    if constexpr (!TS) {
+        const bool want_stats = g.stats_out != nullptr;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 32 + (lane & 31);
-            const bool nok = n < g.N;
-            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int mbase = m0 + wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5);
-                f32x4 out;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int m = mbase + c;
-                    float v = (acc[i][j][rq * 4 + c] + bias) * g.alpha;
-                    if (g.act == 1) v = fmaxf(v, 0.f);
-                    else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-                    if (nok && m < g.M) {
-                        if (rs) v *= rs[m];
-                        if (gt) {
-                            const float gv = gt[(long long)m * g.sGm + n];
-                            v *= g.gate_sigmoid ? 1.0f / (1.0f + expf(-gv)) : gv;
-                        }
-                        if (rd) v += rd[(long long)m * g.sRm + n];
-                        if (!g.c_transposed) Cb[(long long)m * g.sCm + n] = v;
-                    }
-                    out[c] = v;
-                }
-                if (g.c_transposed && nok) {
-                    float* p = Cb + (long long)n * g.sCm + mbase;
-                    if (g.c_vec_ok && mbase + 3 < g.M) {
-                        *reinterpret_cast<f32x4*>(p) = out;
-                    } else {
+                    const int ml = wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5) + c;
+                    const int m = m0 + ml;
+                    const bool mok = !EDGE || m < g.M;
+                    float sum = 0.f, sq = 0.f;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (mbase + c < g.M) p[c] = out[c];
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+                        const bool ok = nok[j] && mok;
+                        const float v = epi(acc[i][j][rq * 4 + c], ml, m, n, j, ok);
+                        if (ok) {
+                            Cb[(long long)m * g.sCm + n] = v;
+                            sum += v;
+                            sq = fmaf(v, v, sq);
+                        }
+                    }
+                    if (want_stats) {
+                        // row statistics of the values just written (the next LayerNorm's input), fixed reduction order
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) {
+                            sum += __shfl_xor(sum, o, 64);
+                            sq += __shfl_xor(sq, o, 64);
+                        }
+                        if ((lane & 31) == 0) {
+                            part[(ml * WAVES_N + wn) * 2] = sum;
+                            part[(ml * WAVES_N + wn) * 2 + 1] = sq;
+                        }
                     }
                 }
             }
         }
+        if (want_stats) {
+            __syncthreads();
+            for (int r = threadIdx.x; r < BM; r += 256) {
+                const int m = m0 + r;
+                if (EDGE && m >= g.M) continue;
+                float sum = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_N; ++w) {
+                    sum += part[(r * WAVES_N + w) * 2];
+                    sq += part[(r * WAVES_N + w) * 2 + 1];
+                }
+                const float inv = 1.0f / (float)g.N;
+                const float mean = sum * inv;
+                const float var = fmaxf(sq * inv - mean * mean, 0.f);
+                float* so = g.stats_out + 2 * ((long long)b * g.sSOb + m);
+                so[0] = mean;
+                so[1] = 1.0f / sqrtf(var + g.stats_eps);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = wn * WN + j * 32;
+                const int n = n0 + nl + (lane & 31);
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int ml = wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5) + c;
+                        const int m = m0 + ml;
+                        const float v = epi(acc[i][j][rq * 4 + c], ml, m, n, j, nok[j] && (!EDGE || m < g.M));
+                        scratch[(lane & 31) * 33 + 8 * rq + 4 * (lane >> 5) + c] = v;
+                    }
+                }
+                // scratch[n_local][m_local] -> rows of 32 consecutive m (128 B) per n
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int mloc = lane & 31;
+                const int mg = m0 + wm * WM + i * 32 + mloc;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const int nloc = rr * 2 + (lane >> 5);
+                    const int ng = n0 + nl + nloc;
+                    if (!EDGE || (ng < g.N && mg < g.M)) Cb[(long long)ng * g.sCm + mg] = scratch[nloc * 33 + mloc];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool TS, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_kernel(const AbxGemm g) {
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int OPER = 2 * BK * LDA + 2 * BK * LDB;
+    constexpr int EPI = 2 * BM + 4 * 32 * 33 + 4 * BM;
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntn = (g.N + BN - 1) / BN;
+    // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give each XCD a contiguous range of tiles so the
+    // N-tiles that share an A panel hit the same private L2.  Bijective for any grid size.
+    int wgid = blockIdx.x;
+    if (!(g.tune & 1)) {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = wgid / ntn, nt = wgid % ntn;
+    const int b = blockIdx.z;
+    const bool interior = g.fast_ok && (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N && (g.K % BK) == 0;
+    if (interior) gemm_block<BM, BN, WM, WN, BK, AKC, BNC, false, TS>(g, smem, mt, nt, b);
+    else gemm_block<BM, BN, WM, WN, BK, AKC, BNC, true, TS>(g, smem, mt, nt, b);
 }
 
 // ---- LayerNorm statistics -------------------------------------------------------------------------------
@@ -298,16 +388,28 @@ __global__ __launch_bounds__(256) void layernorm_kc(const float* __restrict__ x,
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 16, int MINW = 3>
 int launch_cfg(const AbxGemm& g, hipStream_t st) {
     const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
     dim3 grid((unsigned)(mt * ntn), 1, (unsigned)g.batch), block(256);
-    const bool akc = g.sAk == 1 && !(g.sAm == 1 && g.force_a_mcontig);
+    const bool akc = g.sAk == 1;
     const bool bnc = g.sBn == 1;
-    if (akc && bnc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, st, g);
-    else if (akc && !bnc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, st, g);
-    else if (!akc && bnc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, st, g);
+    if (g.c_transposed) {       // transposed store: weight GEMMs only (A k-contiguous activations, B packed weights)
+        if (!(akc && bnc)) { abx_set_error("abx_gemm: transposed store needs k-contiguous A and n-contiguous B"); return ABX_ERR_ARG; }
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, true, true, MINW>), grid, block, 0, st, g);
+    } else if (akc && bnc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, true, false, MINW>), grid, block, 0, st, g);
+    else if (akc && !bnc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, false, false, MINW>), grid, block, 0, st, g);
+    else if (!akc && bnc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, true, false, MINW>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, false, false, MINW>), grid, block, 0, st, g);
+    return abx_check_launch("abx_gemm");
+}
+
+// tuning variants of the main weight-GEMM configuration (selected by AbxGemm.tune bits 1..3; 0 = default)
+template <int BK, int MINW>
+int launch_main_variant(const AbxGemm& g, hipStream_t st) {
+    const long long mt = ((long long)g.M + 127) / 128, ntn = ((long long)g.N + 127) / 128;
+    dim3 grid((unsigned)(mt * ntn), 1, (unsigned)g.batch), block(256);
+    hipLaunchKernelGGL((gemm_kernel<128, 128, 64, 64, BK, true, true, false, MINW>), grid, block, 0, st, g);
     return abx_check_launch("abx_gemm");
 }
 
@@ -321,17 +423,33 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(g.batch <= 65535, "abx_gemm: batch > 65535");
     ABX_REQUIRE(g.sAk == 1 || g.sAm == 1, "abx_gemm: A must be k- or m-contiguous");
     ABX_REQUIRE(g.sBn == 1 || g.sBk == 1, "abx_gemm: B must be n- or k-contiguous");
-    ABX_REQUIRE(!g.ln_stats || (g.ln_gamma && g.ln_beta), "abx_gemm: LN needs gamma/beta");
-    const bool akc = g.sAk == 1 && !(g.sAm == 1 && g.force_a_mcontig);
+    ABX_REQUIRE(!g.ln_stats || g.ln_csum, "abx_gemm: LayerNorm needs the column sums of the gamma-scaled weights");
+    ABX_REQUIRE(!g.stats_out || (g.N <= 192 && !g.c_transposed), "abx_gemm: stats_out needs N <= 192 (one tile per row) and a plain store");
+    const bool akc = g.sAk == 1;
     // 16-byte vector loads need aligned bases and strides that are multiples of 4 elements
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     g.a_vec_ok = al16(g.A) && (g.sAb % 4 == 0) && (akc ? (g.sAm % 4 == 0) : (g.sAk % 4 == 0));
     g.b_vec_ok = al16(g.B) && (g.sBb % 4 == 0) && (g.sBn == 1 ? (g.sBk % 4 == 0) : (g.sBn % 4 == 0));
-    g.c_vec_ok = al16(g.C) && (g.sCb % 4 == 0) && (g.sCm % 4 == 0);
+    g.fast_ok = g.a_vec_ok && g.b_vec_ok;
     const long long mt128 = ((long long)g.M + 127) / 128;
+    if (g.stats_out && g.N > 128) return launch_cfg<128, 192, 64, 96, 16, 2>(g, st);
+    if (g.stats_out && g.N > 64) return launch_cfg<128, 128, 64, 64>(g, st);
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);
     if (mt128 * (((long long)g.N + 127) / 128) * g.batch < 512) return launch_cfg<64, 64, 32, 32>(g, st);
+    if (g.tune >> 1) {
+        ABX_REQUIRE(!g.c_transposed && akc && g.sBn == 1, "abx_gemm: tuning variants exist for the plain weight GEMM only");
+        switch (g.tune >> 1) {
+            case 1: return launch_main_variant<16, 2>(g, st);
+            case 2: return launch_main_variant<16, 4>(g, st);
+            case 3: return launch_cfg<128, 128, 64, 64, 16, 3>(g, st);
+            default: break;
+        }
+    }
+    // 128x192 tiles (96 accumulator registers per lane) when they waste no more columns than 128x128 tiles do: N = 192 (every
+    // residual-stream update of the pair stack), 768 (q|k|v|gate, transition hidden), 544 ...
+    const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;
+    if (pad192 <= pad128 && !(g.tune >> 1)) return launch_cfg<128, 192, 64, 96, 16, 2>(g, st);
     return launch_cfg<128, 128, 64, 64>(g, st);
 }
 

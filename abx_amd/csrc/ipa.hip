@@ -10,9 +10,10 @@
 //     phase A  logits[iq][h][j] = q.k + pw[h] * sum|q_pt - k_pt|^2 + bias2d[b,i,j,h]  (direct (q-k)^2 as the reference,
 //              not the expanded form: no cancellation at |x| ~ 10), mask fill finfo.min, into LDS laid out [iq][j][13]
 //     softmax  one wave per (iq, h) row: shuffle max / sum
-//     phase B1 scalar + point outputs: thread per (h, c<40), 4 accumulators (iq)
-//     phase B2 attention over the pair slab: thread per (channel c, head half): streams z[b,i,j,0:128] exactly once per
-//              query residue (512 B coalesced per j), 6 FMAs per loaded float -> HBM-bound (33.6 MB / sample / layer at L=256)
+//     phase B1 scalar + point outputs: thread per (h, 4 channels of the 40) x 4 key groups, 16-byte loads, LDS reduce
+//     phase B2 attention over the pair slab: lane -> 4 channels (16-byte loads, 512 B coalesced per j), 16 key groups with
+//              >= 4 loads in flight each, 12 heads x 4 channels of accumulators, fixed-order reduction (shuffle + LDS):
+//              streams z[b,i,j,0:128] exactly once per query residue -> HBM-bound (33.6 MB / sample / layer at L=256)
 //     tail     points back to the local frame (r3.invert_rigids, r3.py:54-59), norms sqrt(sum^2 + 1e-8), concat
 //              [scalar 192 | points '(r n)' 288 | norms 96 | pair 1536] = 2112 floats per residue.
 #include "common.h"
@@ -81,31 +82,33 @@ __global__ __launch_bounds__(256) void ipa_pack_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void ipa_attn_kernel(const float* __restrict__ qpack, const float* __restrict__ kpack,
-                                                       const float* __restrict__ vpack, const float* __restrict__ bias2d,
-                                                       const float* __restrict__ z, const float* __restrict__ mask,
-                                                       const float* __restrict__ rots, const float* __restrict__ trans,
-                                                       const float* __restrict__ pw, float* __restrict__ feat, int B, int L) {
+constexpr int IPA_THREADS = 512;                 // 8 waves: enough loads in flight to stream the pair slab
+constexpr int NJG2 = IPA_THREADS / 32;           // j-groups of phase B2 (32 lanes x float4 = 128 channels)
+constexpr int NJG1 = 4;                          // j-groups of phase B1 (120 (h, c4) items x 4)
+
+__global__ __launch_bounds__(IPA_THREADS) void ipa_attn_kernel(const float* __restrict__ qpack, const float* __restrict__ kpack,
+                                                               const float* __restrict__ vpack, const float* __restrict__ bias2d,
+                                                               const float* __restrict__ z, const float* __restrict__ mask,
+                                                               const float* __restrict__ rots, const float* __restrict__ trans,
+                                                               const float* __restrict__ pw, float* __restrict__ feat, int B, int L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lg = smem;                                   // [IQ][L][LDH]
-    float* qs = smem + (size_t)IQ * L * LDH;            // [IQ][H][QREC]
-    float* opt = qs + IQ * H * QREC;                    // [IQ][H][VREC] scalar+point outputs (global frame)
+    float* lg = smem;                                           // [IQ][L][LDH] logits -> attention weights
+    float* qs = smem + (((size_t)IQ * L * LDH + 3) & ~(size_t)3);   // [IQ][H][QREC]
+    float* opt = qs + IQ * H * QREC;                            // [IQ][H][VREC] scalar+point outputs (global frame)
+    float* red = opt + IQ * H * VREC;                           // [8 waves][H][CZ] partial sums (16-byte aligned)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int i0 = blockIdx.x * IQ;
     const int niq = min(IQ, L - i0);
 
-    for (int idx = tid; idx < IQ * H * QREC; idx += 256) {
+    for (int idx = tid; idx < IQ * H * QREC; idx += IPA_THREADS) {
         const int iq = idx / (H * QREC);
         qs[idx] = iq < niq ? qpack[((long long)b * L + i0) * H * QREC + idx] : 0.f;
     }
     __syncthreads();
 
     // ---- phase A: logits -------------------------------------------------------------------------------------
-    float pwh[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) pwh[h] = pw[h];
-    for (int j = tid; j < L; j += 256) {
+    for (int j = tid; j < L; j += IPA_THREADS) {
         const float mj = mask[(long long)b * L + j];
         for (int h = 0; h < H; ++h) {
             const float* kr = kpack + (((long long)b * H + h) * L + j) * QREC;
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(const float* __restrict__
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(kr + c4 * 4);
                 kv[c4 * 4] = t4[0]; kv[c4 * 4 + 1] = t4[1]; kv[c4 * 4 + 2] = t4[2]; kv[c4 * 4 + 3] = t4[3];
             }
+            const float pwh = pw[h];
 #pragma unroll
             for (int iq = 0; iq < IQ; ++iq) {
                 const float* qr = qs + (iq * H + h) * QREC;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(const float* __restrict__
                     const float d = qr[c] - kv[c];
                     d2 = fmaf(d, d, d2);
                 }
-                float v = s + pwh[h] * d2;
+                float v = s + pwh * d2;
                 if (iq < niq) {
                     v += bias2d[(((long long)b * L + i0 + iq) * L + j) * H + h];
                     const float mi = mask[(long long)b * L + i0 + iq];
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    // ---- softmax over j for each (iq, h): 48 rows over 4 waves ------------------------------------------------
-    for (int row = wave; row < IQ * H; row += 4) {
+    // ---- softmax over j for each (iq, h): 48 rows over 8 waves ------------------------------------------------
+    for (int row = wave; row < IQ * H; row += IPA_THREADS / 64) {
         const int iq = row / H, h = row % H;
         float* r = lg + (size_t)iq * L * LDH + h;
         float mx = -INFINITY;
@@ -156,56 +160,85 @@ __global__ __launch_bounds__(256) void ipa_attn_kernel(const float* __restrict__
         for (int j = lane; j < L; j += 64) r[(size_t)j * LDH] *= inv;
     }
     __syncthreads();
-    // ---- phase B1: scalar + point outputs, item = (h, c) ----------------------------------------------------------
-    for (int item = tid; item < H * VREC; item += 256) {
-        const int h = item / VREC, c = item % VREC;
-        float acc[IQ] = {0.f, 0.f, 0.f, 0.f};
-        const float* vb = vpack + ((long long)b * H + h) * L * VREC + c;
-        for (int j = 0; j < L; ++j) {
-            const float vv = vb[(long long)j * VREC];
-#pragma unroll
-            for (int iq = 0; iq < IQ; ++iq) acc[iq] = fmaf(lg[((size_t)iq * L + j) * LDH + h], vv, acc[iq]);
-        }
-#pragma unroll
-        for (int iq = 0; iq < IQ; ++iq) opt[(iq * H + h) * VREC + c] = acc[iq];
-    }
-    // ---- phase B2: attention over the pair slab ---------------------------------------------------------------------
+    // ---- phase B1: scalar + point outputs.  item = (h, c4): 120 items x NJG1 j-groups, 16-byte loads of V -----------
     {
-        const int c = tid & (CZ - 1), hg = tid >> 7;       // heads hg*6 .. hg*6+5
-        for (int iq = 0; iq < niq; ++iq) {
-            const float* zr = z + (((long long)b * L + i0 + iq) * L) * CZ + c;
-            const float* ar = lg + (size_t)iq * L * LDH + hg * 6;
-            float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            int j = 0;
-            for (; j + 4 <= L; j += 4) {
-                float zv[4];
+        const int item = tid % (H * VREC / 4), jg = tid / (H * VREC / 4);
+        const int h = item / (VREC / 4), c4 = item % (VREC / 4);
+        f32x4 acc[IQ];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) zv[u] = zr[(long long)(j + u) * CZ];
+        for (int iq = 0; iq < IQ; ++iq) acc[iq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (jg < NJG1) {
+            const float* vb = vpack + ((long long)b * H + h) * L * VREC + c4 * 4;
+#pragma unroll 4
+            for (int j = jg; j < L; j += NJG1) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long long)j * VREC);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float* a6 = ar + (size_t)(j + u) * LDH;
+                for (int iq = 0; iq < IQ; ++iq) {
+                    const float w = lg[((size_t)iq * L + j) * LDH + h];
 #pragma unroll
-                    for (int hh = 0; hh < 6; ++hh) acc[hh] = fmaf(a6[hh], zv[u], acc[hh]);
+                    for (int c = 0; c < 4; ++c) acc[iq][c] = fmaf(w, vv[c], acc[iq][c]);
                 }
             }
-            for (; j < L; ++j) {
-                const float zv = zr[(long long)j * CZ];
-                const float* a6 = ar + (size_t)j * LDH;
 #pragma unroll
-                for (int hh = 0; hh < 6; ++hh) acc[hh] = fmaf(a6[hh], zv, acc[hh]);
+            for (int iq = 0; iq < IQ; ++iq)
+                *reinterpret_cast<f32x4*>(red + ((size_t)(jg * IQ + iq) * H + h) * VREC + c4 * 4) = acc[iq];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < IQ * H * VREC; idx += IPA_THREADS) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < NJG1; ++g2) sacc += red[(size_t)g2 * IQ * H * VREC + idx];
+            opt[idx] = sacc;
+        }
+        __syncthreads();
+    }
+    // ---- phase B2: attention over the pair slab: lane -> 4 channels (16-byte loads), 16 j-groups, 48 accumulators ------
+    {
+        const int c4 = tid & 31, jg = tid >> 5;
+        for (int iq = 0; iq < niq; ++iq) {
+            const float* zr = z + (((long long)b * L + i0 + iq) * L) * CZ + c4 * 4;
+            const float* ar = lg + (size_t)iq * L * LDH;
+            f32x4 acc[H];
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) acc[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int j = jg; j < L; j += NJG2) {
+                const f32x4 zv = *reinterpret_cast<const f32x4*>(zr + (long long)j * CZ);
+                const float* a12 = ar + (size_t)j * LDH;
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    const float w = a12[hh];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[hh][c] = fmaf(w, zv[c], acc[hh][c]);
+                }
             }
-            float* fo = feat + ((long long)b * L + i0 + iq) * NFEAT + (H * SV + 4 * H * PV);
+            // the two j-groups of a wave (lanes l, l+32) first, then the 8 waves through LDS, in a fixed order
 #pragma unroll
-            for (int hh = 0; hh < 6; ++hh) fo[(hg * 6 + hh) * CZ + c] = acc[hh];
+            for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[hh][c] += __shfl_xor(acc[hh][c], 32, 64);
+            if (lane < 32) {
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh)
+                    *reinterpret_cast<f32x4*>(red + ((size_t)wave * H + hh) * CZ + c4 * 4) = acc[hh];
+            }
+            __syncthreads();
+            float* fo = feat + ((long long)b * L + i0 + iq) * NFEAT + (H * SV + 4 * H * PV);
+            for (int idx = tid; idx < H * CZ; idx += IPA_THREADS) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < IPA_THREADS / 64; ++w8) sacc += red[(size_t)w8 * H * CZ + idx];
+                fo[idx] = sacc;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
     // ---- tail: scalar copy, points to the local frame, norms ----------------------------------------------------------
-    for (int idx = tid; idx < IQ * H * SV; idx += 256) {
+    for (int idx = tid; idx < IQ * H * SV; idx += IPA_THREADS) {
         const int iq = idx / (H * SV), r = idx % (H * SV);
         if (iq < niq) feat[((long long)b * L + i0 + iq) * NFEAT + r] = opt[(iq * H + r / SV) * VREC + (r % SV)];
     }
-    for (int idx = tid; idx < IQ * H * PV; idx += 256) {
+    for (int idx = tid; idx < IQ * H * PV; idx += IPA_THREADS) {
         const int iq = idx / (H * PV), n = idx % (H * PV);
         if (iq >= niq) continue;
         const int h = n / PV, pt = n % PV;
@@ -243,7 +276,7 @@ extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float*
                             int B, int L, hipStream_t st) {
     ABX_REQUIRE(qpack && kpack && vpack && bias2d && z && mask && rots && trans && point_weights && feat, "abx_ipa_attn: null");
     ABX_REQUIRE(B > 0 && L > 0 && B <= 65535, "abx_ipa_attn: bad sizes");
-    const size_t lds = ((size_t)IQ * L * LDH + IQ * H * QREC + IQ * H * VREC) * sizeof(float);
+    const size_t lds = ((((size_t)IQ * L * LDH + 3) & ~(size_t)3) + IQ * H * QREC + IQ * H * VREC + (size_t)(IPA_THREADS / 64) * H * CZ) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_attn: L too large for LDS-resident logits");
     static thread_local bool configured = false;
     if (!configured) {
@@ -252,7 +285,7 @@ extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float*
         if (e != hipSuccess) { abx_set_error("abx_ipa_attn: hipFuncSetAttribute failed"); return (int)e; }
         configured = true;
     }
-    hipLaunchKernelGGL(ipa_attn_kernel, dim3((L + IQ - 1) / IQ, B), dim3(256), lds, st, qpack, kpack, vpack, bias2d, z, mask,
+    hipLaunchKernelGGL(ipa_attn_kernel, dim3((L + IQ - 1) / IQ, B), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, z, mask,
                        rots, trans, point_weights, feat, B, L);
     return abx_check_launch("abx_ipa_attn");
 }

@@ -30,6 +30,7 @@ class Packed:
         self.sd = {k: f(k) for k in sd}
         g = self.sd
         self.wt, self.b = {}, {}
+        self._ln_cache = {}
 
         def lin(name, key=None):
             key = key or name
@@ -69,6 +70,22 @@ class Packed:
     def ln(self, name):
         return self.sd[name + '.weight'], self.sd[name + '.bias']
 
+    def ln_linear(self, key, ln_name):
+        """LayerNorm folded into the following Linear for abx_gemm's algebraic-LN epilogue:
+        returns (Wt' = gamma[:,None] * Wt, csum = colsum(Wt'), bias' = beta @ Wt + b), built once in float64."""
+        ck = (key, ln_name)
+        hit = self._ln_cache.get(ck)
+        if hit is None:
+            gamma, beta = self.sd[ln_name + '.weight'].double(), self.sd[ln_name + '.bias'].double()
+            wt = self.wt[key].double()
+            wts = gamma[:, None] * wt
+            bias = beta @ wt
+            if self.b.get(key) is not None:
+                bias = bias + self.b[key].double()
+            hit = (wts.float().contiguous(), wts.sum(0).float().contiguous(), bias.float().contiguous())
+            self._ln_cache[ck] = hit
+        return hit
+
 
 class Workspace:
     def __init__(self, device):
@@ -86,6 +103,12 @@ class Workspace:
 
 def _lin(P, name, x, out, **kw):
     return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), **kw)
+
+
+def _ln_lin(P, name, ln_name, stats, x, out, **kw):
+    """out = epi(LN(x) @ W^T + b) with the LayerNorm folded into the GEMM epilogue."""
+    wt, csum, bias = P.ln_linear(name, ln_name)
+    return ops.gemm(x, wt, out, bias=bias, ln=(stats, csum), **kw)
 
 
 class Engine:
@@ -144,7 +167,7 @@ class Engine:
             ops.gather_rows(P.sd[P_SEQF + 'proj_aa_type.weight'], ag_idx, e)
             st = ops.row_stats(e)
             e1 = torch.empty(n_ag, 512, device=dev)
-            _lin(P, P_SEQF + 'aa_proj.1', e, e1, ln=(st,) + P.ln(P_SEQF + 'aa_proj.0'), act=1)
+            _ln_lin(P, P_SEQF + 'aa_proj.1', P_SEQF + 'aa_proj.0', st, e, e1, act=1)
             ss = seq_static.view(B, L, 512)
             # rows of the antigen are not contiguous over the batch: one GEMM per sample keeps the C ABI simple
             for b in range(B):
@@ -197,62 +220,58 @@ class Engine:
         prev_pos = st['prev_pos'][b0:b1] if st['prev_pos'] is not None else None
         ops.assemble_seq(sstat, P.sd[P_SEQF + 'proj_aa_type.weight'], seq_t, Lab, temb, prev_seq,
                          *P.ln(P_SEQF + 'prev_seq_norm'), seq_act, Bc, L, CS, E)
+        stats2 = ws.get('stats2', (M2, 2))
         ops.assemble_pair(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos,
-                          P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E)
+                          P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E, stats_out=stats2)
         s2 = seq_act.view(M1, WS_)
         z2 = pair_act.view(M2, WZ)
         z3 = pair_act.view(Bc, LL, WZ)
         w768 = ws.get('w768', (M2, 768))
         w384 = ws.get('w384', (M2 * 384,))
-        stats2 = ws.get('stats2', (M2, 2))
         stats1 = ws.get('stats1', (M1, 2))
+        statsT = ws.get('statsT', (M2, 2))
         pmask = ws.get('pmask', (M2,))
         ops.pair_mask(mask_f, pmask, Bc, L)
 
         # ---------------- seq attention with pair bias (seqformer.py:314-356)
         pre = P_BLK + 'seq_attn.'
         H = c.seqformer.seq_attention_with_pair_bias.num_head
-        ops.row_stats(s2, stats1)
-        ops.row_stats(z2, stats2)
+        ops.row_stats(s2, stats1)                      # pair-row statistics come fused from the producing kernels
         biasT = ws.get('biasT', (Bc, H, LL))
-        ops.gemm(z3, P.wt[pre + 'proj_pair'], biasT.transpose(1, 2), ln=(stats2,) + P.ln(pre + 'pair_norm'))
+        _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', stats2, z3, biasT.transpose(1, 2))
         qkv = ws.get('s_a', (M1, 3 * WS_))
         sgate = ws.get('s_b', (M1, WS_))
         so = ws.get('s_c', (M1, WS_))
-        lns = (stats1,) + P.ln(pre + 'seq_norm')
-        _lin(P, pre + 'attn.proj_in', s2, qkv, ln=lns)
-        _lin(P, pre + 'attn.gate', s2, sgate, ln=lns)
+        _ln_lin(P, pre + 'attn.proj_in', pre + 'seq_norm', stats1, s2, qkv)
+        _ln_lin(P, pre + 'attn.gate', pre + 'seq_norm', stats1, s2, sgate)
         ops.seq_attn(qkv, biasT, mask_f, sgate, so, Bc, L, H, WS_ // H)
         _lin(P, pre + 'attn.proj_out', so, s2, resid=s2)
         # ---------------- seq transition
         pre = P_BLK + 'seq_transition.transition.'
         ops.row_stats(s2, stats1)
         hid = ws.get('s_a', (M1, 4 * WS_))
-        _lin(P, pre + '1', s2, hid, ln=(stats1,) + P.ln(pre + '0'), act=1)
+        _ln_lin(P, pre + '1', pre + '0', stats1, s2, hid, act=1)
         _lin(P, pre + '3', hid, s2, resid=s2)
         # ---------------- outer product mean (seqformer.py:395-411)
         pre = P_BLK + 'outer_product_mean.'
         ops.row_stats(s2, stats1)
         lr = ws.get('s_b', (M1, 128))
-        ops.gemm(s2, P.wt[pre + 'lr'], lr, bias=P.b[pre + 'lr'], ln=(stats1,) + P.ln(pre + 'norm'), rowscale=mask_f.reshape(-1))
+        _ln_lin(P, pre + 'lr', pre + 'norm', stats1, s2, lr, rowscale=mask_f.reshape(-1))
         feat = w384[:M2 * 128].view(M2, 128)
         ops.opm_features(lr, feat, Bc, L, 64)
-        _lin(P, pre + 'out_proj', feat, z2, resid=z2)
+        _lin(P, pre + 'out_proj', feat, z2, resid=z2, stats_out=stats2)
         # ---------------- triangle multiplication (seqformer.py:443-504)
         for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
             pre = P_BLK + name + '.'
-            ops.row_stats(z2, stats2)
-            lnz = (stats2,) + P.ln(pre + 'norm')
             G = w768[:, :448]
-            ops.gemm(z2, P.wt[pre + 'gates'], G, bias=P.b[pre + 'gates'], ln=lnz)
+            _ln_lin(P, pre + 'gates', pre + 'norm', stats2, z2, G)
             left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
             right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
             tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
             G3 = w768.view(Bc, LL, 768)
-            ops.gemm(z3, P.wt[pre + 'left_proj'], left.transpose(1, 2), bias=P.b[pre + 'left_proj'], ln=lnz,
-                     rowscale=pmask, gate=G3[:, :, 0:128])
-            ops.gemm(z3, P.wt[pre + 'right_proj'], right.transpose(1, 2), bias=P.b[pre + 'right_proj'], ln=lnz,
-                     rowscale=pmask, gate=G3[:, :, 128:256])
+            _ln_lin(P, pre + 'left_proj', pre + 'norm', stats2, z3, left.transpose(1, 2), rowscale=pmask, gate=G3[:, :, 0:128])
+            _ln_lin(P, pre + 'right_proj', pre + 'norm', stats2, z3, right.transpose(1, 2), rowscale=pmask,
+                    gate=G3[:, :, 128:256])
             lz = left.view(Bc * 128, L, L)
             rz = right.view(Bc * 128, L, L)
             tz = tt.view(Bc * 128, L, L)
@@ -261,24 +280,20 @@ class Engine:
             else:             # 'bkic,bkjc->bijc'
                 ops.gemm(lz.transpose(1, 2), rz, tz)
             tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
-            ops.row_stats(tcm, stats2)
-            ops.gemm(tcm, P.wt[pre + 'proj_out'], z3, bias=P.b[pre + 'proj_out'], ln=(stats2,) + P.ln(pre + 'final_norm'),
-                     gate=G3[:, :, 256:448], resid=z3)
+            ops.row_stats(tcm, statsT)
+            _ln_lin(P, pre + 'proj_out', pre + 'final_norm', statsT, tcm, z3, gate=G3[:, :, 256:448], resid=z3, stats_out=stats2)
         # ---------------- triangle attention (seqformer.py:506-550)
         for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
             pre = P_BLK + name + '.'
-            ops.row_stats(z2, stats2)
-            lnz = (stats2,) + P.ln(pre + 'norm')
-            ops.gemm(z2, P.wt[pre + 'qkvg'], w768, bias=P.b[pre + 'qkvg'], ln=lnz)
+            _ln_lin(P, pre + 'qkvg', pre + 'norm', stats2, z2, w768)
             bT = ws.get('biasT', (Bc, 4, LL))
-            ops.gemm(z3, P.wt[pre + 'proj_pair'], bT.transpose(1, 2), ln=lnz)
+            _ln_lin(P, pre + 'proj_pair', pre + 'norm', stats2, z3, bT.transpose(1, 2))
             o = w384[:M2 * 192].view(M2, 192)
             ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row)
-            _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
+            _lin(P, pre + 'attn.proj_out', o, z2, resid=z2, stats_out=stats2)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'
-        ops.row_stats(z2, stats2)
-        _lin(P, pre + '1', z2, w768, ln=(stats2,) + P.ln(pre + '0'), act=1)
+        _ln_lin(P, pre + '1', pre + '0', stats2, z2, w768, act=1)
         _lin(P, pre + '3', w768, z2, resid=z2)
 
         # ================= IpaScore (score_network.py:83-196)

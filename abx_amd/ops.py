@@ -24,8 +24,11 @@ def _f32(t):
     return t
 
 
+GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
+
+
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None):
+         resid=None, stats_out=None, tune=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2), gamma, beta).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N)."""
@@ -53,10 +56,12 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         g.c_transposed, g.sCm = 1, Cout.stride(2)
     g.M, g.N, g.K, g.batch = M, N, K, nb
     if ln is not None:
-        stats, gamma, beta = ln
+        stats, csum = ln
         assert stats.numel() == 2 * nb * M, (stats.shape, nb, M)
-        g.ln_stats, g.sSb, g.ln_gamma, g.ln_beta = _p(_f32(stats)), M, _p(_f32(gamma)), _p(_f32(beta))
+        assert csum.numel() == N
+        g.ln_stats, g.sSb, g.ln_csum = _p(_f32(stats)), M, _p(_f32(csum))
     g.a_relu = 1 if a_relu else 0
+    g.tune = GEMM_TUNE if tune is None else tune
     g.bias = _p(bias)
     g.alpha = float(alpha)
     g.act = int(act)
@@ -73,6 +78,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             resid = resid.unsqueeze(0)
         assert resid.shape == (nb, M, N) and resid.stride(2) == 1
         g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(1)
+    if stats_out is not None:
+        assert stats_out.numel() == 2 * nb * M and stats_out.is_contiguous()
+        g.stats_out, g.sSOb, g.stats_eps = _p(_f32(stats_out)), M, 1e-5
     check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
     return Cout
 
@@ -174,12 +182,12 @@ def assemble_seq(seq_static, aa_table, seq_t, Lab, temb, prev_seq, gamma, beta, 
     return out
 
 
-def assemble_pair(pair_static, temb, prev_pair, gamma, beta, prev_pos, pos_table, out, B, L, C_, E):
+def assemble_pair(pair_static, temb, prev_pair, gamma, beta, prev_pos, pos_table, out, B, L, C_, E, stats_out=None):
     ps_b = 0 if pair_static.shape[0] == 1 else pair_static.stride(0)
     if prev_pos is not None:
         assert prev_pos.dtype == torch.int64 and prev_pos.is_contiguous()
     check(_lib.load().abx_assemble_pair(_p(pair_static), ps_b, _p(temb), _p(prev_pair), _p(gamma), _p(beta), _p(prev_pos),
-                                        _p(pos_table), _p(out), B, L, C_, E, _stream()), 'abx_assemble_pair')
+                                        _p(pos_table), _p(out), _p(stats_out), B, L, C_, E, _stream()), 'abx_assemble_pair')
     return out
 
 

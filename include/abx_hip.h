@@ -37,8 +37,10 @@ int abx_init(int device);
  * abx/model/common_modules.py:11-44 (Linear), abx/model/seqformer.py:358-376 (Transition), :380-411 (OPM out_proj),
  * :443-504 (TriangleMultiplication projections + 'bikc,bjkc->bijc' / 'bkic,bkjc->bijc'), :260-312 (q/k/v/gate/out),
  * abx/model/score_network.py:117-137, abx/model/folding.py:69-132 (IPA projections), abx/model/head.py:147-160,207-220.
- *   C[b][m][n] = epi( sum_k A'[b][m][k] * B[b][k][n] ),   A' = relu?(LN?(A))
- *   epi(v) = ((v + bias[n]) * alpha) -> act -> * rowscale[b][m] -> * (sigmoid?)(gate[b][m][n]) -> + resid[b][m][n]
+ *   acc[b][m][n] = sum_k relu?(A[b][m][k]) * B[b][k][n]
+ *   LayerNorm over k is applied algebraically in the epilogue: pass B scaled by gamma (B[k][n] = gamma[k] W[n][k]),
+ *   ln_csum[n] = sum_k B[k][n], bias[n] = sum_k beta[k] W[n][k] + b[n] and the row statistics:  ln(v) = rstd[m] (v - mean[m] csum[n])
+ *   epi(v) = ((ln(v) + bias[n]) * alpha) -> act -> * rowscale[b][m] -> * (sigmoid?)(gate[b][m][n]) -> + resid[b][m][n]
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct AbxGemm {
     const float* A; long long sAb, sAm, sAk;       /* one of sAm / sAk must be 1 */
@@ -47,7 +49,7 @@ typedef struct AbxGemm {
     int M, N, K, batch;
     int c_transposed;
     const float* ln_stats; long long sSb;          /* (mean,rstd) pairs, row index b*sSb + m; NULL = no LayerNorm */
-    const float* ln_gamma; const float* ln_beta;   /* [K] */
+    const float* ln_csum;                          /* [N] column sums of the gamma-scaled B */
     int a_relu;
     const float* bias;                             /* [N] or NULL */
     float alpha;                                   /* use 1.0f for none */
@@ -55,7 +57,9 @@ typedef struct AbxGemm {
     const float* rowscale; long long sRSb;         /* [b*sRSb + m] or NULL */
     const float* gate; long long sGb, sGm; int gate_sigmoid;
     const float* resid; long long sRb, sRm;        /* may alias C */
-    int a_vec_ok, b_vec_ok, c_vec_ok, force_a_mcontig;   /* filled by the library */
+    float* stats_out; long long sSOb; float stats_eps;   /* optional: (mean, rstd) of the OUTPUT rows (N <= 192), row b*sSOb + m */
+    int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
+    int a_vec_ok, b_vec_ok, fast_ok;               /* filled by the library */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
 
@@ -110,10 +114,11 @@ int abx_timestep_embedding(const double* t, const float* freqs, int B, int dim, 
 int abx_assemble_seq(const float* seq_static, long long ss_b, const float* aa_table, const long long* seq_t, int Lab,
                      const float* temb, const float* prev_seq, const float* gamma, const float* beta, float* out, int B,
                      int L, int C, int E, hipStream_t stream);
-/* pair_act[b,i,j] = [ pair_static[b,i,j] | temb[b] | temb[b] ] + LN(prev_pair[b,i,j]) + pos_table[prev_pos[b,i,j]] */
+/* pair_act[b,i,j] = [ pair_static[b,i,j] | temb[b] | temb[b] ] + LN(prev_pair[b,i,j]) + pos_table[prev_pos[b,i,j]];
+ * stats_out (optional): LayerNorm (mean, rstd) of every assembled row for the first consumer */
 int abx_assemble_pair(const float* pair_static, long long ps_b, const float* temb, const float* prev_pair,
                       const float* gamma, const float* beta, const long long* prev_pos, const float* pos_table, float* out,
-                      int B, int L, int C, int E, hipStream_t stream);
+                      float* stats_out, int B, int L, int C, int E, hipStream_t stream);
 /* OuterProductMean features (seqformer.py:400-409): feat[b,i,j] = [ left[b,j]*right[b,i] | left[b,j]-right[b,i] ];
  * left/right rows have stride ld floats */
 int abx_opm_features(const float* left, const float* right, long long ld, float* feat, int B, int L, int C,

@@ -35,6 +35,14 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def fold_ln(W, b, gamma, beta):
+    """LayerNorm folded into the Linear (abx_gemm algebraic-LN contract): Wt' = gamma*Wt, csum, bias' = beta@Wt + b."""
+    wt = W.double().t()
+    wts = gamma.double()[:, None] * wt
+    bias = beta.double() @ wt + (b.double() if b is not None else 0.0)
+    return wts.float().contiguous().to(DEV), wts.sum(0).float().contiguous().to(DEV), bias.float().contiguous().to(DEV)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 70, 52), (37, 20, 256), (513, 192, 192), (64, 6, 256), (96, 448, 192)])
 def test_gemm_plain_bias_act(ops, M, N, K):
@@ -66,10 +74,19 @@ def test_gemm_ln_gate_resid_rowscale(ops):
     check(stats[:, 1], rstd, 1e-6, 'row_stats rstd')
     resd = res.to(DEV).clone()
     gd = gate.to(DEV)
-    ops.gemm(Ad, W.t().contiguous().to(DEV), resd, bias=b.to(DEV), ln=(stats, ga.to(DEV), be.to(DEV)), alpha=0.5,
-             rowscale=rs.to(DEV), gate=gd[:, :N], resid=resd)
+    Wt, csum, bias2 = fold_ln(W, b, ga, be)
+    ops.gemm(Ad, Wt, resd, bias=bias2, ln=(stats, csum), alpha=0.5, rowscale=rs.to(DEV), gate=gd[:, :N], resid=resd)
     ref = ((ref_ln @ W.double().t() + b.double()) * 0.5) * rs.double()[:, None] * torch.sigmoid(gate[:, :N].double()) + res.double()
     check(resd, ref, 3e-6, 'gemm LN+gate+resid (in place)')
+    # fused statistics of the output rows (N <= 192): the next LayerNorm's (mean, rstd)
+    for Nn in (192, 128):
+        out = torch.empty(M, Nn, device=DEV)
+        so = torch.full((M, 2), float('nan'), device=DEV)
+        ops.gemm(Ad, W.t().contiguous().to(DEV)[:, :Nn].contiguous(), out, bias=b.to(DEV)[:Nn].contiguous(), resid=res.to(DEV)[:, :Nn], stats_out=so)
+        r2 = A.double() @ W.double().t()[:, :Nn] + b.double()[:Nn] + res.double()[:, :Nn]
+        check(out, r2, 3e-6, f'gemm stats_out values N={Nn}')
+        check(so[:, 0], r2.mean(-1), 3e-6, f'gemm stats_out mean N={Nn}')
+        check(so[:, 1], 1 / torch.sqrt(r2.var(-1, unbiased=False) + 1e-5), 3e-6, f'gemm stats_out rstd N={Nn}')
     # materialised layernorm, in place and with residual
     x = A.to(DEV).clone()
     ops.layernorm(x, ga.to(DEV), be.to(DEV), out=x)
@@ -105,8 +122,8 @@ def test_gemm_layouts_batched_transposed(ops):
     Zd = Z.to(DEV)
     stats = ops.row_stats(Zd.view(B * LL, C))
     outT = torch.full((B, Cout, LL), float('nan'), device=DEV)
-    ops.gemm(Zd, W.t().contiguous().to(DEV), outT.transpose(1, 2), bias=bias.to(DEV), ln=(stats, ga.to(DEV), be.to(DEV)),
-             rowscale=pm.to(DEV), gate=G.to(DEV)[:, :, 128:256])
+    Wt, csum, bias2 = fold_ln(W, bias, ga, be)
+    ops.gemm(Zd, Wt, outT.transpose(1, 2), bias=bias2, ln=(stats, csum), rowscale=pm.to(DEV), gate=G.to(DEV)[:, :, 128:256])
     ln = torch.nn.functional.layer_norm(Z.double(), (C,), ga.double(), be.double(), 1e-5)
     ref = (ln @ W.double().t() + bias.double()) * pm.double().view(B, LL, 1) * torch.sigmoid(G[:, :, 128:256].double())
     check(outT, ref.transpose(1, 2), 3e-6, 'transposed store')
@@ -118,7 +135,8 @@ def test_gemm_layouts_batched_transposed(ops):
     W2 = torch.randn(C, Cout, generator=g(24)) / Cout ** 0.5
     ga2, be2 = torch.randn(Cout, generator=g(25)), torch.randn(Cout, generator=g(26))
     res = Zd.clone()
-    ops.gemm(tcm, W2.t().contiguous().to(DEV), res, ln=(st2, ga2.to(DEV), be2.to(DEV)), resid=res)
+    Wt2, csum2, bias22 = fold_ln(W2, None, ga2, be2)
+    ops.gemm(tcm, Wt2, res, bias=bias22, ln=(st2, csum2), resid=res)
     ln2 = torch.nn.functional.layer_norm(T.double().transpose(1, 2), (Cout,), ga2.double(), be2.double(), 1e-5)
     check(res, ln2 @ W2.double().t() + Z.double(), 3e-6, 'channel-major A + LN')
 
@@ -246,8 +264,10 @@ def test_embedding_assembly(ops, params):
     so = torch.empty(B, L, 544, device=DEV); po = torch.empty(B, L, L, 192, device=DEV)
     ops.assemble_seq(seq_static.to(DEV), P[O.P_SEQF + 'proj_aa_type.weight'], seq_t.to(DEV), Lab, temb, prev_seq.to(DEV),
                      P[O.P_SEQF + 'prev_seq_norm.weight'], P[O.P_SEQF + 'prev_seq_norm.bias'], so, B, L, 512, 32)
+    pst = torch.empty(B * L * L, 2, device=DEV)
     ops.assemble_pair(pair_static.to(DEV), temb, prev_pair.to(DEV), P[O.P_SEQF + 'prev_pair_norm.weight'],
-                      P[O.P_SEQF + 'prev_pair_norm.bias'], prev_pos.to(DEV), P[O.P_SEQF + 'proj_prev_pos.weight'], po, B, L, 128, 32)
+                      P[O.P_SEQF + 'prev_pair_norm.bias'], prev_pos.to(DEV), P[O.P_SEQF + 'proj_prev_pos.weight'], po, B, L, 128, 32,
+                      stats_out=pst)
     te = temb.cpu()
     sa = seq_static.clone()
     sa[:, :Lab] += params[O.P_SEQF + 'proj_aa_type.weight'][seq_t[:, :Lab]]
@@ -256,6 +276,9 @@ def test_embedding_assembly(ops, params):
     pa = pa + O.lnorm(params, O.P_SEQF + 'prev_pair_norm', prev_pair) + params[O.P_SEQF + 'proj_prev_pos.weight'][prev_pos]
     check(so, sa, 2e-6, 'assemble_seq')
     check(po, pa, 2e-6, 'assemble_pair')
+    pa2 = pa.double().view(-1, 192)
+    check(pst[:, 0], pa2.mean(-1), 2e-6, 'assemble_pair fused stats mean')
+    check(pst[:, 1], 1 / torch.sqrt(pa2.var(-1, unbiased=False) + 1e-5), 2e-6, 'assemble_pair fused stats rstd')
     # shared (broadcast) static context
     ops.assemble_pair(pair_static[:1].contiguous().to(DEV), temb, None, None, None, None, None, po, B, L, 128, 32)
     check(po[1, ..., :128], pair_static[0], 0, 'assemble_pair broadcast')
