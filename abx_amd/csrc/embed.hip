@@ -246,7 +246,32 @@ __global__ __launch_bounds__(256) void pair_embed_features_kernel(
     }
 }
 
+// out[n][j][i] = in[n][i][j] for nmat square L x L matrices (32x32 LDS tiles, both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int L) {
+    __shared__ float tile[32][33];
+    const long long base = (long long)blockIdx.z * L * L;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + r * 8, j = j0 + tx;
+        if (i < L && j < L) tile[ty + r * 8][tx] = in[base + (long long)i * L + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = j0 + ty + r * 8, i = i0 + tx;
+        if (i < L && j < L) out[base + (long long)j * L + i] = tile[tx][ty + r * 8];
+    }
+}
+
 }  // namespace
+
+extern "C" int abx_transpose_last2(const float* in, float* out, int nmat, int L, hipStream_t st) {
+    ABX_REQUIRE(in && out && in != out && nmat > 0 && nmat <= 65535 && L > 0, "abx_transpose_last2: bad args");
+    hipLaunchKernelGGL(transpose_last2_kernel, dim3((L + 31) / 32, (L + 31) / 32, nmat), dim3(256), 0, st, in, out, L);
+    return abx_check_launch("abx_transpose_last2");
+}
 
 extern "C" int abx_timestep_embedding(const double* t, const float* freqs, int B, int dim, float* out, hipStream_t st) {
     ABX_REQUIRE(t && freqs && out && B > 0 && dim >= 4 && dim % 2 == 0, "abx_timestep_embedding: bad args");

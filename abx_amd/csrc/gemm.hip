@@ -168,8 +168,7 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
     // LDS is free now: stage the LayerNorm row statistics of this M-panel; transposed store: per-wave 32x33 scratch;
     // stats_out: per-row partial sums of the two wave columns.
     float* st_lds = smem;                                   // [BM][2]
-    float* scratch = smem + 2 * BM + wave * (32 * 33);       // 4 waves x 32 x 33
-    float* part = smem + 2 * BM + 4 * 32 * 33;               // [BM][WAVES_N][2]
+    float* part = smem + 2 * BM;                             // [BM][WAVES_N][2] (plain store) | transposed-store scratch
     const float* stats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
     if (stats) {
         for (int idx = threadIdx.x; idx < 2 * BM; idx += 256) {
@@ -264,36 +263,41 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
             }
         }
     } else {
+        // transposed store: per 32-row band i, all TN sub-tiles go through the wave's LDS scratch [j][n_local][m_local] and
+        // are written out as rows of 32 consecutive m (128-byte segments) per n
+        float* sc = smem + 2 * BM + wave * (TN * 32 * 33);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = wn * WN + j * 32;
-                const int n = n0 + nl + (lane & 31);
+            for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
+                for (int c = 0; c < 4; ++c) {
+                    const int ml = wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5) + c;
+                    const int m = m0 + ml;
+                    const bool mok = !EDGE || m < g.M;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int ml = wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5) + c;
-                        const int m = m0 + ml;
-                        const float v = epi(acc[i][j][rq * 4 + c], ml, m, n, j, nok[j] && (!EDGE || m < g.M));
-                        scratch[(lane & 31) * 33 + 8 * rq + 4 * (lane >> 5) + c] = v;
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+                        const float v = epi(acc[i][j][rq * 4 + c], ml, m, n, j, nok[j] && mok);
+                        sc[j * (32 * 33) + (lane & 31) * 33 + 8 * rq + 4 * (lane >> 5) + c] = v;
                     }
                 }
-                // scratch[n_local][m_local] -> rows of 32 consecutive m (128 B) per n
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const int mloc = lane & 31;
-                const int mg = m0 + wm * WM + i * 32 + mloc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int mloc = lane & 31;
+            const int mg = m0 + wm * WM + i * 32 + mloc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
                     const int nloc = rr * 2 + (lane >> 5);
-                    const int ng = n0 + nl + nloc;
-                    if (!EDGE || (ng < g.N && mg < g.M)) Cb[(long long)ng * g.sCm + mg] = scratch[nloc * 33 + mloc];
+                    const int ng = n0 + wn * WN + j * 32 + nloc;
+                    if (!EDGE || (ng < g.N && mg < g.M)) Cb[(long long)ng * g.sCm + mg] = sc[j * (32 * 33) + nloc * 33 + mloc];
                 }
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -302,7 +306,7 @@ template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool TS, i
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(const AbxGemm g) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int OPER = 2 * BK * LDA + 2 * BK * LDB;
-    constexpr int EPI = 2 * BM + 4 * 32 * 33 + 4 * BM;
+    constexpr int EPI = 2 * BM + (TS ? 4 * (WN / 32) * 32 * 33 : 4 * BM);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntn = (g.N + BN - 1) / BN;
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give each XCD a contiguous range of tiles so the

@@ -289,7 +289,11 @@ class Engine:
             bT = ws.get('biasT', (Bc, 4, LL))
             _ln_lin(P, pre + 'proj_pair', pre + 'norm', stats2, z3, bT.transpose(1, 2))
             o = w384[:M2 * 192].view(M2, 192)
-            ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row)
+            if not per_row:            # ending node: bias[b,h,q,k] = P[b,k,q,h] -> make it key-contiguous once (2 MB / sample)
+                bT2 = ws.get('biasT2', (Bc, 4, LL))
+                ops.transpose_last2(bT.view(Bc * 4, L, L), bT2.view(Bc * 4, L, L))
+                bT = bT2
+            ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True)
             _lin(P, pre + 'attn.proj_out', o, z2, resid=z2, stats_out=stats2)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'

@@ -116,8 +116,16 @@ def layernorm(x, gamma, beta, out=None, res=None, eps=1e-5):
     return out
 
 
-def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48):
-    """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor; out (B*L*L, H*D)."""
+def transpose_last2(x, out):
+    L = x.shape[-1]
+    assert x.shape[-2] == L and x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
+    check(_lib.load().abx_transpose_last2(_p(_f32(x)), _p(out), x.numel() // (L * L), L, _stream()), 'abx_transpose_last2')
+    return out
+
+
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False):
+    """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
+    already laid out [b,h,q,k] for this orientation (bias_is_qk=True); out (B*L*L, H*D)."""
     lib = _lib.load()
     W = qkvg.shape[1]
     assert W == 4 * H * D and qkvg.is_contiguous() and out.is_contiguous() and biasT.is_contiguous()
@@ -129,7 +137,7 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48):
     a.ss, a.sl = (L * W, W) if per_row else (W, L * W)
     a.bias = _p(biasT)
     a.bias_sb, a.bias_sh = H * L * L, L * L
-    a.bias_sq, a.bias_sk = (L, 1) if per_row else (1, L)
+    a.bias_sq, a.bias_sk = (L, 1) if (per_row or bias_is_qk) else (1, L)
     if keymask is not None:
         a.keymask, a.km_sb = _p(_f32(keymask)), L
     C_ = H * D

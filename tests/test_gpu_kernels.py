@@ -179,6 +179,11 @@ def test_tri_attn(ops, L, per_row):
     if not per_row:
         o = o.transpose(1, 2)
     check(out.view(B, L, L, C), o, 5e-6, f'tri_attn L={L} per_row={per_row}')
+    # same through the key-contiguous bias copy the model uses for the ending node
+    b2 = biasT.to(DEV) if per_row else ops.transpose_last2(biasT.to(DEV).view(B * H, L, L), torch.empty(B * H, L, L, device=DEV)).view(B, H, L, L)
+    out2 = torch.full((B * L * L, C), float('nan'), device=DEV)
+    ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), b2, mask.float().to(DEV), out2, B, L, per_row, bias_is_qk=True)
+    check(out2.view(B, L, L, C), o, 5e-6, f'tri_attn (qk bias) L={L} per_row={per_row}')
 
 
 def test_tri_attn_all_keys_masked_row_and_spike(ops):

@@ -112,8 +112,11 @@ def main():
         mask = torch.ones(Bc, L, device=DEV)
         o = torch.empty(M2, 192, device=DEV)
         for per_row in (True, False):
-            ms = timeit(lambda: ops.tri_attn(x, bT, mask, o, Bc, L, per_row))
+            ms = timeit(lambda: ops.tri_attn(x, bT, mask, o, Bc, L, per_row, bias_is_qk=True))
             rec(f'tri_attn per_row={per_row}', ms, 4.0 * Bc * L * 4 * LL * 48, 4.0 * M2 * (768 + 192))
+        bT2 = torch.empty_like(bT)
+        ms = timeit(lambda: ops.transpose_last2(bT.view(Bc * 4, L, L), bT2.view(Bc * 4, L, L)))
+        rec('transpose_last2 (bias)', ms, 0, 8.0 * Bc * 4 * LL)
     if not only or 'ipa' in only:
         qp, kp, vp = r(M1 * 12 * 28), r(M1 * 12 * 28), r(M1 * 12 * 40)
         bias2d, zz = r(M2, 12), r(M2, 128)
