@@ -23,6 +23,7 @@ class AbxGemm(C.Structure):
         ('c_transposed', I),
         ('ln_stats', c_f), ('sSb', LL),
         ('ln_csum', c_f),
+        ('ln_eps', F),
         ('a_relu', I),
         ('bias', c_f),
         ('alpha', F),

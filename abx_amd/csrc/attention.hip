@@ -3,8 +3,8 @@
 // abx_tri_attn_fwd — triangle attention (reference abx/model/seqformer.py:506-550, Attention.forward :272-312) as a
 // flash-style fused kernel: the (B, L, 4, L, L) logits tensor (268 MB / sample at L = 256) is never materialised.
 // One workgroup per (b, row s, head h): K [L][48] and V [L][48] of that row are staged ONCE in LDS (padded strides 50 / 52
-// floats, conflict-free for the MFMA operand reads below); each of the 8 waves (2 per SIMD, so one wave's softmax VALU runs
-// under the other's MFMAs) walks query tiles of 16 rows with a base-2 online softmax over 64-key tiles; the pair bias of
+// floats, conflict-free for the MFMA operand reads below); each of the 12 waves (3 per SIMD, so one wave's softmax VALU / LDS
+// latency hides under the others' MFMAs) walks query tiles of 16 rows with a base-2 online softmax over 64-key tiles; the pair bias of
 // a tile is fetched before its QK^T MFMAs.  Both contractions run on v_mfma_f32_16x16x4_f32 (exact fp32):
 //     S^T[key][q]  = sum_d K[key][d] * Q[q][d]        ("swapped" QK^T: a lane owns 4 keys of ONE query column, so the
 //                                                      softmax row reductions are in-lane + two cross-group shuffles)
@@ -22,7 +22,7 @@ constexpr int TD = 48;        // head dim of triangle attention
 constexpr int LDK = 50;       // K row stride in LDS (floats): (key*50 + d) mod 32 distinct over 16 keys x 2 d
 constexpr int LDV = 52;       // V row stride: 4*52 mod 32 == 16 -> lane groups g land on disjoint bank halves
 
-constexpr int TRI_THREADS = 512;      // 8 waves = 2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs
+constexpr int TRI_THREADS = 768;      // 12 waves = 3 per SIMD: softmax VALU / LDS latency of one wave hide under the others' MFMAs
 constexpr float LOG2E = 1.4426950408889634f;
 
 __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn a) {
@@ -47,12 +47,21 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
     }
     // additive key mask for every key slot of the padded tiles: 0 (valid), finfo.min marker (masked), -inf (beyond L)
     float* Ms = Vs + (size_t)L * LDV;
+    const int Lpad = ((L + 63) / 64) * 64;
     {
         const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
-        for (int key = tid; key < ((L + 63) / 64) * 64; key += TRI_THREADS)
-            Ms[key] = key < L ? ((!km || km[key] != 0.f) ? 0.f : 1.f) : 2.f;
+        if (tid == 0) Ms[Lpad] = 0.f;
+        __syncthreads();
+        bool any_masked = false;
+        for (int key = tid; key < Lpad; key += TRI_THREADS) {
+            const float mv = key < L ? ((!km || km[key] != 0.f) ? 0.f : 1.f) : 2.f;
+            Ms[key] = mv;
+            any_masked |= mv == 1.f;
+        }
+        if (any_masked) Ms[Lpad] = 1.f;            // benign race: every writer stores the same value
     }
     __syncthreads();
+    const bool has_mask = Ms[Lpad] != 0.f;
 
     const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
     const int nqt = (L + 15) / 16, nkt = (L + 63) / 64;
@@ -108,15 +117,26 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
             }
             // this lane: keys kb + g*4 + r (r = 0..3) of query column lq
             float mx = -INFINITY;
+            if (!has_mask && kt * 64 + 64 <= L) {              // common case: full tile, nothing masked
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + kt * 64 + sub * 16 + g * 4);
+                for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
-                    v = mk[r] == 0.f ? v : (mk[r] == 1.f ? ABX_NEG_MAX : -INFINITY);
-                    sc[sub][r] = v;
-                    mx = fmaxf(mx, v);
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                        sc[sub][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + kt * 64 + sub * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                        v = mk[r] == 0.f ? v : (mk[r] == 1.f ? ABX_NEG_MAX : -INFINITY);
+                        sc[sub][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
                 }
             }
             // ---- online softmax update of this query column
@@ -137,10 +157,12 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
             rs += __shfl_xor(rs, 32, 64);
             l_run = l_run * alpha + rs;
             m_run = m_new;
+            if (!__all(alpha == 1.0f)) {                        // the running maximum rarely moves after the first tiles
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+                for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+            }
             // ---- O^T += V^T P : MFMA step (sub, r) contracts keys {kb + g*4 + r : g = 0..3}
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
@@ -243,7 +265,7 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
-    const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64) * sizeof(float);
+    const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout (L <= 397)");
     static thread_local size_t configured = 0;
     if (lds > configured) {

@@ -77,13 +77,49 @@ struct TileLoader {
         }
     }
 
-    __device__ __forceinline__ void store(float* __restrict__ lds, bool relu) const {
+    // LayerNorm statistics of the A rows, accumulated from the operand registers while they wait for their LDS slot
+    // (inline-LN mode).  KC: slot i = one row, sums of (x - shift[i]); RC: slots 0..3 = the four rows of this lane's float4.
+    __device__ __forceinline__ void stats_accum(float* __restrict__ s, float* __restrict__ q, const float* __restrict__ shift,
+                                                int k0, int K) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * 256;
+            if (NVEC % 256 == 0 || idx < NVEC) {
+                if (KC) {
+                    const int kq = idx % (BK / 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (!EDGE || k0 + kq * 4 + c < K) {
+                            const float d = v[i][c] - shift[i];
+                            s[i] += d;
+                            q[i] = fmaf(d, d, q[i]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        s[c] += v[i][c];
+                        q[c] = fmaf(v[i][c], v[i][c], q[c]);
+                    }
+                }
+            }
+        }
+    }
+
+    // shift (KC, inline LayerNorm): the row's first element is subtracted from the operand so that the folded LayerNorm
+    // rstd * (acc - (mean - shift) * csum) has no mean >> sigma cancellation
+    __device__ __forceinline__ void store(float* __restrict__ lds, bool relu, const float* __restrict__ shift = nullptr) const {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * 256;
             if (NVEC % 256 == 0 || idx < NVEC) {
                 f32x4 r = v[i];
+                if (KC && shift) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] -= shift[i];
+                }
                 if (relu) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) r[c] = fmaxf(r[c], 0.f);
@@ -129,9 +165,21 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
     const long long a_smn = g.sAm, a_sk = g.sAk, b_smn = g.sBn, b_sk = g.sBk;
     const int nk = (g.K + BK - 1) / BK;
 
+    // inline LayerNorm statistics: computed from the A operand stream itself (no separate statistics pass over HBM)
+    const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f}, lshift[4] = {0.f, 0.f, 0.f, 0.f};
+
     la.load(Ab, a_smn, a_sk, m0, 0, g.M, g.K, a_vec);
     lb.load(Bb, b_smn, b_sk, n0, 0, g.N, g.K, b_vec);
-    la.store(As, relu);
+    if (ln_inline) {
+        if (AKC) {      // shift = first element of the row (held by the kq == 0 lane of the quad): kills the E[x^2]-mean^2 cancellation
+#pragma unroll
+            for (int i = 0; i < TileLoader<BM, BK, AKC, EDGE>::NV; ++i) lshift[i] = __shfl(la.v[i][0], lane & ~3, 64);
+        }
+        la.stats_accum(ls, lq, lshift, 0, g.K);
+    }
+    const float* shp = (ln_inline && AKC) ? lshift : nullptr;
+    la.store(As, relu, shp);
     lb.store(Bs, false);
     __syncthreads();
 
@@ -158,7 +206,8 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < nk) {
-            la.store(As + (cur ^ 1) * BK * LDA, relu);
+            if (ln_inline) la.stats_accum(ls, lq, lshift, (t + 1) * BK, g.K);
+            la.store(As + (cur ^ 1) * BK * LDA, relu, shp);
             lb.store(Bs + (cur ^ 1) * BK * LDB, false);
         }
         __syncthreads();
@@ -169,13 +218,55 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
     // stats_out: per-row partial sums of the two wave columns.
     float* st_lds = smem;                                   // [BM][2]
     float* part = smem + 2 * BM;                             // [BM][WAVES_N][2] (plain store) | transposed-store scratch
-    const float* stats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
-    if (stats) {
+    const float* gstats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
+    const bool stats = gstats != nullptr || ln_inline;
+    if (gstats) {
         for (int idx = threadIdx.x; idx < 2 * BM; idx += 256) {
             const int m = m0 + (idx >> 1);
-            st_lds[idx] = (!EDGE || m < g.M) ? stats[2 * (long long)m + (idx & 1)] : 0.f;
+            st_lds[idx] = (!EDGE || m < g.M) ? gstats[2 * (long long)m + (idx & 1)] : 0.f;
         }
         __syncthreads();
+    } else if (ln_inline) {
+        const float invK = 1.0f / (float)g.K;
+        if (AKC) {
+            constexpr int NVA = TileLoader<BM, BK, AKC, EDGE>::NV;
+#pragma unroll
+            for (int i = 0; i < NVA; ++i) {
+                float sm = ls[i], sq = lq[i];
+                sm += __shfl_xor(sm, 1, 64); sq += __shfl_xor(sq, 1, 64);
+                sm += __shfl_xor(sm, 2, 64); sq += __shfl_xor(sq, 2, 64);
+                const int idx = threadIdx.x + i * 256;
+                if ((idx & 3) == 0 && idx < BM * BK / 4) {
+                    const int row = idx / (BK / 4);
+                    const float dm = sm * invK;
+                    st_lds[2 * row] = dm;                       // the operand was shifted: only (mean - shift) remains
+                    st_lds[2 * row + 1] = 1.0f / sqrtf(fmaxf(sq * invK - dm * dm, 0.f) + g.ln_eps);
+                }
+            }
+            __syncthreads();
+        } else {
+            // m-contiguous A: this lane saw rows mq*4..+3 for the k-rows (tid/32 + 8 i); combine the 8 k-groups through LDS
+            float* red = smem + 2 * BM;                      // [8][BM][2]
+            const int mq = threadIdx.x % (BM / 4), kg = threadIdx.x / (BM / 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[(kg * BM + mq * 4 + c) * 2] = ls[c];
+                red[(kg * BM + mq * 4 + c) * 2 + 1] = lq[c];
+            }
+            __syncthreads();
+            for (int r = threadIdx.x; r < BM; r += 256) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int kg2 = 0; kg2 < 256 / (BM / 4); ++kg2) {
+                    sm += red[(kg2 * BM + r) * 2];
+                    sq += red[(kg2 * BM + r) * 2 + 1];
+                }
+                const float mean = sm * invK;
+                st_lds[2 * r] = mean;
+                st_lds[2 * r + 1] = 1.0f / sqrtf(fmaxf(sq * invK - mean * mean, 0.f) + g.ln_eps);
+            }
+            __syncthreads();
+        }
     }
     float* Cb = g.C + (long long)b * g.sCb;
     const float* rs = g.rowscale ? g.rowscale + (long long)b * g.sRSb : nullptr;
@@ -188,7 +279,7 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
         const int n = n0 + wn * WN + j * 32 + (lane & 31);
         nok[j] = !EDGE || n < g.N;
         bias[j] = (g.bias && nok[j]) ? g.bias[n] : 0.f;
-        csum[j] = (stats && nok[j]) ? g.ln_csum[n] : 0.f;
+        csum[j] = (stats && nok[j]) ? g.ln_csum[n] : 0.f;   // stats: bool
     }
     auto epi = [&](float v, int ml, int m, int n, int j, bool ok) -> float {
         if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
@@ -306,7 +397,7 @@ template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool TS, i
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(const AbxGemm g) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int OPER = 2 * BK * LDA + 2 * BK * LDB;
-    constexpr int EPI = 2 * BM + (TS ? 4 * (WN / 32) * 32 * 33 : 4 * BM);
+    constexpr int EPI = 2 * BM + (TS ? 4 * (WN / 32) * 32 * 33 : (AKC ? 4 * BM : (256 / (BM / 4)) * BM * 2));
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntn = (g.N + BN - 1) / BN;
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give each XCD a contiguous range of tiles so the
@@ -428,6 +519,8 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(g.sAk == 1 || g.sAm == 1, "abx_gemm: A must be k- or m-contiguous");
     ABX_REQUIRE(g.sBn == 1 || g.sBk == 1, "abx_gemm: B must be n- or k-contiguous");
     ABX_REQUIRE(!g.ln_stats || g.ln_csum, "abx_gemm: LayerNorm needs the column sums of the gamma-scaled weights");
+    ABX_REQUIRE(!(g.ln_csum && g.a_relu), "abx_gemm: LayerNorm and relu-on-load are exclusive");
+    if (g.ln_csum && !g.ln_stats && g.ln_eps <= 0.f) g.ln_eps = 1e-5f;
     ABX_REQUIRE(!g.stats_out || (g.N <= 192 && !g.c_transposed), "abx_gemm: stats_out needs N <= 192 (one tile per row) and a plain store");
     const bool akc = g.sAk == 1;
     // 16-byte vector loads need aligned bases and strides that are multiples of 4 elements

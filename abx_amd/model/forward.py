@@ -165,9 +165,8 @@ class Engine:
             n_ag = ag_idx.numel()
             e = torch.empty(n_ag, 512, device=dev)
             ops.gather_rows(P.sd[P_SEQF + 'proj_aa_type.weight'], ag_idx, e)
-            st = ops.row_stats(e)
             e1 = torch.empty(n_ag, 512, device=dev)
-            _ln_lin(P, P_SEQF + 'aa_proj.1', P_SEQF + 'aa_proj.0', st, e, e1, act=1)
+            _ln_lin(P, P_SEQF + 'aa_proj.1', P_SEQF + 'aa_proj.0', None, e, e1, act=1)
             ss = seq_static.view(B, L, 512)
             # rows of the antigen are not contiguous over the batch: one GEMM per sample keeps the C ABI simple
             for b in range(B):
@@ -220,57 +219,51 @@ class Engine:
         prev_pos = st['prev_pos'][b0:b1] if st['prev_pos'] is not None else None
         ops.assemble_seq(sstat, P.sd[P_SEQF + 'proj_aa_type.weight'], seq_t, Lab, temb, prev_seq,
                          *P.ln(P_SEQF + 'prev_seq_norm'), seq_act, Bc, L, CS, E)
-        stats2 = ws.get('stats2', (M2, 2))
         ops.assemble_pair(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos,
-                          P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E, stats_out=stats2)
+                          P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E)
         s2 = seq_act.view(M1, WS_)
         z2 = pair_act.view(M2, WZ)
         z3 = pair_act.view(Bc, LL, WZ)
         w768 = ws.get('w768', (M2, 768))
         w384 = ws.get('w384', (M2 * 384,))
-        stats1 = ws.get('stats1', (M1, 2))
-        statsT = ws.get('statsT', (M2, 2))
         pmask = ws.get('pmask', (M2,))
         ops.pair_mask(mask_f, pmask, Bc, L)
 
         # ---------------- seq attention with pair bias (seqformer.py:314-356)
         pre = P_BLK + 'seq_attn.'
         H = c.seqformer.seq_attention_with_pair_bias.num_head
-        ops.row_stats(s2, stats1)                      # pair-row statistics come fused from the producing kernels
         biasT = ws.get('biasT', (Bc, H, LL))
-        _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', stats2, z3, biasT.transpose(1, 2))
+        _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', None, z3, biasT.transpose(1, 2))
         qkv = ws.get('s_a', (M1, 3 * WS_))
         sgate = ws.get('s_b', (M1, WS_))
         so = ws.get('s_c', (M1, WS_))
-        _ln_lin(P, pre + 'attn.proj_in', pre + 'seq_norm', stats1, s2, qkv)
-        _ln_lin(P, pre + 'attn.gate', pre + 'seq_norm', stats1, s2, sgate)
+        _ln_lin(P, pre + 'attn.proj_in', pre + 'seq_norm', None, s2, qkv)
+        _ln_lin(P, pre + 'attn.gate', pre + 'seq_norm', None, s2, sgate)
         ops.seq_attn(qkv, biasT, mask_f, sgate, so, Bc, L, H, WS_ // H)
         _lin(P, pre + 'attn.proj_out', so, s2, resid=s2)
         # ---------------- seq transition
         pre = P_BLK + 'seq_transition.transition.'
-        ops.row_stats(s2, stats1)
         hid = ws.get('s_a', (M1, 4 * WS_))
-        _ln_lin(P, pre + '1', pre + '0', stats1, s2, hid, act=1)
+        _ln_lin(P, pre + '1', pre + '0', None, s2, hid, act=1)
         _lin(P, pre + '3', hid, s2, resid=s2)
         # ---------------- outer product mean (seqformer.py:395-411)
         pre = P_BLK + 'outer_product_mean.'
-        ops.row_stats(s2, stats1)
         lr = ws.get('s_b', (M1, 128))
-        _ln_lin(P, pre + 'lr', pre + 'norm', stats1, s2, lr, rowscale=mask_f.reshape(-1))
+        _ln_lin(P, pre + 'lr', pre + 'norm', None, s2, lr, rowscale=mask_f.reshape(-1))
         feat = w384[:M2 * 128].view(M2, 128)
         ops.opm_features(lr, feat, Bc, L, 64)
-        _lin(P, pre + 'out_proj', feat, z2, resid=z2, stats_out=stats2)
+        _lin(P, pre + 'out_proj', feat, z2, resid=z2)
         # ---------------- triangle multiplication (seqformer.py:443-504)
         for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
             pre = P_BLK + name + '.'
             G = w768[:, :448]
-            _ln_lin(P, pre + 'gates', pre + 'norm', stats2, z2, G)
+            _ln_lin(P, pre + 'gates', pre + 'norm', None, z2, G)
             left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
             right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
             tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
             G3 = w768.view(Bc, LL, 768)
-            _ln_lin(P, pre + 'left_proj', pre + 'norm', stats2, z3, left.transpose(1, 2), rowscale=pmask, gate=G3[:, :, 0:128])
-            _ln_lin(P, pre + 'right_proj', pre + 'norm', stats2, z3, right.transpose(1, 2), rowscale=pmask,
+            _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, left.transpose(1, 2), rowscale=pmask, gate=G3[:, :, 0:128])
+            _ln_lin(P, pre + 'right_proj', pre + 'norm', None, z3, right.transpose(1, 2), rowscale=pmask,
                     gate=G3[:, :, 128:256])
             lz = left.view(Bc * 128, L, L)
             rz = right.view(Bc * 128, L, L)
@@ -280,24 +273,23 @@ class Engine:
             else:             # 'bkic,bkjc->bijc'
                 ops.gemm(lz.transpose(1, 2), rz, tz)
             tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
-            ops.row_stats(tcm, statsT)
-            _ln_lin(P, pre + 'proj_out', pre + 'final_norm', statsT, tcm, z3, gate=G3[:, :, 256:448], resid=z3, stats_out=stats2)
+            _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=G3[:, :, 256:448], resid=z3)
         # ---------------- triangle attention (seqformer.py:506-550)
         for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
             pre = P_BLK + name + '.'
-            _ln_lin(P, pre + 'qkvg', pre + 'norm', stats2, z2, w768)
+            _ln_lin(P, pre + 'qkvg', pre + 'norm', None, z2, w768)
             bT = ws.get('biasT', (Bc, 4, LL))
-            _ln_lin(P, pre + 'proj_pair', pre + 'norm', stats2, z3, bT.transpose(1, 2))
+            _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2))
             o = w384[:M2 * 192].view(M2, 192)
             if not per_row:            # ending node: bias[b,h,q,k] = P[b,k,q,h] -> make it key-contiguous once (2 MB / sample)
                 bT2 = ws.get('biasT2', (Bc, 4, LL))
                 ops.transpose_last2(bT.view(Bc * 4, L, L), bT2.view(Bc * 4, L, L))
                 bT = bT2
             ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True)
-            _lin(P, pre + 'attn.proj_out', o, z2, resid=z2, stats_out=stats2)
+            _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'
-        _ln_lin(P, pre + '1', pre + '0', stats2, z2, w768, act=1)
+        _ln_lin(P, pre + '1', pre + '0', None, z2, w768, act=1)
         _lin(P, pre + '3', w768, z2, resid=z2)
 
         # ================= IpaScore (score_network.py:83-196)

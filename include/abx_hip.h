@@ -48,8 +48,10 @@ typedef struct AbxGemm {
     float* C;       long long sCb, sCm;            /* n-contiguous; if c_transposed: (m,n) at C + b*sCb + n*sCm + m */
     int M, N, K, batch;
     int c_transposed;
-    const float* ln_stats; long long sSb;          /* (mean,rstd) pairs, row index b*sSb + m; NULL = no LayerNorm */
-    const float* ln_csum;                          /* [N] column sums of the gamma-scaled B */
+    const float* ln_stats; long long sSb;          /* (mean,rstd) pairs, row index b*sSb + m; NULL with ln_csum set = the kernel
+                                                      computes the row statistics itself from the A operand stream */
+    const float* ln_csum;                          /* [N] column sums of the gamma-scaled B; NULL = no LayerNorm */
+    float ln_eps;                                  /* inline statistics: epsilon (0 -> 1e-5) */
     int a_relu;
     const float* bias;                             /* [N] or NULL */
     float alpha;                                   /* use 1.0f for none */

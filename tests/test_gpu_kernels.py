@@ -78,6 +78,15 @@ def test_gemm_ln_gate_resid_rowscale(ops):
     ops.gemm(Ad, Wt, resd, bias=bias2, ln=(stats, csum), alpha=0.5, rowscale=rs.to(DEV), gate=gd[:, :N], resid=resd)
     ref = ((ref_ln @ W.double().t() + b.double()) * 0.5) * rs.double()[:, None] * torch.sigmoid(gate[:, :N].double()) + res.double()
     check(resd, ref, 3e-6, 'gemm LN+gate+resid (in place)')
+    resd = res.to(DEV).clone()
+    ops.gemm(Ad, Wt, resd, bias=bias2, ln=(None, csum), alpha=0.5, rowscale=rs.to(DEV), gate=gd[:, :N], resid=resd)
+    check(resd, ref, 3e-6, 'gemm inline-LN+gate+resid (in place)')
+    # inline statistics with a large common offset (mean >> std): the shifted accumulation must not cancel
+    Aoff = (A * 0.05 + 300.0).to(DEV)          # |mean| / sigma = 3000
+    outo = torch.empty(M, N, device=DEV)
+    ops.gemm(Aoff, Wt, outo, bias=bias2, ln=(None, csum))
+    refo = torch.nn.functional.layer_norm((A.double() * 0.05 + 300.0).float().double(), (K,), ga.double(), be.double(), 1e-5) @ W.double().t() + b.double()
+    check(outo, refo, 2e-5, 'gemm inline-LN with mean >> std')
     # fused statistics of the output rows (N <= 192): the next LayerNorm's (mean, rstd)
     for Nn in (192, 128):
         out = torch.empty(M, Nn, device=DEV)
@@ -127,6 +136,9 @@ def test_gemm_layouts_batched_transposed(ops):
     ln = torch.nn.functional.layer_norm(Z.double(), (C,), ga.double(), be.double(), 1e-5)
     ref = (ln @ W.double().t() + bias.double()) * pm.double().view(B, LL, 1) * torch.sigmoid(G[:, :, 128:256].double())
     check(outT, ref.transpose(1, 2), 3e-6, 'transposed store')
+    outT.fill_(float('nan'))
+    ops.gemm(Zd, Wt, outT.transpose(1, 2), bias=bias2, ln=(None, csum), rowscale=pm.to(DEV), gate=G.to(DEV)[:, :, 128:256])
+    check(outT, ref.transpose(1, 2), 3e-6, 'transposed store, inline LN')
     # channel-major A (m-contiguous) with channel-major LN stats, back to channel-last with residual
     T = torch.randn(B, Cout, LL, generator=g(23))
     Td = T.to(DEV)
@@ -139,6 +151,9 @@ def test_gemm_layouts_batched_transposed(ops):
     ops.gemm(tcm, Wt2, res, bias=bias22, ln=(st2, csum2), resid=res)
     ln2 = torch.nn.functional.layer_norm(T.double().transpose(1, 2), (Cout,), ga2.double(), be2.double(), 1e-5)
     check(res, ln2 @ W2.double().t() + Z.double(), 3e-6, 'channel-major A + LN')
+    res = Zd.clone()
+    ops.gemm(tcm, Wt2, res, bias=bias22, ln=(None, csum2), resid=res)
+    check(res, ln2 @ W2.double().t() + Z.double(), 3e-6, 'channel-major A + inline LN')
 
 
 def test_gemm_small_n_and_relu_input(ops):

@@ -61,7 +61,7 @@ def main():
             C = torch.empty(M2, N, device=DEV)
             bias, csum = r(N), r(N)
             if K == 192:
-                ms = timeit(lambda: ops.gemm(A, W, C, bias=bias, ln=(stats, csum)))
+                ms = timeit(lambda: ops.gemm(A, W, C, bias=bias, ln=(None, csum)))
             else:
                 ms = timeit(lambda: ops.gemm(A, W, C, bias=bias))
             rec(f'gemm {M2}x{N}x{K} {tag}', ms, 2.0 * M2 * N * K, 4.0 * M2 * (N + K))
@@ -72,7 +72,7 @@ def main():
         left = torch.empty(Bc, 128, LL, device=DEV)
         W = r(192, 128) / 14
         bias, csum = r(128), r(128)
-        ms = timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(stats, csum), rowscale=pm, gate=G[:, :, :128]))
+        ms = timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(None, csum), rowscale=pm, gate=G[:, :, :128]))
         rec('gemm tri-mul proj (LN, gate, transposed store)', ms, 2.0 * M2 * 128 * 192, 4.0 * M2 * (192 + 128 + 128))
         lz, rz, tz = left.view(Bc * 128, L, L), torch.randn_like(left).view(Bc * 128, L, L), torch.empty(Bc * 128, L, L, device=DEV)
         ms = timeit(lambda: ops.gemm(lz, rz.transpose(1, 2), tz))
@@ -83,7 +83,7 @@ def main():
         st2 = ops.row_stats(tcm)
         W2 = r(128, 192) / 11
         b2, c2 = r(192), r(192)
-        ms = timeit(lambda: ops.gemm(tcm, W2, z3, bias=b2, ln=(st2, c2), gate=G[:, :, 256:448], resid=z3))
+        ms = timeit(lambda: ops.gemm(tcm, W2, z3, bias=b2, ln=(None, c2), gate=G[:, :, 256:448], resid=z3))
         rec('gemm tri-mul out (channel-major A, LN, gate)', ms, 2.0 * M2 * 192 * 128, 4.0 * M2 * (128 + 192 * 3))
         ms = timeit(lambda: ops.row_stats(z, stats))
         rec('row_stats (M2 x 192)', ms, 0, 4.0 * M2 * 192)
