@@ -108,36 +108,48 @@ __global__ __launch_bounds__(IPA_THREADS) void ipa_attn_kernel(const float* __re
     __syncthreads();
 
     // ---- phase A: logits -------------------------------------------------------------------------------------
+    // K records of HB heads are fetched together (HB*7 16-byte loads in flight per lane) before any arithmetic
+    constexpr int HB = 3;
     for (int j = tid; j < L; j += IPA_THREADS) {
         const float mj = mask[(long long)b * L + j];
-        for (int h = 0; h < H; ++h) {
-            const float* kr = kpack + (((long long)b * H + h) * L + j) * QREC;
-            float kv[QREC];
+        float mi[IQ];
 #pragma unroll
-            for (int c4 = 0; c4 < QREC / 4; ++c4) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(kr + c4 * 4);
-                kv[c4 * 4] = t4[0]; kv[c4 * 4 + 1] = t4[1]; kv[c4 * 4 + 2] = t4[2]; kv[c4 * 4 + 3] = t4[3];
+        for (int iq = 0; iq < IQ; ++iq) mi[iq] = iq < niq ? mask[(long long)b * L + i0 + iq] : 0.f;
+#pragma unroll 1
+        for (int h0 = 0; h0 < H; h0 += HB) {
+            f32x4 kq[HB][QREC / 4];
+            float bz[HB][IQ];
+#pragma unroll
+            for (int hh = 0; hh < HB; ++hh) {
+                const float* kr = kpack + (((long long)b * H + h0 + hh) * L + j) * QREC;
+#pragma unroll
+                for (int c4 = 0; c4 < QREC / 4; ++c4) kq[hh][c4] = *reinterpret_cast<const f32x4*>(kr + c4 * 4);
+#pragma unroll
+                for (int iq = 0; iq < IQ; ++iq)
+                    bz[hh][iq] = iq < niq ? bias2d[(((long long)b * L + i0 + iq) * L + j) * H + h0 + hh] : 0.f;
             }
-            const float pwh = pw[h];
 #pragma unroll
-            for (int iq = 0; iq < IQ; ++iq) {
-                const float* qr = qs + (iq * H + h) * QREC;
-                float s = 0.f;
+            for (int hh = 0; hh < HB; ++hh) {
+                const int h = h0 + hh;
+                const float pwh = pw[h];
 #pragma unroll
-                for (int c = 0; c < SQK; ++c) s = fmaf(qr[c], kv[c], s);
-                float d2 = 0.f;
+                for (int iq = 0; iq < IQ; ++iq) {
+                    const float* qr = qs + (iq * H + h) * QREC;
+                    float sacc = 0.f, d2 = 0.f;
 #pragma unroll
-                for (int c = SQK; c < QREC; ++c) {
-                    const float d = qr[c] - kv[c];
-                    d2 = fmaf(d, d, d2);
+                    for (int c = 0; c < SQK; ++c) sacc = fmaf(qr[c], kq[hh][c >> 2][c & 3], sacc);
+#pragma unroll
+                    for (int c = SQK; c < QREC; ++c) {
+                        const float d = qr[c] - kq[hh][c >> 2][c & 3];
+                        d2 = fmaf(d, d, d2);
+                    }
+                    float v = sacc + pwh * d2;
+                    if (iq < niq) {
+                        v += bz[hh][iq];
+                        if (mi[iq] * mj == 0.f) v = ABX_NEG_MAX;
+                    }
+                    lg[((size_t)iq * L + j) * LDH + h] = v;
                 }
-                float v = s + pwh * d2;
-                if (iq < niq) {
-                    v += bias2d[(((long long)b * L + i0 + iq) * L + j) * H + h];
-                    const float mi = mask[(long long)b * L + i0 + iq];
-                    if (mi * mj == 0.f) v = ABX_NEG_MAX;
-                }
-                lg[((size_t)iq * L + j) * LDH + h] = v;
             }
         }
     }
@@ -169,14 +181,25 @@ __global__ __launch_bounds__(IPA_THREADS) void ipa_attn_kernel(const float* __re
         for (int iq = 0; iq < IQ; ++iq) acc[iq] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (jg < NJG1) {
             const float* vb = vpack + ((long long)b * H + h) * L * VREC + c4 * 4;
-#pragma unroll 4
-            for (int j = jg; j < L; j += NJG1) {
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long long)j * VREC);
+            constexpr int UB = 8;                       // loads in flight per lane
+            for (int jb = jg; jb < L; jb += NJG1 * UB) {
+                f32x4 vv[UB];
 #pragma unroll
-                for (int iq = 0; iq < IQ; ++iq) {
-                    const float w = lg[((size_t)iq * L + j) * LDH + h];
+                for (int u = 0; u < UB; ++u) {
+                    const int j = min(jb + u * NJG1, L - 1);
+                    vv[u] = *reinterpret_cast<const f32x4*>(vb + (long long)j * VREC);
+                }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[iq][c] = fmaf(w, vv[c], acc[iq][c]);
+                for (int u = 0; u < UB; ++u) {
+                    const int j = jb + u * NJG1;
+                    if (j < L) {
+#pragma unroll
+                        for (int iq = 0; iq < IQ; ++iq) {
+                            const float w = lg[((size_t)iq * L + j) * LDH + h];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[iq][c] = fmaf(w, vv[u][c], acc[iq][c]);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -201,15 +224,26 @@ __global__ __launch_bounds__(IPA_THREADS) void ipa_attn_kernel(const float* __re
             f32x4 acc[H];
 #pragma unroll
             for (int hh = 0; hh < H; ++hh) acc[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int j = jg; j < L; j += NJG2) {
-                const f32x4 zv = *reinterpret_cast<const f32x4*>(zr + (long long)j * CZ);
-                const float* a12 = ar + (size_t)j * LDH;
+            constexpr int UZ = 8;                       // 16-byte slab loads in flight per lane (8 KB per wave)
+            for (int jb = jg; jb < L; jb += NJG2 * UZ) {
+                f32x4 zv[UZ];
 #pragma unroll
-                for (int hh = 0; hh < H; ++hh) {
-                    const float w = a12[hh];
+                for (int u = 0; u < UZ; ++u) {
+                    const int j = min(jb + u * NJG2, L - 1);
+                    zv[u] = *reinterpret_cast<const f32x4*>(zr + (long long)j * CZ);
+                }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[hh][c] = fmaf(w, zv[c], acc[hh][c]);
+                for (int u = 0; u < UZ; ++u) {
+                    const int j = jb + u * NJG2;
+                    if (j < L) {
+                        const float* a12 = ar + (size_t)j * LDH;
+#pragma unroll
+                        for (int hh = 0; hh < H; ++hh) {
+                            const float w = a12[hh];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[hh][c] = fmaf(w, zv[u][c], acc[hh][c]);
+                        }
+                    }
                 }
             }
             // the two j-groups of a wave (lanes l, l+32) first, then the 8 waves through LDS, in a fixed order

@@ -27,6 +27,27 @@ def _f32(t):
 GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 
 
+def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False, stats_out=False):
+    """Name of the gemm_kernel<...> instantiation abx_gemm launches for a problem (mirror of the selection in
+    csrc/gemm.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
+    if stats_out and N > 128:
+        cfg = (128, 192, 64, 96, 2)
+    elif stats_out and N > 64:
+        cfg = (128, 128, 64, 64, 3)
+    elif N <= 32:
+        cfg = (128, 32, 32, 32, 3)
+    elif N <= 64:
+        cfg = (128, 64, 32, 64, 3)
+    elif ((M + 127) // 128) * ((N + 127) // 128) * batch < 512:
+        cfg = (64, 64, 32, 32, 3)
+    elif ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128:
+        cfg = (128, 192, 64, 96, 2)
+    else:
+        cfg = (128, 128, 64, 64, 3)
+    b = lambda x: 'true' if x else 'false'
+    return f'gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 16, {b(a_kcontig)}, {b(b_ncontig)}, {b(transposed)}, {cfg[4]}>'
+
+
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
          resid=None, stats_out=None, tune=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.

@@ -53,13 +53,15 @@ class OpTimer:
             nb = A.shape[0] if A.dim() == 3 else 1
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
-            return f'gemm[{nb}x{M}x{N}x{K}]', 2.0 * nb * M * N * K, 4.0 * nb * (M * K + M * N) + 4.0 * K * N
+            kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, C.stride(-1) != 1,
+                                             kw.get('stats_out') is not None)
+            return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K + M * N) + 4.0 * K * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
-            return f'tri_attn[B{Bc} L{L}]', 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
+            return 'tri_attn_kernel', 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
         if name == 'ipa_attn':
             Bc, L = args[-2], args[-1]
-            return f'ipa_attn[B{Bc} L{L}]', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12)
+            return 'ipa_attn_kernel', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12)
         return name, 0.0, 0.0
 
     def __enter__(self):
@@ -86,12 +88,14 @@ class OpTimer:
         torch.cuda.synchronize()
 
     def summary(self):
+        """Aggregate per KERNEL (like `rocprofv3 --stats`): total ms, launches, total algorithmic flops / bytes."""
         agg = defaultdict(lambda: [0.0, 0, 0.0, 0.0])
         for (sig, fl, by), e0, e1 in self.records:
             a = agg[sig]
             a[0] += e0.elapsed_time(e1)
             a[1] += 1
-            a[2], a[3] = fl, by
+            a[2] += fl
+            a[3] += by
         return sorted(((k, v[0], v[1], v[2], v[3]) for k, v in agg.items()), key=lambda x: -x[1])
 
 
@@ -265,7 +269,7 @@ def main():
         total = sum(s[1] for s in summ)
         top = summ[0]
         name, ms, calls, fl, by = top
-        dur = ms / calls / 1e3
+        dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
         if name.startswith('ipa_attn'):
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
         else:
@@ -274,7 +278,8 @@ def main():
                     avg_launch_ms=ms / calls, share_of_step=ms / total)
         result['roofline'] = roof
         result['op_profile_ms'] = [{'op': s[0], 'ms': round(s[1], 3), 'calls': s[2],
-                                    'tflops': (s[3] * s[2] / (s[1] / 1e3) / 1e12 if s[3] else None)} for s in summ[:12]]
+                                    'avg_ms': round(s[1] / s[2], 4),
+                                    'tflops': (s[3] / (s[1] / 1e3) / 1e12 if s[3] else None)} for s in summ[:14]]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args, D, batch, B, L, float(grid[1]))
