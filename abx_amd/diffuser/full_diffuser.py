@@ -246,12 +246,22 @@ class FullDiffuser:
         x_t = torch.exp(lmc) * x0 + torch.sqrt(1.0 - torch.exp(2.0 * lmc)) * z
         trans_score = self.calc_trans_score(x_t, x0, t, scale=False)
         trans_t = x_t / self.coord_scale_f32
-        # tokens: x_t ~ Categorical(q_t0[x_0]) (+ the x_tilde perturbation of discrete_diffuser.py:84-127)
+        # tokens (discrete_diffuser.py:72-127): x_t ~ Categorical(q_t0[x_0]); then ONE extra jump per sample ("x_tilde"): the
+        # position ~ Categorical(sum of off-diagonal rates) (uniform here), the new token ~ Categorical(rate row of x_t)
         e = torch.exp(-20 * self.rate_const * t.float())[:, None, None]
         q = e * torch.eye(20, device=dev)[None] + (1 - e) / 20
+        q = torch.where(q < 1e-8, torch.zeros_like(q), q)
         x0c = torch.clamp(seq_0, 0, 19).long()
         rows = torch.gather(q, 1, x0c[..., None].expand(B, L, 20))
-        seq_t = noise['seq'].to(dev) if noise and 'seq' in noise else torch.distributions.Categorical(rows).sample()
+        x_t = noise['seq_xt'].to(dev) if noise and 'seq_xt' in noise else torch.distributions.Categorical(rows).sample()
+        rate_rows = self.rate_const * (1.0 - torch.nn.functional.one_hot(x_t.long(), 20).float())      # (B,L,20), diagonal zeroed
+        dims = noise['seq_dim'].to(dev) if noise and 'seq_dim' in noise else \
+            torch.distributions.Categorical(rate_rows.sum(-1)).sample()
+        bidx = torch.arange(B, device=dev)
+        newv = noise['seq_new'].to(dev) if noise and 'seq_new' in noise else \
+            torch.distributions.Categorical(rate_rows[bidx, dims]).sample()
+        seq_t = x_t.clone()
+        seq_t[bidx, dims] = newv
         if diffuse_mask is not None:
             m = diffuse_mask
             rot_t = self._apply_mask(rot_t, rot_0, m[..., None])

@@ -738,8 +738,21 @@ class OracleSeq:
         xp = x_t + torch.sum(jumps * diffs, dim=2)
         return torch.clamp(xp, 0, self.K - 1).to(torch.int32)
 
-    def forward_marginal(self, x_0, t, noise):
-        raise NotImplementedError('optimize-mode token noising is drawn by the caller (Categorical sampling)')
+    def forward_marginal(self, x_0, t, noise=None):
+        """discrete_diffuser.py:72-127: x_t ~ Categorical(q_t0[x_0]) plus ONE extra jump per sample (x_tilde)."""
+        B, L = x_0.shape
+        qt0 = self.transition(t)
+        x_0 = torch.clamp(x_0, 0, self.K - 1).long()
+        rows = torch.gather(qt0, 1, x_0[..., None].expand(B, L, self.K))
+        x_t = noise['seq_xt'] if noise else torch.distributions.Categorical(rows).sample()
+        rate = self.rate_matrix[x_t.long()].clone()                                    # rate[x_t, :]
+        rate.scatter_(2, x_t.long()[..., None], 0.0)
+        dims = noise['seq_dim'] if noise else torch.distributions.Categorical(rate.sum(-1)).sample()
+        bi = torch.arange(B)
+        newv = noise['seq_new'] if noise else torch.distributions.Categorical(rate[bi, dims]).sample()
+        x_tilde = x_t.clone()
+        x_tilde[bi, dims] = newv
+        return x_tilde
 
 
 def _mask_merge(x_diff, x_fixed, m):
@@ -778,6 +791,23 @@ class OracleDiffuser:
         rot1 = _mask_merge(rot1, rot_t, m[..., None])
         seq1 = _mask_merge(seq1, seq_t, m)
         return torch.cat([rotvec_to_quat(rot1), tr1], dim=-1), seq1
+
+    def forward_marginal(self, rigids_0, seq_0, t, diffuse_mask=None, noise=None):
+        """full_diffuser.py:57-126 (optimize mode: noise the ground truth to time t)."""
+        trans_0, rot_0 = rigids_0[..., 4:], quat_to_rotvec(rigids_0[..., :4])
+        rot_t, rot_score = self.so3.forward_marginal(rot_0, t, noise)
+        trans_t, trans_score = self.r3.forward_marginal(trans_0, t, noise)
+        seq_t = self.seq.forward_marginal(seq_0, t, noise)
+        if diffuse_mask is not None:
+            m = diffuse_mask
+            rot_t = _mask_merge(rot_t, rot_0, m[..., None])
+            trans_t = _mask_merge(trans_t, trans_0, m[..., None])
+            trans_score = _mask_merge(trans_score, torch.zeros_like(trans_score), m[..., None])
+            rot_score = _mask_merge(rot_score, torch.zeros_like(rot_score), m[..., None])
+            seq_t = _mask_merge(seq_t, seq_0, m)
+        rs, ts = self.score_scaling(t)
+        return {'rigids_t': torch.cat([rotvec_to_quat(rot_t), trans_t], dim=-1), 'trans_score': trans_score,
+                'rot_score': rot_score, 'trans_score_scaling': ts, 'rot_score_scaling': rs, 'seq_t': seq_t}
 
     def sample_ref(self, n_samples, impute_rigids, impute_seq, diffuse_mask, noise=None):
         """full_diffuser.py:229-290; draw order randn(B,L,3), rand(B,L), randn(B,L,3), randint(B,L)."""

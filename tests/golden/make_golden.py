@@ -24,7 +24,6 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
 sys.path.insert(0, HERE)
-sys.path.insert(0, ROOT)
 import ref_shims  # noqa: E402
 
 ref_shims.install()
@@ -35,7 +34,6 @@ import torch  # noqa: E402
 
 torch.set_num_threads(8)
 from ref_shims import ConfigDict  # noqa: E402
-from abx_amd import synthetic  # noqa: E402
 
 cfg_json = json.load(open('/root/reference/config/config_model.json'))
 cfg_json['model']['embeddings_and_seqformer']['esm']['enabled'] = False
@@ -49,6 +47,12 @@ diffuser = FullDiffuser.get(cfg.diffuser)
 from abx.model.abx import ScoreNetwork, get_prev  # noqa: E402
 from abx.model.features import FeatureBuilder  # noqa: E402
 import inference as ref_inference  # noqa: E402
+
+# the repository root goes on the path only AFTER the reference's packages are in sys.modules: the repo ships alias packages
+# named `abx` and `diffuser` (drop-in import paths) that must not shadow the reference here
+sys.path.insert(0, ROOT)
+from abx_amd import synthetic  # noqa: E402
+assert ref_inference.__file__.startswith(ref_shims.REF) and sys.modules['diffuser.full_diffuser'].__file__.startswith(ref_shims.REF)
 
 SEED_W = 7
 model = ScoreNetwork(cfg.model, diffuser).eval()
@@ -303,6 +307,72 @@ tj['final.t'] = traj_cap['batch']['t']
 save('traj_tiny.npz', tj)
 
 # ---------------------------------------------------------------------------------------------------
+# 4b. optimize mode (BASELINE config 4): forward_marginal noising at t = opt_step/100 and the shortened reverse loop
+# ---------------------------------------------------------------------------------------------------
+OPT_STEP = 4
+feats_opt = []
+for fn, opts in feats:
+    opts = dict(opts)
+    if 'diffuse' in fn:
+        opts['diff_conf'] = dict(cfg_json['diffuser'], opt_step=OPT_STEP)
+    feats_opt.append((fn, opts))
+_orig_rand, _orig_normal = torch.rand, torch.normal
+_orig_cat_sample = torch.distributions.categorical.Categorical.sample
+fm_log = []
+
+
+def _rec(kind, fn):
+    def inner(*a, **k):
+        z = fn(*a, **k)
+        fm_log.append((kind, z.clone(), [x.clone() for x in a if torch.is_tensor(x)], {kk: vv.clone() for kk, vv in k.items() if torch.is_tensor(vv)}))
+        return z
+    return inner
+
+
+torch.randn, torch.rand, torch.normal = _rec('randn', _orig_randn), _rec('rand', _orig_rand), _rec('normal', _orig_normal)
+torch.distributions.categorical.Categorical.sample = _rec('cat', _orig_cat_sample)
+torch.manual_seed(777)
+try:
+    batch_opt = FeatureBuilder(feats_opt, is_training=False)(copy.deepcopy(raw))
+finally:
+    torch.randn, torch.rand, torch.normal = _orig_randn, _orig_rand, _orig_normal
+    torch.distributions.categorical.Categorical.sample = _orig_cat_sample
+kinds = [k for k, *_ in fm_log]
+assert kinds == ['randn', 'rand', 'normal', 'cat', 'cat', 'cat'], kinds
+nz = fm_log[2]
+mean, std = nz[3]['mean'], nz[3]['std']
+opt = {'noise.rot_axis': fm_log[0][1], 'noise.rot_u': fm_log[1][1], 'noise.trans_z': (nz[1] - mean) / std,
+       'noise.trans_xt': nz[1], 'noise.seq_xt': fm_log[3][1].view(B, L), 'noise.seq_dim': fm_log[4][1], 'noise.seq_new': fm_log[5][1]}
+for k in ('rigids_t', 'seq_t', 't', 'fixed_mask', 'rigids_0', 'rot_score', 'trans_score', 'rot_score_scaling', 'trans_score_scaling'):
+    opt['feat.' + k] = batch_opt[k]
+
+
+class ArgsOpt:
+    mode = 'optimize'
+    output_dir = '/tmp/abx_golden_scratch'
+
+
+noise_log.clear()
+traj_cap.clear()
+torch.randn, torch.poisson = log_randn, log_poisson
+torch.manual_seed(888)
+try:
+    ref_inference.sample_fn(copy.deepcopy(batch_opt), cfg, diffuser, model, ArgsOpt(), num_t=100)
+finally:
+    torch.randn, torch.poisson = _orig_randn, _orig_poisson
+nsteps = len(noise_log) // 3
+assert [k for k, _ in noise_log] == ['randn', 'randn', 'poisson'] * nsteps and nsteps == OPT_STEP - 1, (len(noise_log), nsteps)
+for s_ in range(nsteps):
+    opt[f'n{s_}.z_rot'] = noise_log[3 * s_][1]
+    opt[f'n{s_}.z_trans'] = noise_log[3 * s_ + 1][1]
+    opt[f'n{s_}.jumps'] = noise_log[3 * s_ + 2][1]
+assert len(traj_cap['traj']) == 1
+d = traj_cap['traj'][0]
+opt.update({'last.seq': d['seq'], 'last.atom14': d['atom14_results'], 'last.pLDDT': d['pLDDT'], 'last.time': np.float64(d['time']),
+            'final.rigids_t': traj_cap['batch']['rigids_t'], 'final.seq_t': traj_cap['batch']['seq_t']})
+save('optimize_tiny.npz', opt)
+
+# ---------------------------------------------------------------------------------------------------
 # 5. IGSO(3) tables
 # ---------------------------------------------------------------------------------------------------
 small_conf = dict(cfg_json['diffuser']['so3'], num_sigma=40, num_omega=40, cache_dir='/tmp/abx_golden_scratch/.cache_small/')
@@ -319,7 +389,7 @@ for k in ('_pdf', '_cdf', '_score_norms'):
     ig['sha256' + k] = np.frombuffer(hashlib.sha256(getattr(big, k).numpy().tobytes()).digest(), dtype=np.uint8)
 # rows of the big tables used by the tiny tests (t = 1.0, ~0.5, 0.02, 0.67, 0.34): full rows, so that the score
 # lookup can be checked without regenerating the 1000x1000 tables on CPU
-ts = torch.tensor([1.0, float(t_np), 0.02, 0.67, 0.34, 0.01], dtype=torch.float64)
+ts = torch.tensor([1.0, float(t_np), 0.02, 0.67, 0.34, 0.01, 0.04, 0.03], dtype=torch.float64)
 rows = sorted(set(big.t_to_idx(ts)))
 ig['rows'] = np.asarray(rows)
 ig['rows_score_norms'] = big._score_norms[rows]

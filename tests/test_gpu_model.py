@@ -241,3 +241,46 @@ def test_device_rng_sampling_is_shard_invariant(gpu_model, cfg):
     assert torch.equal(full['seq'], seq)
     assert torch.equal(full['atom14'], atoms)
     assert len(set(map(tuple, full['seq'].cpu().tolist()))) >= 1
+
+
+def test_init_features_match_reference_golden(gpu_model, cfg):
+    """Row I of SURVEY §8a on the device: the feature pipeline + FullDiffuser.sample_ref (design) and .forward_marginal
+    (optimize, incl. the x_tilde token jump) under the reference's recorded draws."""
+    from abx_amd import features
+    model, D = gpu_model
+    f = load_npz('feat_tiny.npz')
+    raw = {k[4:]: tt(v).to(DEV) for k, v in f.items() if k.startswith('raw.')}
+    noise = {k[6:]: tt(v).to(DEV) for k, v in f.items() if k.startswith('noise.')}
+    b = features.build_features(dict(raw), D, generate_area='H3', noise=noise)
+    assert torch.equal(b['seq_t'].cpu(), tt(f['feat.seq_t'])) and torch.equal(b['fixed_mask'].cpu(), tt(f['feat.fixed_mask']))
+    close(b['rigids_t'], f['feat.rigids_t'], 2e-5, 1e-6, 'design rigids_t')
+    close(b['torsion_angles_sin_cos'], f['feat.torsion_angles_sin_cos'], 2e-5, 0, 'torsions')   # torch-on-GPU vs CPU rounding of the feature pipeline
+    close(b['rigids_0'], f['feat.rigids_0'], 2e-5, 0, 'rigids_0')
+    g = load_npz('optimize_tiny.npz')
+    noise = {k[6:]: tt(v).to(DEV) for k, v in g.items() if k.startswith('noise.')}
+    b = features.build_features(dict(raw), D, generate_area='H3', opt_step=4, noise=noise)
+    assert torch.equal(b['seq_t'].cpu(), tt(g['feat.seq_t']))
+    close(b['t'], g['feat.t'], 0, 0, 't')
+    close(b['rigids_t'], g['feat.rigids_t'], 2e-5, 1e-6, 'optimize rigids_t')
+    close(b['trans_score'], g['feat.trans_score'], 2e-5, 1e-5, 'optimize trans_score')
+
+
+def test_optimize_mode_trajectory_matches_reference_golden(gpu_model, cfg):
+    """The reference's sample_fn(mode='optimize', opt_step=4): 4 grid points, HIP sampler under the recorded noise."""
+    from abx_amd import sampler
+    model, D = gpu_model
+    g = load_npz('optimize_tiny.npz')
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    for k in ('rigids_t', 'seq_t', 't', 'fixed_mask', 'rigids_0'):
+        b[k] = tt(g['feat.' + k])
+    b = to_dev(b)
+
+    def noise_fn(k):
+        return dict(z_rot=tt(g[f'n{k}.z_rot']).to(DEV), z_trans=tt(g[f'n{k}.z_trans']).to(DEV), jumps=tt(g[f'n{k}.jumps']).to(DEV))
+
+    traj = sampler.sample_fn(b, cfg, D, model, mode='optimize', num_t=100, noise_fn=noise_fn)
+    assert len(traj) == 1 and float(traj[0]['time']) == float(g['last.time'])
+    assert np.array_equal(traj[0]['seq'].cpu().numpy(), g['last.seq'])
+    close(traj[0]['atom14_results'], g['last.atom14'], 5e-3, 1e-4, 'optimize atom14')
+    close(traj[0]['pLDDT'], g['last.pLDDT'], 1e-2, 1e-4, 'optimize pLDDT')
+    close(traj[0]['rigids_t'], g['final.rigids_t'], 2e-3, 1e-4, 'optimize final rigids')

@@ -202,3 +202,28 @@ def test_short_trajectory_matches_reference(params, cfg, pinned_diffuser):
         close(d['atom14_results'], tj[f'k{k}.atom14'], 5e-3, 1e-4, f'step {k} atom14')
         close(d['pLDDT'], tj[f'k{k}.pLDDT'], 1e-2, 1e-4, f'step {k} pLDDT')
     close(traj[-1]['rigids_t'], tj['final.rigids_t'], 2e-3, 1e-4, 'final rigids')
+
+
+def test_optimize_mode_matches_reference(params, cfg, pinned_diffuser):
+    """BASELINE config 4 shape of the path: forward_marginal noising at t = opt_step/100 (incl. the x_tilde token jump) and the
+    shortened reverse loop of the reference's sample_fn(mode='optimize'), under the recorded draws."""
+    from abx_amd import features
+    g = load_npz('optimize_tiny.npz')
+    f = load_npz('feat_tiny.npz')
+    raw = {k[4:]: tt(v) for k, v in f.items() if k.startswith('raw.')}
+    noise = {k[6:]: tt(v) for k, v in g.items() if k.startswith('noise.')}
+    b = features.build_features(dict(raw), pinned_diffuser, generate_area='H3', opt_step=4, noise=noise)
+    assert torch.equal(b['seq_t'], tt(g['feat.seq_t'])) and torch.equal(b['fixed_mask'], tt(g['feat.fixed_mask']))
+    close(b['t'], g['feat.t'], 0, name='t')
+    close(b['rigids_t'], g['feat.rigids_t'], 2e-5, 1e-6, 'optimize rigids_t')
+    close(b['trans_score'], g['feat.trans_score'], 2e-5, 1e-5, 'optimize trans_score')
+    close(b['trans_score_scaling'], g['feat.trans_score_scaling'], 1e-6, 1e-6, 'trans score scaling')
+
+    def noise_fn(k):
+        return dict(z_rot=tt(g[f'n{k}.z_rot']), z_trans=tt(g[f'n{k}.z_trans']), jumps=tt(g[f'n{k}.jumps']))
+
+    traj = O.sample_fn(params, b, cfg, pinned_diffuser, mode='optimize', num_t=100, noise_fn=noise_fn)
+    assert len(traj) == 4 and float(traj[-1]['time']) == float(g['last.time'])
+    assert np.array_equal(traj[-1]['seq'].numpy(), g['last.seq'])
+    close(traj[-1]['atom14_results'], g['last.atom14'], 5e-3, 1e-4, 'optimize atom14')
+    close(traj[-1]['rigids_t'], g['final.rigids_t'], 2e-3, 1e-4, 'optimize final rigids')
