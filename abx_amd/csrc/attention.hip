@@ -2,8 +2,8 @@
 //
 // abx_tri_attn_fwd — triangle attention (reference abx/model/seqformer.py:506-550, Attention.forward :272-312) as a
 // flash-style fused kernel: the (B, L, 4, L, L) logits tensor (268 MB / sample at L = 256) is never materialised.
-// One workgroup per (b, row s, head h): K [L][48] and V [L][48] of that row are staged ONCE in LDS (padded strides 50 / 52
-// floats, conflict-free for the MFMA operand reads below); each of the 12 waves (3 per SIMD, so one wave's softmax VALU / LDS
+// One workgroup per (b, row s, head h): K [L][48] and V [L][48] of that row are staged ONCE in LDS (row stride 52 floats;
+// K rows permuted so a lane's 12 QK^T operands are three 16-byte reads); each of the 12 waves (3 per SIMD, so one wave's softmax VALU / LDS
 // latency hides under the others' MFMAs) walks query tiles of 16 rows with a base-2 online softmax over 64-key tiles; the pair bias of
 // a tile is fetched before its QK^T MFMAs.  Both contractions run on v_mfma_f32_16x16x4_f32 (exact fp32):
 //     S^T[key][q]  = sum_d K[key][d] * Q[q][d]        ("swapped" QK^T: a lane owns 4 keys of ONE query column, so the
@@ -13,13 +13,15 @@
 //
 // abx_seq_attn_fwd — sequence attention with 32-head pair bias (seqformer.py:314-356, split_first=False :278-281);
 // 0.8 % of the step, one thread per query with K/V of the (b, h) pair in LDS.
+#include <type_traits>
+
 #include "common.h"
 #include "abx_hip.h"
 
 namespace {
 
 constexpr int TD = 48;        // head dim of triangle attention
-constexpr int LDK = 50;       // K row stride in LDS (floats): (key*50 + d) mod 32 distinct over 16 keys x 2 d
+constexpr int LDK = 52;       // K rows are stored permuted [key][g][kd] (d = kd*4 + g): a lane's 12 operands are 3 x 16-byte reads
 constexpr int LDV = 52;       // V row stride: 4*52 mod 32 == 16 -> lane groups g land on disjoint bank halves
 
 constexpr int TRI_THREADS = 768;      // 12 waves = 3 per SIMD: softmax VALU / LDS latency of one wave hide under the others' MFMAs
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
         const long long off = base + (long long)key * a.sl + c4 * 4;
         const f32x4 kv = *reinterpret_cast<const f32x4*>(a.k + off);
         const f32x4 vv = *reinterpret_cast<const f32x4*>(a.v + off);
-        float* kd = Ks + key * LDK + c4 * 4;
-        kd[0] = kv[0]; kd[1] = kv[1]; kd[2] = kv[2]; kd[3] = kv[3];
+        float* kd = Ks + key * LDK + c4;                     // element d = c4*4 + j goes to [g = j][kd = c4]
+        kd[0] = kv[0]; kd[12] = kv[1]; kd[24] = kv[2]; kd[36] = kv[3];
         *reinterpret_cast<f32x4*>(Vs + key * LDV + c4 * 4) = vv;
     }
     // additive key mask for every key slot of the padded tiles: 0 (valid), finfo.min marker (masked), -inf (beyond L)
@@ -85,13 +87,17 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        for (int kt = 0; kt < nkt; ++kt) {
-            // ---- bias of this 64-key tile: issued first so the loads fly under the QK^T MFMAs
+        // one 64-key tile.  FAST: the tile lies fully inside [0, L) and no key is masked -> no clamps, no mask arithmetic,
+        // LDS addresses are a per-tile base plus compile-time offsets.
+        auto tile = [&](const int kt, auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const int k0 = kt * 64;
+            // ---- bias of this tile: issued first so the loads fly under the QK^T MFMAs
             float bz[4][4];
-            if (bias_vec && kt * 64 + 64 <= L) {                 // starting node: 4 consecutive keys per lane -> one 16-B load
+            if (bias_vec && (FAST || k0 + 64 <= L)) {            // 4 consecutive keys per lane -> one 16-B load
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + kt * 64 + sub * 16 + g * 4);
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + k0 + sub * 16 + g * 4);
                     bz[sub][0] = t4[0]; bz[sub][1] = t4[1]; bz[sub][2] = t4[2]; bz[sub][3] = t4[3];
                 }
             } else {
@@ -99,25 +105,30 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = min(kt * 64 + sub * 16 + g * 4 + r, L - 1);
+                        const int key = FAST ? k0 + sub * 16 + g * 4 + r : min(k0 + sub * 16 + g * 4 + r, L - 1);
                         bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
                     }
             }
             f32x4 sc[4];
             // ---- S^T tiles: 4 sub-blocks of 16 keys
+            const float* kbase = Ks + (k0 + lq) * LDK + g * 12;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                const int kb = kt * 64 + sub * 16;
-                const int krow = min(kb + lq, L - 1);
-                const float* kp = Ks + krow * LDK + g;
+                const f32x4* kp = reinterpret_cast<const f32x4*>(
+                    FAST ? kbase + sub * 16 * LDK : Ks + min(k0 + sub * 16 + lq, L - 1) * LDK + g * 12);
+                const f32x4 ka = kp[0], kb4 = kp[1], kc = kp[2];
                 f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kd = 0; kd < 12; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kd * 4], qf[kd], c0, 0, 0, 0);
+                for (int kd = 0; kd < 4; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kd], qf[kd], c0, 0, 0, 0);
+#pragma unroll
+                for (int kd = 0; kd < 4; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb4[kd], qf[4 + kd], c0, 0, 0, 0);
+#pragma unroll
+                for (int kd = 0; kd < 4; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[kd], qf[8 + kd], c0, 0, 0, 0);
                 sc[sub] = c0;
             }
-            // this lane: keys kb + g*4 + r (r = 0..3) of query column lq
+            // this lane: keys k0 + sub*16 + g*4 + r (r = 0..3) of query column lq
             float mx = -INFINITY;
-            if (!has_mask && kt * 64 + 64 <= L) {              // common case: full tile, nothing masked
+            if (FAST) {
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
             } else {
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + kt * 64 + sub * 16 + g * 4);
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
@@ -163,20 +174,23 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
             }
-            // ---- O^T += V^T P : MFMA step (sub, r) contracts keys {kb + g*4 + r : g = 0..3}
+            // ---- O^T += V^T P : MFMA step (sub, r) contracts keys {k0 + sub*16 + g*4 + r : g = 0..3}
+            const float* vbase = Vs + (k0 + g * 4) * LDV + lq;
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                const int kb = kt * 64 + sub * 16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = min(kb + g * 4 + r, L - 1);    // p == 0 for keys >= L
-                    const float* vp = Vs + key * LDV + lq;
+                    const float* vp = FAST ? vbase + (sub * 16 + r) * LDV
+                                           : Vs + min(k0 + sub * 16 + g * 4 + r, L - 1) * LDV + lq;   // p == 0 for keys >= L
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[d * 16], sc[sub][r], o[d], 0, 0, 0);
                 }
             }
-        }
+        };
+        const int nfast = has_mask ? 0 : L / 64;
+        for (int kt = 0; kt < nfast; ++kt) tile(kt, std::true_type{});
+        for (int kt = nfast; kt < nkt; ++kt) tile(kt, std::false_type{});
         // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
         if (qok) {
             const float inv = 1.0f / l_run;
@@ -266,7 +280,7 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
-    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout (L <= 397)");
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout (L <= 389)");
     static thread_local size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_attn_kernel),
