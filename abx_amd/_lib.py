@@ -31,9 +31,9 @@ class AbxGemm(C.Structure):
         ('rowscale', c_f), ('sRSb', LL),
         ('gate', c_f), ('sGb', LL), ('sGm', LL), ('gate_sigmoid', I),
         ('resid', c_f), ('sRb', LL), ('sRm', LL),
-        ('stats_out', c_f), ('sSOb', LL), ('stats_eps', F),
         ('tune', I),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
+        ('c_vec_ok', I), ('g_vec_ok', I), ('r_vec_ok', I), ('rs_vec_ok', I),
     ]
 
 

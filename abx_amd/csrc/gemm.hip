@@ -214,10 +214,8 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // LDS is free now: stage the LayerNorm row statistics of this M-panel; transposed store: per-wave 32x33 scratch;
-    // stats_out: per-row partial sums of the two wave columns.
+    // LDS is free now: stage the LayerNorm row statistics of this M-panel, then the per-wave store scratch behind them
     float* st_lds = smem;                                   // [BM][2]
-    float* part = smem + 2 * BM;                             // [BM][WAVES_N][2] (plain store) | transposed-store scratch
     const float* gstats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
     const bool stats = gstats != nullptr || ln_inline;
     if (gstats) {
@@ -272,120 +270,135 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
     const float* rs = g.rowscale ? g.rowscale + (long long)b * g.sRSb : nullptr;
     const float* gt = g.gate ? g.gate + (long long)b * g.sGb : nullptr;
     const float* rd = g.resid ? g.resid + (long long)b * g.sRb : nullptr;
+    const bool c_vec = g.c_vec_ok != 0, g_vec = g.g_vec_ok != 0, r_vec = g.r_vec_ok != 0, gsig = g.gate_sigmoid != 0;
     float bias[TN], csum[TN];
-    bool nok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        nok[j] = !EDGE || n < g.N;
-        bias[j] = (g.bias && nok[j]) ? g.bias[n] : 0.f;
-        csum[j] = (stats && nok[j]) ? g.ln_csum[n] : 0.f;   // stats: bool
+        const bool nok = !EDGE || n < g.N;
+        bias[j] = (g.bias && nok) ? g.bias[n] : 0.f;
+        csum[j] = (stats && nok) ? g.ln_csum[n] : 0.f;
     }
-    auto epi = [&](float v, int ml, int m, int n, int j, bool ok) -> float {
+    // per-element part that needs no global operand: folded LayerNorm, bias, alpha, activation
+    auto epi1 = [&](float v, int ml, int j) -> float {
         if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
         v = (v + bias[j]) * g.alpha;
         if (g.act == 1) v = fmaxf(v, 0.f);
         else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-        if (ok) {
-            if (rs) v *= rs[m];
-            if (gt) {
-                const float gv = gt[(long long)m * g.sGm + n];
-                v *= g.gate_sigmoid ? 1.0f / (1.0f + expf(-gv)) : gv;
-            }
-            if (rd) v += rd[(long long)m * g.sRm + n];
-        }
         return v;
     };
+    // 4 consecutive elements along the contiguous output dimension: gate / residual reads and the store are 16-byte accesses
+    // when the operand allows it (cnt < 4: ragged tail)
+    auto load4 = [&](const float* p, bool vec, int cnt) -> f32x4 {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (vec && cnt == 4) r = *reinterpret_cast<const f32x4*>(p);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < cnt) r[c] = p[c];
+        }
+        return r;
+    };
+    auto epi2_store = [&](f32x4 v, long long off_c, long long off_g, long long off_r, int cnt) {
+        if (gt) {
+            f32x4 gv = load4(gt + off_g, g_vec, cnt);
+            if (gsig) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gv[c] = 1.0f / (1.0f + expf(-gv[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= gv[c];
+        }
+        if (rd) {
+            const f32x4 rv = load4(rd + off_r, r_vec, cnt);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += rv[c];
+        }
+        if (c_vec && cnt == 4) *reinterpret_cast<f32x4*>(Cb + off_c) = v;
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < cnt) Cb[off_c + c] = v[c];
+        }
+    };
     if constexpr (!TS) {
-        const bool want_stats = g.stats_out != nullptr;
+        // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][WN + 4] and leaves as float4 along n
+        constexpr int LW = WN + 4, C4 = WN / 4, NQ = 32 * C4 / 64;
+        float* wsc = smem + 2 * BM + wave * (32 * LW);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int ml = wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5) + c;
-                    const int m = m0 + ml;
-                    const bool mok = !EDGE || m < g.M;
-                    float sum = 0.f, sq = 0.f;
+                    const int mloc = 8 * rq + 4 * (lane >> 5) + c;
+                    const int ml = wm * WM + i * 32 + mloc;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-                        const bool ok = nok[j] && mok;
-                        const float v = epi(acc[i][j][rq * 4 + c], ml, m, n, j, ok);
-                        if (ok) {
-                            Cb[(long long)m * g.sCm + n] = v;
-                            sum += v;
-                            sq = fmaf(v, v, sq);
-                        }
-                    }
-                    if (want_stats) {
-                        // row statistics of the values just written (the next LayerNorm's input), fixed reduction order
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) {
-                            sum += __shfl_xor(sum, o, 64);
-                            sq += __shfl_xor(sq, o, 64);
-                        }
-                        if ((lane & 31) == 0) {
-                            part[(ml * WAVES_N + wn) * 2] = sum;
-                            part[(ml * WAVES_N + wn) * 2 + 1] = sq;
-                        }
-                    }
-                }
-            }
-        }
-        if (want_stats) {
-            __syncthreads();
-            for (int r = threadIdx.x; r < BM; r += 256) {
-                const int m = m0 + r;
-                if (EDGE && m >= g.M) continue;
-                float sum = 0.f, sq = 0.f;
-#pragma unroll
-                for (int w = 0; w < WAVES_N; ++w) {
-                    sum += part[(r * WAVES_N + w) * 2];
-                    sq += part[(r * WAVES_N + w) * 2 + 1];
-                }
-                const float inv = 1.0f / (float)g.N;
-                const float mean = sum * inv;
-                const float var = fmaxf(sq * inv - mean * mean, 0.f);
-                float* so = g.stats_out + 2 * ((long long)b * g.sSOb + m);
-                so[0] = mean;
-                so[1] = 1.0f / sqrtf(var + g.stats_eps);
-            }
-        }
-    } else {
-        // transposed store: per 32-row band i, all TN sub-tiles go through the wave's LDS scratch [j][n_local][m_local] and
-        // are written out as rows of 32 consecutive m (128-byte segments) per n
-        float* sc = smem + 2 * BM + wave * (TN * 32 * 33);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int ml = wm * WM + i * 32 + 8 * rq + 4 * (lane >> 5) + c;
-                    const int m = m0 + ml;
-                    const bool mok = !EDGE || m < g.M;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-                        const float v = epi(acc[i][j][rq * 4 + c], ml, m, n, j, nok[j] && mok);
-                        sc[j * (32 * 33) + (lane & 31) * 33 + 8 * rq + 4 * (lane >> 5) + c] = v;
-                    }
+                    for (int j = 0; j < TN; ++j) wsc[mloc * LW + j * 32 + (lane & 31)] = epi1(acc[i][j][rq * 4 + c], ml, j);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int mloc = lane & 31;
-            const int mg = m0 + wm * WM + i * 32 + mloc;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const int nloc = rr * 2 + (lane >> 5);
-                    const int ng = n0 + wn * WN + j * 32 + nloc;
-                    if (!EDGE || (ng < g.N && mg < g.M)) Cb[(long long)ng * g.sCm + mg] = sc[j * (32 * 33) + nloc * 33 + mloc];
+            for (int q = 0; q < NQ; ++q) {
+                const int f = lane + 64 * q;
+                const int row = f / C4, c4 = f % C4;
+                const int m = m0 + wm * WM + i * 32 + row;
+                const int n = n0 + wn * WN + c4 * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[row * LW + c4 * 4]);
+                int cnt = 4;
+                if (EDGE) {
+                    if (m >= g.M || n >= g.N) continue;
+                    cnt = min(4, g.N - n);
                 }
+                if (rs) {
+                    const float s = rs[m];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] *= s;
+                }
+                epi2_store(v, (long long)m * g.sCm + n, (long long)m * g.sGm + n, (long long)m * g.sRm + n, cnt);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        // transposed store (C, gate and resid are all addressed [n][m], m contiguous): each 32-column sub-tile goes through the
+        // wave's LDS scratch [32 n][WM + 4] (the 4 accumulator rows of a register quad are contiguous there) and leaves as
+        // float4 along m: WM * 4 contiguous bytes per output row
+        constexpr int LWT = WM + 4, M4 = WM / 4, NQ = 32 * M4 / 64;
+        float* wsc = smem + 2 * BM + wave * (32 * LWT);
+        const bool rs_vec = g.rs_vec_ok != 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int mloc = i * 32 + 8 * rq + 4 * (lane >> 5);
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = epi1(acc[i][j][rq * 4 + c], wm * WM + mloc + c, j);
+                    *reinterpret_cast<f32x4*>(&wsc[(lane & 31) * LWT + mloc]) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int f = lane + 64 * q;
+                const int nl = f / M4, m4 = f % M4;
+                const int n = n0 + wn * WN + j * 32 + nl;
+                const int m = m0 + wm * WM + m4 * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[nl * LWT + m4 * 4]);
+                int cnt = 4;
+                if (EDGE) {
+                    if (m >= g.M || n >= g.N) continue;
+                    cnt = min(4, g.M - m);
+                }
+                if (rs) {
+                    const f32x4 s = load4(rs + m, rs_vec, cnt);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] *= s[c];
+                }
+                epi2_store(v, (long long)n * g.sCm + m, (long long)n * g.sGm + m, (long long)n * g.sRm + m, cnt);
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -397,7 +410,9 @@ template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool TS, i
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(const AbxGemm g) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int OPER = 2 * BK * LDA + 2 * BK * LDB;
-    constexpr int EPI = 2 * BM + (TS ? 4 * (WN / 32) * 32 * 33 : (AKC ? 4 * BM : (256 / (BM / 4)) * BM * 2));
+    constexpr int SCR = 4 * 32 * ((TS ? WM : WN) + 4);                         // per-wave store scratch (4 waves)
+    constexpr int RED = AKC ? 0 : (256 / (BM / 4)) * BM * 2;                     // inline-LN reduction of m-contiguous A
+    constexpr int EPI = 2 * BM + (SCR > RED ? SCR : RED);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntn = (g.N + BN - 1) / BN;
     // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs): give each XCD a contiguous range of tiles so the
@@ -521,16 +536,17 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(!g.ln_stats || g.ln_csum, "abx_gemm: LayerNorm needs the column sums of the gamma-scaled weights");
     ABX_REQUIRE(!(g.ln_csum && g.a_relu), "abx_gemm: LayerNorm and relu-on-load are exclusive");
     if (g.ln_csum && !g.ln_stats && g.ln_eps <= 0.f) g.ln_eps = 1e-5f;
-    ABX_REQUIRE(!g.stats_out || (g.N <= 192 && !g.c_transposed), "abx_gemm: stats_out needs N <= 192 (one tile per row) and a plain store");
     const bool akc = g.sAk == 1;
     // 16-byte vector loads need aligned bases and strides that are multiples of 4 elements
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     g.a_vec_ok = al16(g.A) && (g.sAb % 4 == 0) && (akc ? (g.sAm % 4 == 0) : (g.sAk % 4 == 0));
     g.b_vec_ok = al16(g.B) && (g.sBb % 4 == 0) && (g.sBn == 1 ? (g.sBk % 4 == 0) : (g.sBn % 4 == 0));
     g.fast_ok = g.a_vec_ok && g.b_vec_ok;
+    g.c_vec_ok = al16(g.C) && (g.sCb % 4 == 0) && (g.sCm % 4 == 0);
+    g.g_vec_ok = g.gate && al16(g.gate) && (g.sGb % 4 == 0) && (g.sGm % 4 == 0);
+    g.r_vec_ok = g.resid && al16(g.resid) && (g.sRb % 4 == 0) && (g.sRm % 4 == 0);
+    g.rs_vec_ok = g.rowscale && al16(g.rowscale) && (g.sRSb % 4 == 0);
     const long long mt128 = ((long long)g.M + 127) / 128;
-    if (g.stats_out && g.N > 128) return launch_cfg<128, 192, 64, 96, 16, 2>(g, st);
-    if (g.stats_out && g.N > 64) return launch_cfg<128, 128, 64, 64>(g, st);
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);
     if (mt128 * (((long long)g.N + 127) / 128) * g.batch < 512) return launch_cfg<64, 64, 32, 32>(g, st);

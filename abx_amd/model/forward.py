@@ -51,7 +51,7 @@ class Packed:
                     'embed.weight', 'proj_aa_type', 'proj_rel_pos', 'proj_prev_pos', 'aapair_to_distcoef')):
                 lin(name[:-7])
         for tm in ('triangle_multiplication_outgoing', 'triangle_multiplication_incoming'):
-            fused(P_BLK + tm + '.gates', [P_BLK + tm + s for s in ('.left_gate', '.right_gate', '.final_gate')])
+            fused(P_BLK + tm + '.lr_gates', [P_BLK + tm + s for s in ('.left_gate', '.right_gate')])
         for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
             fused(P_BLK + ta + '.qkvg', [P_BLK + ta + s for s in ('.attn.proj_q', '.attn.proj_k', '.attn.proj_v', '.attn.gate')])
         fused(P_BLK + 'outer_product_mean.lr', [P_BLK + 'outer_product_mean.left_proj', P_BLK + 'outer_product_mean.right_proj'])
@@ -256,15 +256,18 @@ class Engine:
         # ---------------- triangle multiplication (seqformer.py:443-504)
         for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
             pre = P_BLK + name + '.'
-            G = w768[:, :448]
-            _ln_lin(P, pre + 'gates', pre + 'norm', None, z2, G)
+            # sigmoid(left_gate | right_gate) channel-major like the projections they gate; sigmoid(final_gate) row-major
+            GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
+            Gf = w768.view(-1)[Bc * 256 * LL:Bc * 448 * LL].view(Bc, LL, 192)
+            _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2)
+            _ln_lin(P, pre + 'final_gate', pre + 'norm', None, z3, Gf, act=2)
             left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
             right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
             tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
-            G3 = w768.view(Bc, LL, 768)
-            _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, left.transpose(1, 2), rowscale=pmask, gate=G3[:, :, 0:128])
+            _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, left.transpose(1, 2), rowscale=pmask,
+                    gate=GT[:, 0:128].transpose(1, 2), gate_sigmoid=False)
             _ln_lin(P, pre + 'right_proj', pre + 'norm', None, z3, right.transpose(1, 2), rowscale=pmask,
-                    gate=G3[:, :, 128:256])
+                    gate=GT[:, 128:256].transpose(1, 2), gate_sigmoid=False)
             lz = left.view(Bc * 128, L, L)
             rz = right.view(Bc * 128, L, L)
             tz = tt.view(Bc * 128, L, L)
@@ -273,7 +276,7 @@ class Engine:
             else:             # 'bkic,bkjc->bijc'
                 ops.gemm(lz.transpose(1, 2), rz, tz)
             tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
-            _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=G3[:, :, 256:448], resid=z3)
+            _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=Gf, gate_sigmoid=False, resid=z3)
         # ---------------- triangle attention (seqformer.py:506-550)
         for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
             pre = P_BLK + name + '.'

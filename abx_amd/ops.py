@@ -27,14 +27,10 @@ def _f32(t):
 GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 
 
-def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False, stats_out=False):
+def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False):
     """Name of the gemm_kernel<...> instantiation abx_gemm launches for a problem (mirror of the selection in
     csrc/gemm.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
-    if stats_out and N > 128:
-        cfg = (128, 192, 64, 96, 2)
-    elif stats_out and N > 64:
-        cfg = (128, 128, 64, 64, 3)
-    elif N <= 32:
+    if N <= 32:
         cfg = (128, 32, 32, 32, 3)
     elif N <= 64:
         cfg = (128, 64, 32, 64, 3)
@@ -49,10 +45,11 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, stats_out=None, tune=None):
+         resid=None, tune=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
-    stride is 1) stored transposed.  ln = (stats (rows,2), gamma, beta).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N)."""
+    stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
+    tensors laid out like Cout (n-contiguous, or m-contiguous when Cout is stored transposed)."""
     lib = _lib.load()
     if A.dim() == 2:
         A = A.unsqueeze(0)
@@ -94,16 +91,15 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     if gate is not None:
         if gate.dim() == 2:
             gate = gate.unsqueeze(0)
-        assert gate.shape == (nb, M, N) and gate.stride(2) == 1
-        g.gate, g.sGb, g.sGm, g.gate_sigmoid = _p(_f32(gate)), (gate.stride(0) if nb > 1 else 0), gate.stride(1), int(gate_sigmoid)
+        cd, sd = (1, 2) if g.c_transposed else (2, 1)
+        assert gate.shape == (nb, M, N) and gate.stride(cd) == 1, 'gate must be laid out like Cout'
+        g.gate, g.sGb, g.sGm, g.gate_sigmoid = _p(_f32(gate)), (gate.stride(0) if nb > 1 else 0), gate.stride(sd), int(gate_sigmoid)
     if resid is not None:
         if resid.dim() == 2:
             resid = resid.unsqueeze(0)
-        assert resid.shape == (nb, M, N) and resid.stride(2) == 1
-        g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(1)
-    if stats_out is not None:
-        assert stats_out.numel() == 2 * nb * M and stats_out.is_contiguous()
-        g.stats_out, g.sSOb, g.stats_eps = _p(_f32(stats_out)), M, 1e-5
+        cd, sd = (1, 2) if g.c_transposed else (2, 1)
+        assert resid.shape == (nb, M, N) and resid.stride(cd) == 1, 'resid must be laid out like Cout'
+        g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(sd)
     check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
     return Cout
 

@@ -53,8 +53,7 @@ class OpTimer:
             nb = A.shape[0] if A.dim() == 3 else 1
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
-            kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, C.stride(-1) != 1,
-                                             kw.get('stats_out') is not None)
+            kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, C.stride(-1) != 1)
             return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K + M * N) + 4.0 * K * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]

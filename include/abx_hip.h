@@ -57,11 +57,11 @@ typedef struct AbxGemm {
     float alpha;                                   /* use 1.0f for none */
     int act;                                       /* 0 none, 1 relu, 2 sigmoid */
     const float* rowscale; long long sRSb;         /* [b*sRSb + m] or NULL */
-    const float* gate; long long sGb, sGm; int gate_sigmoid;
-    const float* resid; long long sRb, sRm;        /* may alias C */
-    float* stats_out; long long sSOb; float stats_eps;   /* optional: (mean, rstd) of the OUTPUT rows (N <= 192), row b*sSOb + m */
+    const float* gate; long long sGb, sGm; int gate_sigmoid;   /* addressed like C: (m,n) at gate + b*sGb + m*sGm + n, or */
+    const float* resid; long long sRb, sRm;        /* + n*sGm + m when c_transposed; resid likewise and may alias C */
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
     int a_vec_ok, b_vec_ok, fast_ok;               /* filled by the library */
+    int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
 

@@ -87,15 +87,18 @@ def test_gemm_ln_gate_resid_rowscale(ops):
     ops.gemm(Aoff, Wt, outo, bias=bias2, ln=(None, csum))
     refo = torch.nn.functional.layer_norm((A.double() * 0.05 + 300.0).float().double(), (K,), ga.double(), be.double(), 1e-5) @ W.double().t() + b.double()
     check(outo, refo, 2e-5, 'gemm inline-LN with mean >> std')
-    # fused statistics of the output rows (N <= 192): the next LayerNorm's (mean, rstd)
-    for Nn in (192, 128):
-        out = torch.empty(M, Nn, device=DEV)
-        so = torch.full((M, 2), float('nan'), device=DEV)
-        ops.gemm(Ad, W.t().contiguous().to(DEV)[:, :Nn].contiguous(), out, bias=b.to(DEV)[:Nn].contiguous(), resid=res.to(DEV)[:, :Nn], stats_out=so)
-        r2 = A.double() @ W.double().t()[:, :Nn] + b.double()[:Nn] + res.double()[:, :Nn]
-        check(out, r2, 3e-6, f'gemm stats_out values N={Nn}')
-        check(so[:, 0], r2.mean(-1), 3e-6, f'gemm stats_out mean N={Nn}')
-        check(so[:, 1], 1 / torch.sqrt(r2.var(-1, unbiased=False) + 1e-5), 3e-6, f'gemm stats_out rstd N={Nn}')
+    # ragged / unaligned epilogue operands: N not a multiple of 4, gate and resid views that start off a 16-byte boundary
+    for Nn, Mm in ((190, 300), (67, 130), (129, 257)):
+        gate_u = torch.randn(Mm, Nn + 3, generator=g(90))[:, 1:1 + Nn]
+        res_u = torch.randn(Mm, Nn + 1, generator=g(91))[:, 1:]
+        outb = torch.full((Mm, Nn + 5), float('nan'), device=DEV)
+        out = outb[:, 3:3 + Nn]
+        Wn = W[:Nn] if Nn <= N else torch.randn(Nn, K, generator=g(92)) / K ** 0.5
+        An = torch.randn(Mm, K, generator=g(93))
+        ops.gemm(An.to(DEV), Wn.t().contiguous().to(DEV), out, gate=gate_u.to(DEV), resid=res_u.to(DEV), gate_sigmoid=False)
+        r2 = (An.double() @ Wn.double().t()) * gate_u.double() + res_u.double()
+        check(out, r2, 3e-6, f'gemm unaligned gate/resid/out N={Nn}')
+        assert torch.isnan(outb[:, :3]).all() and torch.isnan(outb[:, 3 + Nn:]).all(), 'store outside the output view'
     # materialised layernorm, in place and with residual
     x = A.to(DEV).clone()
     ops.layernorm(x, ga.to(DEV), be.to(DEV), out=x)
@@ -132,13 +135,23 @@ def test_gemm_layouts_batched_transposed(ops):
     stats = ops.row_stats(Zd.view(B * LL, C))
     outT = torch.full((B, Cout, LL), float('nan'), device=DEV)
     Wt, csum, bias2 = fold_ln(W, bias, ga, be)
-    ops.gemm(Zd, Wt, outT.transpose(1, 2), bias=bias2, ln=(stats, csum), rowscale=pm.to(DEV), gate=G.to(DEV)[:, :, 128:256])
+    GT = G.to(DEV).transpose(1, 2).contiguous()                 # channel-major gates, like the transposed output
+    gview = GT[:, 128:256].transpose(1, 2)
+    ops.gemm(Zd, Wt, outT.transpose(1, 2), bias=bias2, ln=(stats, csum), rowscale=pm.to(DEV), gate=gview)
     ln = torch.nn.functional.layer_norm(Z.double(), (C,), ga.double(), be.double(), 1e-5)
     ref = (ln @ W.double().t() + bias.double()) * pm.double().view(B, LL, 1) * torch.sigmoid(G[:, :, 128:256].double())
     check(outT, ref.transpose(1, 2), 3e-6, 'transposed store')
     outT.fill_(float('nan'))
-    ops.gemm(Zd, Wt, outT.transpose(1, 2), bias=bias2, ln=(None, csum), rowscale=pm.to(DEV), gate=G.to(DEV)[:, :, 128:256])
+    ops.gemm(Zd, Wt, outT.transpose(1, 2), bias=bias2, ln=(None, csum), rowscale=pm.to(DEV), gate=gview)
     check(outT, ref.transpose(1, 2), 3e-6, 'transposed store, inline LN')
+    # ragged transposed store (M = 37*37 not a multiple of 4, odd N) with a transposed residual, sigmoid at the producer
+    B2, LL2, N2 = 2, 37 * 37, 45
+    Z2 = torch.randn(B2, LL2, C, generator=g(94))
+    W2 = torch.randn(N2, C, generator=g(95)) / C ** 0.5
+    R2 = torch.randn(B2, N2, LL2, generator=g(96))
+    o2 = torch.full((B2, N2, LL2), float('nan'), device=DEV)
+    ops.gemm(Z2.to(DEV), W2.t().contiguous().to(DEV), o2.transpose(1, 2), act=2, resid=R2.to(DEV).transpose(1, 2))
+    check(o2, (torch.sigmoid(Z2.double() @ W2.double().t()) + R2.double().transpose(1, 2)).transpose(1, 2), 3e-6, 'ragged transposed store')
     # channel-major A (m-contiguous) with channel-major LN stats, back to channel-last with residual
     T = torch.randn(B, Cout, LL, generator=g(23))
     Td = T.to(DEV)

@@ -106,6 +106,43 @@ def main():
                     kw['ln'] = (stats, csum)
                 ms = timeit(lambda: ops.gemm(A, W, C, **kw))
                 rec(f'gemm {N}x{K} tune={tune} (noremap={tune & 1}, variant={tune >> 1})', ms, 2.0 * M2 * N * K)
+    if only and 'tm' in only:
+        z = r(M2, 192); z3 = z.view(Bc, LL, 192)
+        G = r(Bc, LL, 448)
+        left = r(Bc, 128, LL)
+        tcm = left.transpose(1, 2)
+        W2 = r(128, 192) / 11
+        b2, c2 = r(192), r(192)
+        out3 = torch.empty(Bc, LL, 192, device=DEV)
+        fl = 2.0 * M2 * 192 * 128
+        rec('cm-A plain (no LN/gate/resid), out separate', timeit(lambda: ops.gemm(tcm, W2, out3, bias=b2)), fl)
+        rec('cm-A + inline LN', timeit(lambda: ops.gemm(tcm, W2, out3, bias=b2, ln=(None, c2))), fl)
+        rec('cm-A + LN + gate', timeit(lambda: ops.gemm(tcm, W2, out3, bias=b2, ln=(None, c2), gate=G[:, :, 256:448])), fl)
+        rec('cm-A + LN + gate + resid(in place)', timeit(lambda: ops.gemm(tcm, W2, z3, bias=b2, ln=(None, c2), gate=G[:, :, 256:448], resid=z3)), fl)
+        a_kc = r(Bc, LL, 128)
+        rec('kc-A plain same shape', timeit(lambda: ops.gemm(a_kc, W2, out3, bias=b2)), fl)
+        rec('kc-A + LN + gate + resid', timeit(lambda: ops.gemm(a_kc, W2, z3, bias=b2, ln=(None, c2), gate=G[:, :, 256:448], resid=z3)), fl)
+        W = r(192, 128) / 14
+        bias, csum = r(128), r(128)
+        pm = torch.ones(M2, device=DEV)
+        fl = 2.0 * M2 * 128 * 192
+        outn = torch.empty(Bc, LL, 128, device=DEV)
+        rec('proj normal store plain', timeit(lambda: ops.gemm(z3, W, outn, bias=bias)), fl)
+        rec('proj normal store + LN + gate + mask', timeit(lambda: ops.gemm(z3, W, outn, bias=bias, ln=(None, csum), rowscale=pm, gate=G[:, :, :128])), fl)
+        rec('proj T-store plain', timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias)), fl)
+        rec('proj T-store + LN', timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(None, csum))), fl)
+        GT = r(Bc, 256, LL)
+        rec('proj T-store + LN + T-gate(sigmoid) + mask', timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(None, csum), rowscale=pm, gate=GT[:, :128].transpose(1, 2))), fl)
+        rec('proj T-store + LN + T-gate(plain) + mask', timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(None, csum), rowscale=pm, gate=GT[:, :128].transpose(1, 2), gate_sigmoid=False)), fl)
+        W3 = r(192, 256) / 14
+        b3, c3 = r(256), r(256)
+        rec('lr_gates N=256 T-store + LN + sigmoid', timeit(lambda: ops.gemm(z3, W3, GT.transpose(1, 2), bias=b3, ln=(None, c3), act=2)), 2.0 * M2 * 256 * 192)
+        W4 = r(192, 192) / 14
+        rec('final_gate N=192 + LN + sigmoid', timeit(lambda: ops.gemm(z3, W4, out3, bias=b2, ln=(None, c2), act=2)), 2.0 * M2 * 192 * 192)
+        W5 = r(192, 448) / 14
+        b5, c5 = r(448), r(448)
+        G2 = G.view(M2, 448)
+        rec('old fused gates N=448 + LN', timeit(lambda: ops.gemm(z, W5, G2, bias=b5, ln=(None, c5))), 2.0 * M2 * 448 * 192)
     if not only or 'tri' in only:
         x = r(M2, 768)
         bT = r(Bc, 4, LL)
