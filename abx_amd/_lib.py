@@ -31,6 +31,11 @@ class AbxGemm(C.Structure):
         ('rowscale', c_f), ('sRSb', LL),
         ('gate', c_f), ('sGb', LL), ('sGm', LL), ('gate_sigmoid', I),
         ('resid', c_f), ('sRb', LL), ('sRm', LL),
+        ('B_split', C.c_void_p), ('sB3p', LL), ('sB3n', LL), ('sB3k', LL), ('sB3b', LL),
+        ('A_split', C.c_void_p), ('sA3p', LL), ('sA3m', LL), ('sA3k', LL), ('sA3b', LL),
+        ('C_split', C.c_void_p), ('sCp', LL), ('sCk', LL), ('c_split_L', I),
+        ('a_pair_transpose', I),
+        ('exact', I),
         ('tune', I),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
         ('c_vec_ok', I), ('g_vec_ok', I), ('r_vec_ok', I), ('rs_vec_ok', I),
@@ -85,6 +90,7 @@ _PROTOS = {
     'abx_last_error_string': (C.c_char_p, []),
     'abx_init': (I, [I]),
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
+    'abx_split_weights': (I, [c_f, LL, LL, I, I, C.c_void_p, _S]),
     'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),
     'abx_layernorm': (I, [c_f, LL, LL, I, c_f, c_f, F, c_f, LL, c_f, LL, _S]),
     'abx_tri_attn_fwd': (I, [C.POINTER(AbxTriAttn), _S]),

@@ -21,6 +21,25 @@ int abx_check_launch(const char* what);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// two fp32 -> three packed bf16 pairs (lo half = first element) with a + b = p0 + p1 + p2 exactly: round-to-nearest-even
+// pieces (v_cvt_pk_bf16_f32), the subtractions are exact.  The operand image of the split-bf16 GEMM kernels (gemm3.hip).
+__device__ __forceinline__ void split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    f32x2 x = {a, b};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    f32x2 x0 = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
+    f32x2 r = x - x0;
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    f32x2 x1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    f32x2 r2 = r - x1;
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

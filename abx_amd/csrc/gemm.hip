@@ -22,6 +22,9 @@
 // Block ids are remapped so that the N-tiles of one M-panel run on the same XCD (private L2) back to back.
 #include "common.h"
 #include "abx_hip.h"
+#include "gemm_epilogue.h"
+
+int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc);     // gemm3.hip
 
 namespace {
 
@@ -266,144 +269,7 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
             __syncthreads();
         }
     }
-    float* Cb = g.C + (long long)b * g.sCb;
-    const float* rs = g.rowscale ? g.rowscale + (long long)b * g.sRSb : nullptr;
-    const float* gt = g.gate ? g.gate + (long long)b * g.sGb : nullptr;
-    const float* rd = g.resid ? g.resid + (long long)b * g.sRb : nullptr;
-    const bool c_vec = g.c_vec_ok != 0, g_vec = g.g_vec_ok != 0, r_vec = g.r_vec_ok != 0, gsig = g.gate_sigmoid != 0;
-    float bias[TN], csum[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        const bool nok = !EDGE || n < g.N;
-        bias[j] = (g.bias && nok) ? g.bias[n] : 0.f;
-        csum[j] = (stats && nok) ? g.ln_csum[n] : 0.f;
-    }
-    // per-element part that needs no global operand: folded LayerNorm, bias, alpha, activation
-    auto epi1 = [&](float v, int ml, int j) -> float {
-        if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
-        v = (v + bias[j]) * g.alpha;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
-        return v;
-    };
-    // 4 consecutive elements along the contiguous output dimension: gate / residual reads and the store are 16-byte accesses
-    // when the operand allows it (cnt < 4: ragged tail)
-    auto load4 = [&](const float* p, bool vec, int cnt) -> f32x4 {
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
-        if (vec && cnt == 4) r = *reinterpret_cast<const f32x4*>(p);
-        else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (c < cnt) r[c] = p[c];
-        }
-        return r;
-    };
-    auto epi2_store = [&](f32x4 v, long long off_c, long long off_g, long long off_r, int cnt) {
-        if (gt) {
-            f32x4 gv = load4(gt + off_g, g_vec, cnt);
-            if (gsig) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) gv[c] = 1.0f / (1.0f + expf(-gv[c]));
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] *= gv[c];
-        }
-        if (rd) {
-            const f32x4 rv = load4(rd + off_r, r_vec, cnt);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += rv[c];
-        }
-        if (c_vec && cnt == 4) *reinterpret_cast<f32x4*>(Cb + off_c) = v;
-        else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (c < cnt) Cb[off_c + c] = v[c];
-        }
-    };
-    if constexpr (!TS) {
-        // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][WN + 4] and leaves as float4 along n
-        constexpr int LW = WN + 4, C4 = WN / 4, NQ = 32 * C4 / 64;
-        float* wsc = smem + 2 * BM + wave * (32 * LW);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int mloc = 8 * rq + 4 * (lane >> 5) + c;
-                    const int ml = wm * WM + i * 32 + mloc;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) wsc[mloc * LW + j * 32 + (lane & 31)] = epi1(acc[i][j][rq * 4 + c], ml, j);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int f = lane + 64 * q;
-                const int row = f / C4, c4 = f % C4;
-                const int m = m0 + wm * WM + i * 32 + row;
-                const int n = n0 + wn * WN + c4 * 4;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[row * LW + c4 * 4]);
-                int cnt = 4;
-                if (EDGE) {
-                    if (m >= g.M || n >= g.N) continue;
-                    cnt = min(4, g.N - n);
-                }
-                if (rs) {
-                    const float s = rs[m];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] *= s;
-                }
-                epi2_store(v, (long long)m * g.sCm + n, (long long)m * g.sGm + n, (long long)m * g.sRm + n, cnt);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    } else {
-        // transposed store (C, gate and resid are all addressed [n][m], m contiguous): each 32-column sub-tile goes through the
-        // wave's LDS scratch [32 n][WM + 4] (the 4 accumulator rows of a register quad are contiguous there) and leaves as
-        // float4 along m: WM * 4 contiguous bytes per output row
-        constexpr int LWT = WM + 4, M4 = WM / 4, NQ = 32 * M4 / 64;
-        float* wsc = smem + 2 * BM + wave * (32 * LWT);
-        const bool rs_vec = g.rs_vec_ok != 0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int mloc = i * 32 + 8 * rq + 4 * (lane >> 5);
-                    f32x4 v;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = epi1(acc[i][j][rq * 4 + c], wm * WM + mloc + c, j);
-                    *reinterpret_cast<f32x4*>(&wsc[(lane & 31) * LWT + mloc]) = v;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int f = lane + 64 * q;
-                const int nl = f / M4, m4 = f % M4;
-                const int n = n0 + wn * WN + j * 32 + nl;
-                const int m = m0 + wm * WM + m4 * 4;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[nl * LWT + m4 * 4]);
-                int cnt = 4;
-                if (EDGE) {
-                    if (m >= g.M || n >= g.N) continue;
-                    cnt = min(4, g.M - m);
-                }
-                if (rs) {
-                    const f32x4 s = load4(rs + m, rs_vec, cnt);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] *= s[c];
-                }
-                epi2_store(v, (long long)n * g.sCm + m, (long long)n * g.sGm + m, (long long)n * g.sRm + m, cnt);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
+    gemm_epilogue<BM, BN, WM, WN, EDGE, TS>(g, st_lds, smem + 2 * BM, acc, m0, n0, b, stats);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool TS, int MINW>
@@ -528,11 +394,14 @@ int launch_main_variant(const AbxGemm& g, hipStream_t st) {
 extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(gp != nullptr, "abx_gemm: null descriptor");
     AbxGemm g = *gp;
-    ABX_REQUIRE(g.A && g.B && g.C, "abx_gemm: null operand");
+    ABX_REQUIRE((g.A || g.A_split) && (g.B || g.B_split) && (g.C || g.C_split), "abx_gemm: null operand");
+    ABX_REQUIRE(!g.C_split || (g.c_transposed && g.c_split_L > 0 && g.c_split_L % 4 == 0 && g.M == (long long)g.c_split_L * g.c_split_L &&
+                               g.sCm >= g.M),
+                "abx_gemm: C_split needs the transposed store of a pair tensor (M = L*L, L % 4 == 0)");
     ABX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "abx_gemm: empty problem");
     ABX_REQUIRE(g.batch <= 65535, "abx_gemm: batch > 65535");
-    ABX_REQUIRE(g.sAk == 1 || g.sAm == 1, "abx_gemm: A must be k- or m-contiguous");
-    ABX_REQUIRE(g.sBn == 1 || g.sBk == 1, "abx_gemm: B must be n- or k-contiguous");
+    ABX_REQUIRE(!g.A || g.sAk == 1 || g.sAm == 1, "abx_gemm: A must be k- or m-contiguous");
+    ABX_REQUIRE(!g.B || g.sBn == 1 || g.sBk == 1, "abx_gemm: B must be n- or k-contiguous");
     ABX_REQUIRE(!g.ln_stats || g.ln_csum, "abx_gemm: LayerNorm needs the column sums of the gamma-scaled weights");
     ABX_REQUIRE(!(g.ln_csum && g.a_relu), "abx_gemm: LayerNorm and relu-on-load are exclusive");
     if (g.ln_csum && !g.ln_stats && g.ln_eps <= 0.f) g.ln_eps = 1e-5f;
@@ -542,10 +411,18 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     g.a_vec_ok = al16(g.A) && (g.sAb % 4 == 0) && (akc ? (g.sAm % 4 == 0) : (g.sAk % 4 == 0));
     g.b_vec_ok = al16(g.B) && (g.sBb % 4 == 0) && (g.sBn == 1 ? (g.sBk % 4 == 0) : (g.sBn % 4 == 0));
     g.fast_ok = g.a_vec_ok && g.b_vec_ok;
-    g.c_vec_ok = al16(g.C) && (g.sCb % 4 == 0) && (g.sCm % 4 == 0);
+    g.c_vec_ok = g.C_split ? ((reinterpret_cast<uintptr_t>(g.C_split) & 7) == 0 && g.sCb % 4 == 0 && g.sCm % 4 == 0 && g.sCp % 4 == 0)
+                           : (al16(g.C) && (g.sCb % 4 == 0) && (g.sCm % 4 == 0));
     g.g_vec_ok = g.gate && al16(g.gate) && (g.sGb % 4 == 0) && (g.sGm % 4 == 0);
     g.r_vec_ok = g.resid && al16(g.resid) && (g.sRb % 4 == 0) && (g.sRm % 4 == 0);
     g.rs_vec_ok = g.rowscale && al16(g.rowscale) && (g.sRSb % 4 == 0);
+    if (!g.exact) {
+        int rc = 0;
+        if (!abx_gemm3_dispatch(g, st, &rc)) return rc;
+    }
+    ABX_REQUIRE(g.A && g.B, "abx_gemm: split-bf16 operands given but the problem does not qualify for the split kernels "
+                            "(K % 16, alignment, size) and no fp32 operands were passed for the exact kernel");
+    ABX_REQUIRE(g.a_pair_transpose <= 0, "abx_gemm: a_pair_transpose is served by the split-bf16 kernels only");
     const long long mt128 = ((long long)g.M + 127) / 128;
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);

@@ -1,0 +1,354 @@
+// fp32 GEMM on the bf16 matrix cores by operand splitting ("bf16x3"): the large contractions of the pair stack.
+//
+// Every fp32 operand element is written EXACTLY as the sum of three bf16 values x = x0 + x1 + x2 (round-to-nearest pieces:
+// 8 + 8 + 8 significand bits), and a*b is evaluated as the six products with i + j <= 2
+//     a0 b2 + a1 b1 + a2 b0 + a0 b1 + a1 b0 + a0 b0            (smallest terms first)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each bf16 x bf16 product is exact in fp32; the three dropped terms are
+// below 2^-25 |a||b|, i.e. under the rounding error of a native fp32 fma, so the result is fp32-accurate (measured against
+// fp64 in tests/test_gpu_kernels.py: same error as the exact v_mfma_f32_32x32x2_f32 kernel of gemm.hip) while the matrix
+// cores run 16/6 = 2.7x faster than their fp32 rate.  The exact kernel remains selectable (AbxGemm.exact).
+//
+// Data movement is all asynchronous global->LDS DMA (global_load_lds_dwordx4): no operand passes through VGPRs on its way
+// to LDS, so nothing the compiler schedules can drain the prefetch queue; the k-loop counts its own outstanding loads
+// (s_waitcnt vmcnt(N) + raw s_barrier).
+//   A  fp32, k-contiguous rows (AMODE 0): ring of 3 stages [BM][16] fp32 (64-byte rows, 16-byte slots XOR-swizzled through
+//      the SOURCE address).  Every wave reads its own rows as fp32 fragments and splits them in registers right in front of
+//      the MFMAs; the LayerNorm statistics (inline mode), the mean shift and relu-on-load are applied to those registers.
+//      Optional pair transposition of the rows (a_pair_transpose): the DMA source address is per lane, so the incoming
+//      TriangleMultiplication reads z[k][i] rows in (i,k) order for free.
+//   A  fp32, row-contiguous / channel-major (AMODE 1): ring of 3 stages [16 k][BM] fp32, fragments by 4-byte LDS reads.
+//   A  pre-split bf16 planes (AMODE 2) and B always pre-split planes, k-TILED in memory: [K/16][3][rows][16] so that the
+//      32 bytes a row contributes to a k-tile sit next to the neighbouring rows' (full 128-byte lines per DMA instead of a
+//      quarter line per row, which the 32 KB L1 cannot keep until the next k-tile): weights from abx_split_weights, or
+//      activations written by a producer GEMM with C_split (the TriangleMultiplication einsum seqformer.py:490-493 takes
+//      both operands this way).  LDS image [plane][row][32 B], the two 16-byte halves swapped on odd row-octets:
+//      conflict-free ds_read_b128 fragment reads (lane -> row, lane >> 5 -> k half).
+// Requirements (abx_gemm falls back to the exact kernel otherwise): K % 16 == 0, 16-byte aligned operand rows.
+// Epilogue: gemm_epilogue.h (shared with gemm.hip).
+#include "common.h"
+#include "abx_hip.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int BK = 16;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// 16 bytes per lane, global -> LDS at (wave-uniform) dst + lane * 16
+__device__ __forceinline__ void glds16(const void* src, char* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_and_barrier() {
+    // own DMA writes for the next tile have landed (the newest N stay in flight), own LDS reads retired, then the block barrier
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// byte offset of (plane, row, 16-byte half) in a [3][ROWS][16] bf16 tile image
+template <int ROWS>
+__device__ __forceinline__ int plane_off(int plane, int row, int half) {
+    return plane * (ROWS * 32) + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+}
+
+// DMA source pointers of one wave for a [3][ROWS][16] bf16 plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
+// Surplus chunks (image not a multiple of 4 KB) and rows past the matrix re-read a valid row; their LDS bytes are never used
+// for valid outputs.
+template <int ROWS, int NL>
+__device__ __forceinline__ void plane_sources(const unsigned short* base, long long s_plane, long long s_row, int r0, int R,
+                                              const char* (&src)[NL]) {
+    // (the k-tile stride is applied by the caller: one k-tile = 16 consecutive k of every row)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int o = (wave * NL + i) * 1024 + lane * 16;                 // byte offset in the stage
+        if (o >= 3 * ROWS * 32) o -= 3 * ROWS * 32;                 // surplus chunk: duplicate of the image start
+        const int plane = o / (ROWS * 32), rem = o % (ROWS * 32);
+        const int row = rem >> 5, hp = (rem >> 4) & 1;
+        const int half = hp ^ ((row >> 3) & 1);
+        const int gr = min(r0 + row, R - 1);
+        src[i] = reinterpret_cast<const char*>(base + plane * s_plane + (long long)gr * s_row + 8 * half);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS>
+__device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;                  // bytes per A stage
+    constexpr int NLA = (A_IMG + 4095) / 4096;                                  // DMA instructions per wave per A tile
+    constexpr int A_STAGE = NLA * 4096;
+    constexpr int B_IMG = 3 * BN * 32;
+    constexpr int NLB = (B_IMG + 4095) / 4096;
+    constexpr int B_STAGE = NLB * 4096;
+    char* As = reinterpret_cast<char*>(smem);                 // ring of 3 stages
+    char* Bs = As + 3 * A_STAGE;                              // 2 stages
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int h = lane >> 5;
+
+    // ---- per-lane DMA source pointers (tile 0); each k-tile advances them by 16 elements along k
+    const char* srcA[NLA];
+    const char* srcB[NLB];
+    long long a_step;                                          // bytes per k-tile
+    if constexpr (AMODE == 0) {
+        const float* Ab = g.A + (long long)b * g.sAb;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int r = (wave * NLA + i) * 16 + (lane >> 2), p = lane & 3;
+            const int kq = p ^ ((r >> 2) & 3);                 // physical 16-byte slot p of row r holds logical k-quad kq
+            long long gr = min(m0 + r, g.M - 1);
+            if (g.a_pair_transpose > 0) gr = (gr % g.a_pair_transpose) * g.a_pair_transpose + gr / g.a_pair_transpose;
+            srcA[i] = reinterpret_cast<const char*>(Ab + gr * g.sAm + kq * 4);
+        }
+        a_step = BK * 4;
+    } else if constexpr (AMODE == 1) {
+        const float* Ab = g.A + (long long)b * g.sAb;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int kl = (wave * NLA + i) * 2 + (lane >> 5), mq = lane & 31;     // LDS [k][BM]: 2 k-rows per instruction
+            const int gm = min(m0 + mq * 4, g.M - 4);
+            srcA[i] = reinterpret_cast<const char*>(Ab + (long long)kl * g.sAk + gm);
+        }
+        a_step = (long long)BK * g.sAk * 4;
+    } else {
+        plane_sources<BM, NLA>(g.A_split + (long long)b * g.sA3b, g.sA3p, g.sA3m, m0, g.M, srcA);
+        a_step = g.sA3k * 2;
+    }
+    plane_sources<BN, NLB>(g.B_split + (long long)b * g.sB3b, g.sB3p, g.sB3n, n0, g.N, srcB);
+    const long long b_step = g.sB3k * 2;
+    const int nk = g.K / BK;
+
+    auto issue_a = [&](int tile) {          // tile index clamped by the caller
+        char* dst = As + (tile % 3) * A_STAGE + wave * NLA * 1024;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) glds16(srcA[i] + tile * a_step, dst + i * 1024);
+    };
+    auto issue_b = [&](int tile) {
+        char* dst = Bs + (tile & 1) * B_STAGE + wave * NLB * 1024;
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) glds16(srcB[i] + tile * b_step, dst + i * 1024);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool relu = g.a_relu != 0;
+    const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
+    float ls[TM], lq[TM], lshift[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ls[i] = lq[i] = lshift[i] = 0.f;
+
+    // prologue: A(0), B(0), A(1) in this order; the k-loop keeps exactly one A tile (NLA loads) in flight across its barrier
+    issue_a(0);
+    issue_b(0);
+    issue_a(min(1, nk - 1));
+    wait_vm_and_barrier<NLA>();
+
+    // per-lane LDS fragment offsets
+    int offA[TM][AMODE == 0 ? 2 : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + (lane & 31);
+        if constexpr (AMODE == 0) {
+            const int x = (r >> 2) & 3;
+            offA[i][0] = r * 64 + (((2 * h) ^ x) << 4);
+            offA[i][1] = r * 64 + (((2 * h + 1) ^ x) << 4);
+        } else if constexpr (AMODE == 1) {
+            offA[i][0] = (8 * h) * (BM * 4) + r * 4;
+        } else {
+            offA[i][0] = plane_off<BM>(0, r, h);
+        }
+    }
+    int offB[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = plane_off<BN>(0, wn * WN + j * 32 + (lane & 31), h);
+
+    for (int t = 0; t < nk; ++t) {
+        // next tiles: B(t+1) first, then A(t+2): the wait at the end of this step leaves only A(t+2) outstanding
+        if (!(g.tune & 64)) issue_b(min(t + 1, nk - 1));
+        if (!(g.tune & 32)) issue_a(min(t + 2, nk - 1));
+
+        const char* as = As + (t % 3) * A_STAGE;
+        const char* bs = Bs + (t & 1) * B_STAGE;
+        bf16x8 a[TM][3], bb[TN][3];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bb[j][p] = *reinterpret_cast<const bf16x8*>(bs + offB[j] + p * (BN * 32));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (AMODE == 2) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(as + offA[i][0] + p * (BM * 32));
+            } else {
+                float x[8];
+                if constexpr (AMODE == 0) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(as + offA[i][0]);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(as + offA[i][1]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { x[c] = lo[c]; x[4 + c] = hi[c]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = *reinterpret_cast<const float*>(as + offA[i][0] + e * (BM * 4));
+                }
+                if (ln_inline) {
+                    // statistics of the row from this lane's 8 k (the other k half sits in lane ^ 32), shifted by the row's
+                    // first element so that E[x^2] - mean^2 does not cancel when |mean| >> sigma
+                    if (t == 0) lshift[i] = __shfl(x[0], lane & 31, 64);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        x[e] -= lshift[i];
+                        ls[i] += x[e];
+                        lq[i] = fmaf(x[e], x[e], lq[i]);
+                    }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+                }
+                unsigned q0[4], q1[4], q2[4];
+                if (g.tune & 128) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { q0[e] = __float_as_uint(x[2 * e]); q1[e] = __float_as_uint(x[2 * e + 1]); q2[e] = q0[e] ^ q1[e]; }
+                } else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], q0[e], q1[e], q2[e]);
+                a[i][0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
+                a[i][1] = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+                a[i][2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+            }
+        }
+        // six product terms, smallest first; consecutive MFMAs hit different accumulators
+        constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
+        if (!(g.tune & 16))
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j], 0, 0, 0);
+        if (g.tune & 96) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else wait_vm_and_barrier<NLA>();
+    }
+    // drain the (redundant) tail DMA before the epilogue reuses the LDS
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- LayerNorm row statistics of this M-panel -> LDS, then the shared epilogue
+    float* st_lds = smem;                                   // [BM][2]
+    const float* gstats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
+    const bool stats = gstats != nullptr || ln_inline;
+    if (gstats) {
+        for (int idx = threadIdx.x; idx < 2 * BM; idx += 256) {
+            const int m = m0 + (idx >> 1);
+            st_lds[idx] = (!EDGE || m < g.M) ? gstats[2 * (long long)m + (idx & 1)] : 0.f;
+        }
+        __syncthreads();
+    } else if (ln_inline) {
+        const float invK = 1.0f / (float)g.K;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float sm = ls[i] + __shfl_xor(ls[i], 32, 64), sq = lq[i] + __shfl_xor(lq[i], 32, 64);
+            if (wn == 0 && h == 0) {                            // the wn waves hold identical copies
+                const int row = wm * WM + i * 32 + lane;
+                const float dm = sm * invK;
+                st_lds[2 * row] = dm;                           // the operand was shifted: only (mean - shift) remains
+                st_lds[2 * row + 1] = 1.0f / sqrtf(fmaxf(sq * invK - dm * dm, 0.f) + g.ln_eps);
+            }
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<BM, BN, WM, WN, EDGE, TS>(g, st_lds, smem + 2 * BM, acc, m0, n0, b, stats);
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
+    constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;
+    constexpr int A_STAGE = (A_IMG + 4095) / 4096 * 4096;
+    constexpr int B_STAGE = (3 * BN * 32 + 4095) / 4096 * 4096;
+    constexpr int OPER = (3 * A_STAGE + 2 * B_STAGE) / 4;                          // floats
+    constexpr int SCR = 4 * 32 * ((TS ? WM : WN) + 4);
+    constexpr int EPI = 2 * BM + SCR;
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntn = (g.N + BN - 1) / BN;
+    int wgid = blockIdx.x;
+    if (!(g.tune & 1)) {        // XCD-aware remap: the N-tiles of one M-panel run on the same XCD (see gemm.hip)
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int mt = wgid / ntn, nt = wgid % ntn;
+    const int b = blockIdx.z;
+    const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
+    if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS>(g, smem, mt, nt, b);
+    else gemm3_block<BM, BN, WM, WN, AMODE, true, TS>(g, smem, mt, nt, b);
+}
+
+template <int BM, int BN, int WM, int WN, int MINW>
+int launch3(const AbxGemm& g, hipStream_t st) {
+    const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
+    dim3 grid((unsigned)(mt * ntn), 1, (unsigned)g.batch), block(256);
+    const int amode = g.A_split ? 2 : (g.sAk == 1 ? 0 : 1);
+    if (g.c_transposed) {
+        if (amode != 0) { abx_set_error("abx_gemm: transposed store needs a k-contiguous fp32 A"); return ABX_ERR_ARG; }
+        hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, 0, true, MINW>), grid, block, 0, st, g);
+    } else if (amode == 0) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, 0, false, MINW>), grid, block, 0, st, g);
+    else if (amode == 1) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, 1, false, MINW>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, 2, false, MINW>), grid, block, 0, st, g);
+    return abx_check_launch("abx_gemm");
+}
+
+// fp32 weights W[n][k] (element strides s_n, s_k) -> k-tiled bf16 planes [Kp/16][3][N][16], zero padded to Kp
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, long long s_n, long long s_k, int N, int K,
+                                                            int Kp, unsigned short* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * Kp) return;
+    const int n = (int)(idx / Kp), k = (int)(idx % Kp);
+    const float x = k < K ? w[n * s_n + k * s_k] : 0.f;
+    unsigned p0, p1, p2;
+    split2(x, 0.f, p0, p1, p2);
+    const long long o = ((long long)(k >> 4) * 3 * N + n) * 16 + (k & 15);
+    out[o] = (unsigned short)(p0 & 0xffffu);
+    out[o + (long long)N * 16] = (unsigned short)(p1 & 0xffffu);
+    out[o + 2LL * N * 16] = (unsigned short)(p2 & 0xffffu);
+}
+
+}  // namespace
+
+// Called by abx_gemm (gemm.hip) once the descriptor has been validated and the vector flags filled.
+// Returns 1 when the problem is not served by this path (the caller falls back to the exact kernel).
+int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!g.B_split || g.K % 16 != 0 || g.N <= 64) return 1;
+    const long long mt128 = ((long long)g.M + 127) / 128;
+    if (mt128 * (((long long)g.N + 127) / 128) * g.batch < 512) return 1;
+    if (!al16(g.B_split) || g.sB3n % 8 != 0 || g.sB3p % 8 != 0 || g.sB3b % 8 != 0 || g.sB3k % 8 != 0) return 1;
+    if (g.A_split) {
+        if (!al16(g.A_split) || g.sA3m % 8 != 0 || g.sA3p % 8 != 0 || g.sA3b % 8 != 0 || g.sA3k % 8 != 0 || g.c_transposed) return 1;
+    } else if (g.sAk == 1) {
+        if (!al16(g.A) || g.sAm % 4 != 0 || g.sAb % 4 != 0) return 1;
+        if (g.a_pair_transpose > 0 && (long long)g.a_pair_transpose * g.a_pair_transpose != g.M) return 1;
+    } else {
+        if (!al16(g.A) || g.sAk % 4 != 0 || g.sAb % 4 != 0 || g.M % 4 != 0 || g.M < 4 || g.a_pair_transpose > 0) return 1;
+    }
+    const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;
+    if (pad192 <= pad128 && !((g.tune >> 1) & 7)) *rc = launch3<128, 192, 64, 96, 2>(g, st);
+    else *rc = launch3<128, 128, 64, 64, 2>(g, st);
+    return 0;
+}
+
+extern "C" int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t st) {
+    ABX_REQUIRE(w && out && N > 0 && K > 0, "abx_split_weights: bad args");
+    const int Kp = (K + 15) / 16 * 16;
+    const long long total = (long long)N * Kp;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, s_n, s_k, N, K, Kp, out);
+    return abx_check_launch("abx_split_weights");
+}

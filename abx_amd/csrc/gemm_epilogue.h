@@ -1,0 +1,177 @@
+// Fused GEMM epilogue shared by the exact-fp32 (gemm.hip) and the split-bf16 (gemm3.hip) kernels.
+// The accumulators use the C/D layout of the 32x32 MFMAs (dtype independent on gfx950):
+//   col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+// st_lds: [BM][2] (mean - shift, rstd) of this M-panel when `stats`; scratch: per-wave store staging (4 waves).
+#pragma once
+#include "common.h"
+#include "abx_hip.h"
+
+template <int BM, int BN, int WM, int WN, bool EDGE, bool TS>
+__device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __restrict__ st_lds, float* __restrict__ scratch,
+                                              f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    float* Cb = g.C + (long long)b * g.sCb;
+    const float* rs = g.rowscale ? g.rowscale + (long long)b * g.sRSb : nullptr;
+    const float* gt = g.gate ? g.gate + (long long)b * g.sGb : nullptr;
+    const float* rd = g.resid ? g.resid + (long long)b * g.sRb : nullptr;
+    const bool c_vec = g.c_vec_ok != 0, g_vec = g.g_vec_ok != 0, r_vec = g.r_vec_ok != 0, gsig = g.gate_sigmoid != 0;
+    float bias[TN], csum[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool nok = !EDGE || n < g.N;
+        bias[j] = (g.bias && nok) ? g.bias[n] : 0.f;
+        csum[j] = (stats && nok) ? g.ln_csum[n] : 0.f;
+    }
+    // per-element part that needs no global operand: folded LayerNorm, bias, alpha, activation
+    auto epi1 = [&](float v, int ml, int j) -> float {
+        if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
+        v = (v + bias[j]) * g.alpha;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+        return v;
+    };
+    // 4 consecutive elements along the contiguous output dimension: gate / residual reads and the store are 16-byte accesses
+    // when the operand allows it (cnt < 4: ragged tail)
+    auto load4 = [&](const float* p, bool vec, int cnt) -> f32x4 {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (vec && cnt == 4) r = *reinterpret_cast<const f32x4*>(p);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < cnt) r[c] = p[c];
+        }
+        return r;
+    };
+    auto epi2_store = [&](f32x4 v, long long off_c, long long off_g, long long off_r, int cnt, int m_idx, int n_idx) {
+        if (gt) {
+            f32x4 gv = load4(gt + off_g, g_vec, cnt);
+            if (gsig) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gv[c] = 1.0f / (1.0f + expf(-gv[c]));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= gv[c];
+        }
+        if (rd) {
+            const f32x4 rv = load4(rd + off_r, r_vec, cnt);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += rv[c];
+        }
+        if (g.C_split) {
+            // output as three bf16 planes (v = p0 + p1 + p2 exactly): the pre-split operand image of the next contraction
+            unsigned a0, a1, a2, b0, b1, b2;
+            split2(v[0], v[1], a0, a1, a2);
+            split2(v[2], v[3], b0, b1, b2);
+            // m = i * L + k: the planes are the k-tiled operand image [k/16][plane][i][16] of the following contraction
+            const int ii = m_idx / g.c_split_L, kk = m_idx - ii * g.c_split_L;
+            unsigned short* cs = g.C_split + (long long)b * g.sCb + (long long)n_idx * g.sCm + (kk >> 4) * g.sCk + ii * 16 + (kk & 15);
+            if (c_vec && cnt == 4) {
+                *reinterpret_cast<u32x2*>(cs) = u32x2{a0, b0};
+                *reinterpret_cast<u32x2*>(cs + g.sCp) = u32x2{a1, b1};
+                *reinterpret_cast<u32x2*>(cs + 2 * g.sCp) = u32x2{a2, b2};
+            } else {
+                const unsigned pa[3] = {a0, a1, a2}, pb[3] = {b0, b1, b2};
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    unsigned short* o = cs + p * g.sCp;
+                    if (cnt > 0) o[0] = (unsigned short)(pa[p] & 0xffffu);
+                    if (cnt > 1) o[1] = (unsigned short)(pa[p] >> 16);
+                    if (cnt > 2) o[2] = (unsigned short)(pb[p] & 0xffffu);
+                    if (cnt > 3) o[3] = (unsigned short)(pb[p] >> 16);
+                }
+            }
+        } else if (c_vec && cnt == 4) *reinterpret_cast<f32x4*>(Cb + off_c) = v;
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < cnt) Cb[off_c + c] = v[c];
+        }
+    };
+    if constexpr (!TS) {
+        // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][WN + 4] and leaves as float4 along n
+        constexpr int LW = WN + 4, C4 = WN / 4, NQ = 32 * C4 / 64;
+        float* wsc = scratch + wave * (32 * LW);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int mloc = 8 * rq + 4 * (lane >> 5) + c;
+                    const int ml = wm * WM + i * 32 + mloc;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) wsc[mloc * LW + j * 32 + (lane & 31)] = epi1(acc[i][j][rq * 4 + c], ml, j);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int f = lane + 64 * q;
+                const int row = f / C4, c4 = f % C4;
+                const int m = m0 + wm * WM + i * 32 + row;
+                const int n = n0 + wn * WN + c4 * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[row * LW + c4 * 4]);
+                int cnt = 4;
+                if (EDGE) {
+                    if (m >= g.M || n >= g.N) continue;
+                    cnt = min(4, g.N - n);
+                }
+                if (rs) {
+                    const float s = rs[m];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] *= s;
+                }
+                epi2_store(v, (long long)m * g.sCm + n, (long long)m * g.sGm + n, (long long)m * g.sRm + n, cnt, m, n);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        // transposed store (C, gate and resid are all addressed [n][m], m contiguous): each 32-column sub-tile goes through the
+        // wave's LDS scratch [32 n][WM + 4] (the 4 accumulator rows of a register quad are contiguous there) and leaves as
+        // float4 along m: WM * 4 contiguous bytes per output row
+        constexpr int LWT = WM + 4, M4 = WM / 4, NQ = 32 * M4 / 64;
+        float* wsc = scratch + wave * (32 * LWT);
+        const bool rs_vec = g.rs_vec_ok != 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int mloc = i * 32 + 8 * rq + 4 * (lane >> 5);
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = epi1(acc[i][j][rq * 4 + c], wm * WM + mloc + c, j);
+                    *reinterpret_cast<f32x4*>(&wsc[(lane & 31) * LWT + mloc]) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int f = lane + 64 * q;
+                const int nl = f / M4, m4 = f % M4;
+                const int n = n0 + wn * WN + j * 32 + nl;
+                const int m = m0 + wm * WM + m4 * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[nl * LWT + m4 * 4]);
+                int cnt = 4;
+                if (EDGE) {
+                    if (m >= g.M || n >= g.N) continue;
+                    cnt = min(4, g.M - m);
+                }
+                if (rs) {
+                    const f32x4 s = load4(rs + m, rs_vec, cnt);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] *= s[c];
+                }
+                epi2_store(v, (long long)n * g.sCm + m, (long long)n * g.sGm + m, (long long)n * g.sRm + m, cnt, m, n);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}

@@ -31,6 +31,7 @@ class Packed:
         g = self.sd
         self.wt, self.b = {}, {}
         self._ln_cache = {}
+        self._split_cache = {}
 
         def lin(name, key=None):
             key = key or name
@@ -82,33 +83,51 @@ class Packed:
             bias = beta @ wt
             if self.b.get(key) is not None:
                 bias = bias + self.b[key].double()
-            hit = (wts.float().contiguous(), wts.sum(0).float().contiguous(), bias.float().contiguous())
+            w32 = wts.float().contiguous()
+            hit = (w32, wts.sum(0).float().contiguous(), bias.float().contiguous(), self._split(w32))
             self._ln_cache[ck] = hit
         return hit
+
+    @staticmethod
+    def _split(wt):
+        # bf16x3 operand image for the split-bf16 GEMM kernels (only problems with N > 64 ever take that path)
+        return ops.split_weights(wt) if (wt.shape[1] > 64 and wt.is_cuda) else None
+
+    def split(self, key):
+        if key not in self._split_cache:
+            self._split_cache[key] = self._split(self.wt[key])
+        return self._split_cache[key]
 
 
 class Workspace:
     def __init__(self, device):
         self.device = device
         self.bufs = {}
+        self.shapes = {}
 
-    def get(self, name, shape, dtype=torch.float32):
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        """zero=True: the view is zero-filled whenever the buffer is new or was last handed out with another shape
+        (padding regions that the kernels never write must read as 0)."""
         n = int(np.prod(shape))
         buf = self.bufs.get(name)
-        if buf is None or buf.numel() < n or buf.dtype != dtype:
+        fresh = buf is None or buf.numel() < n or buf.dtype != dtype
+        if fresh:
             buf = torch.empty(max(n, 1), device=self.device, dtype=dtype)
             self.bufs[name] = buf
+        if zero and (fresh or self.shapes.get(name) != tuple(shape)):
+            buf[:n].zero_()
+        self.shapes[name] = tuple(shape)
         return buf[:n].view(*shape)
 
 
 def _lin(P, name, x, out, **kw):
-    return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), **kw)
+    return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), B3=P.split(name), **kw)
 
 
 def _ln_lin(P, name, ln_name, stats, x, out, **kw):
     """out = epi(LN(x) @ W^T + b) with the LayerNorm folded into the GEMM epilogue."""
-    wt, csum, bias = P.ln_linear(name, ln_name)
-    return ops.gemm(x, wt, out, bias=bias, ln=(stats, csum), **kw)
+    wt, csum, bias, w3 = P.ln_linear(name, ln_name)
+    return ops.gemm(x, wt, out, bias=bias, ln=(stats, csum), B3=w3, **kw)
 
 
 class Engine:
@@ -254,27 +273,42 @@ class Engine:
         ops.opm_features(lr, feat, Bc, L, 64)
         _lin(P, pre + 'out_proj', feat, z2, resid=z2)
         # ---------------- triangle multiplication (seqformer.py:443-504)
+        # Large problems run the contraction on the split-bf16 kernels: the projections write left/right directly as the
+        # k-tiled bf16 plane operands of the contraction (C_split), and the incoming variant reads z pair-transposed
+        # (a_pair_transpose) so that both einsums become the same row-major 'ik,jk->ij' product.
+        planes = ops.gemm_split_eligible(LL, 128, 192, Bc) and L % 4 == 0
         for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
             pre = P_BLK + name + '.'
             # sigmoid(left_gate | right_gate) channel-major like the projections they gate; sigmoid(final_gate) row-major
             GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
             Gf = w768.view(-1)[Bc * 256 * LL:Bc * 448 * LL].view(Bc, LL, 192)
-            _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2)
+            pt = L if (planes and not outgoing) else 0
+            _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2, a_pair_transpose=pt)
             _ln_lin(P, pre + 'final_gate', pre + 'norm', None, z3, Gf, act=2)
-            left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
-            right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
             tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
-            _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, left.transpose(1, 2), rowscale=pmask,
-                    gate=GT[:, 0:128].transpose(1, 2), gate_sigmoid=False)
-            _ln_lin(P, pre + 'right_proj', pre + 'norm', None, z3, right.transpose(1, 2), rowscale=pmask,
-                    gate=GT[:, 128:256].transpose(1, 2), gate_sigmoid=False)
-            lz = left.view(Bc * 128, L, L)
-            rz = right.view(Bc * 128, L, L)
             tz = tt.view(Bc * 128, L, L)
-            if outgoing:      # 'bikc,bjkc->bijc'
-                ops.gemm(lz, rz.transpose(1, 2), tz)
-            else:             # 'bkic,bkjc->bijc'
-                ops.gemm(lz.transpose(1, 2), rz, tz)
+            if planes:
+                KT = (L + 15) // 16
+                lp = ws.get('tm_left', (Bc, 128, KT, 3, L, 16), torch.int16, zero=(L % 16 != 0))
+                rp = ws.get('tm_right', (Bc, 128, KT, 3, L, 16), torch.int16, zero=(L % 16 != 0))
+                _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, lp, rowscale=pmask,
+                        gate=GT[:, 0:128].transpose(1, 2), gate_sigmoid=False, a_pair_transpose=pt)
+                _ln_lin(P, pre + 'right_proj', pre + 'norm', None, z3, rp, rowscale=pmask,
+                        gate=GT[:, 128:256].transpose(1, 2), gate_sigmoid=False, a_pair_transpose=pt)
+                ops.gemm(lp.view(Bc * 128, KT, 3, L, 16), rp.view(Bc * 128, KT, 3, L, 16), tz)
+            else:
+                left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
+                right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
+                _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, left.transpose(1, 2), rowscale=pmask,
+                        gate=GT[:, 0:128].transpose(1, 2), gate_sigmoid=False)
+                _ln_lin(P, pre + 'right_proj', pre + 'norm', None, z3, right.transpose(1, 2), rowscale=pmask,
+                        gate=GT[:, 128:256].transpose(1, 2), gate_sigmoid=False)
+                lz = left.view(Bc * 128, L, L)
+                rz = right.view(Bc * 128, L, L)
+                if outgoing:      # 'bikc,bjkc->bijc'
+                    ops.gemm(lz, rz.transpose(1, 2), tz)
+                else:             # 'bkic,bkjc->bijc'
+                    ops.gemm(lz.transpose(1, 2), rz, tz)
             tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
             _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=Gf, gate_sigmoid=False, resid=z3)
         # ---------------- triangle attention (seqformer.py:506-550)

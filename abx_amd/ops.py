@@ -27,52 +27,107 @@ def _f32(t):
 GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 
 
-def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False):
-    """Name of the gemm_kernel<...> instantiation abx_gemm launches for a problem (mirror of the selection in
-    csrc/gemm.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
+GEMM_EXACT = False   # True: every GEMM on the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32); default: large problems on the
+                     # split-bf16 kernels of csrc/gemm3.hip (fp32-accurate)
+
+
+def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False, split=False, exact=None, a_split=False):
+    """Name of the kernel instantiation abx_gemm launches for a problem (mirror of the selection in csrc/gemm.hip and
+    csrc/gemm3.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
+    b = lambda x: 'true' if x else 'false'
+    exact = GEMM_EXACT if exact is None else exact
+    blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128
+    if not exact and split and N > 64 and blocks128 >= 512 and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
+        amode = 2 if a_split else (0 if a_kcontig else 1)
+        cfg = (128, 192, 64, 96) if wide192 else (128, 128, 64, 64)
+        return f'gemm3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {amode}, {b(transposed)}, 2>'
     if N <= 32:
         cfg = (128, 32, 32, 32, 3)
     elif N <= 64:
         cfg = (128, 64, 32, 64, 3)
-    elif ((M + 127) // 128) * ((N + 127) // 128) * batch < 512:
+    elif blocks128 < 512:
         cfg = (64, 64, 32, 32, 3)
-    elif ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128:
+    elif wide192:
         cfg = (128, 192, 64, 96, 2)
     else:
         cfg = (128, 128, 64, 64, 3)
-    b = lambda x: 'true' if x else 'false'
     return f'gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 16, {b(a_kcontig)}, {b(b_ncontig)}, {b(transposed)}, {cfg[4]}>'
 
 
+def gemm_split_eligible(M, N, K, batch=1):
+    """True when abx_gemm serves an (aligned) problem of this size on the split-bf16 kernels (mirror of
+    abx_gemm3_dispatch in csrc/gemm3.hip)."""
+    return (not GEMM_EXACT) and N > 64 and K % 16 == 0 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= 512
+
+
+def split_weights(Wt):
+    """Wt (K, N) packed weight (n-contiguous) -> int16 tensor [Kp/16][3][N][16] of k-tiled bf16 planes with
+    W = p0 + p1 + p2 exactly (operand image of the split-bf16 GEMM kernels); Kp = K rounded up to 16."""
+    K, N = Wt.shape
+    _f32(Wt)
+    Kp = (K + 15) // 16 * 16
+    out = torch.empty(Kp // 16, 3, N, 16, device=Wt.device, dtype=torch.int16)
+    check(_lib.load().abx_split_weights(_p(Wt), Wt.stride(1), Wt.stride(0), N, K, _p(out), _stream()), 'abx_split_weights')
+    return out
+
+
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
-    tensors laid out like Cout (n-contiguous, or m-contiguous when Cout is stored transposed)."""
+    tensors laid out like Cout (n-contiguous, or m-contiguous when Cout is stored transposed).
+    Split-bf16 operands (int16 tensors of k-tiled bf16 planes, x = p0 + p1 + p2): B3 (K/16,3,N,16) = split_weights(B);
+    A (b,K/16,3,M,16) and B (b,K/16,3,N,16) both as planes: the TriangleMultiplication contraction; Cout (b,N,L/16,3,L,16)
+    int16 (M = L*L pair rows, m = i*L + k): the output is written as the plane operand [n][k/16][plane][i][16] of that
+    contraction (transposed store).  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i."""
     lib = _lib.load()
-    if A.dim() == 2:
-        A = A.unsqueeze(0)
-    if Cout.dim() == 2:
-        Cout = Cout.unsqueeze(0)
-    nb, M, K = A.shape
-    if B.dim() == 2:
-        B = B.unsqueeze(0)
-    assert B.shape[1] == K, (A.shape, B.shape)
-    N = B.shape[2]
-    assert Cout.shape == (nb, M, N), (Cout.shape, (nb, M, N))
-    _f32(A), _f32(B), _f32(Cout)
     g = AbxGemm()
-    g.A, g.sAb, g.sAm, g.sAk = _p(A), A.stride(0) if nb > 1 else 0, A.stride(1), A.stride(2)
-    g.B, g.sBb, g.sBk, g.sBn = _p(B), (B.stride(0) if B.shape[0] > 1 else 0), B.stride(1), B.stride(2)
-    g.C = _p(Cout)
-    g.sCb = Cout.stride(0) if nb > 1 else 0
-    if Cout.stride(2) == 1:
-        g.c_transposed, g.sCm = 0, Cout.stride(1)
+    a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
+    if a_planes:
+        assert A.dim() == 5 and A.shape[2] == 3 and A.shape[4] == 16 and A.stride(4) == 1
+        nb, KT, _, M, _ = A.shape
+        K = KT * 16
+        g.A_split, g.sA3b, g.sA3k, g.sA3p, g.sA3m = _p(A), (A.stride(0) if nb > 1 else 0), A.stride(1), A.stride(2), A.stride(3)
     else:
-        assert Cout.stride(1) == 1, 'Cout must be n-contiguous or m-contiguous'
-        g.c_transposed, g.sCm = 1, Cout.stride(2)
+        if A.dim() == 2:
+            A = A.unsqueeze(0)
+        nb, M, K = A.shape
+        _f32(A)
+        g.A, g.sAb, g.sAm, g.sAk = _p(A), A.stride(0) if nb > 1 else 0, A.stride(1), A.stride(2)
+    if b_planes:
+        assert B.dim() == 5 and B.shape[2] == 3 and B.shape[4] == 16 and B.stride(4) == 1 and B.shape[1] * 16 == K and B.shape[0] == nb
+        N = B.shape[3]
+        g.B_split, g.sB3b, g.sB3k, g.sB3p, g.sB3n = _p(B), (B.stride(0) if nb > 1 else 0), B.stride(1), B.stride(2), B.stride(3)
+    else:
+        if B.dim() == 2:
+            B = B.unsqueeze(0)
+        assert B.shape[1] == K, (A.shape, B.shape)
+        N = B.shape[2]
+        _f32(B)
+        g.B, g.sBb, g.sBk, g.sBn = _p(B), (B.stride(0) if B.shape[0] > 1 else 0), B.stride(1), B.stride(2)
+    if c_planes:
+        L = Cout.shape[4]
+        assert Cout.dim() == 6 and Cout.shape == (nb, N, (L + 15) // 16, 3, L, 16) and M == L * L, (Cout.shape, nb, M, N)
+        assert Cout.stride(5) == 1 and Cout.stride(4) == 16
+        g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), L
+        g.c_transposed = 1
+    else:
+        if Cout.dim() == 2:
+            Cout = Cout.unsqueeze(0)
+        assert Cout.shape == (nb, M, N), (Cout.shape, (nb, M, N))
+        _f32(Cout)
+        g.C = _p(Cout)
+        Cl = Cout
+        g.sCb = Cl.stride(0) if nb > 1 else 0
+        if Cl.stride(2) == 1:
+            g.c_transposed, g.sCm = 0, Cl.stride(1)
+        else:
+            assert Cl.stride(1) == 1, 'Cout must be n-contiguous or m-contiguous'
+            g.c_transposed, g.sCm = 1, Cl.stride(2)
     g.M, g.N, g.K, g.batch = M, N, K, nb
+    g.a_pair_transpose = int(a_pair_transpose)
     if ln is not None:
         stats, csum = ln                     # stats None: the kernel derives (mean, rstd) from its own A stream
         assert csum.numel() == N
@@ -81,6 +136,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             assert stats.numel() == 2 * nb * M, (stats.shape, nb, M)
             g.ln_stats, g.sSb = _p(_f32(stats)), M
     g.a_relu = 1 if a_relu else 0
+    g.exact = int(GEMM_EXACT if exact is None else exact)
+    if B3 is not None:
+        assert B3.dtype == torch.int16 and B3.is_contiguous() and B3.shape[1:] == (3, N, 16) and B3.shape[0] * 16 >= K
+        g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
     g.tune = GEMM_TUNE if tune is None else tune
     g.bias = _p(bias)
     g.alpha = float(alpha)
@@ -102,6 +161,11 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(sd)
     check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
     return Cout
+
+
+def planes_to_float(p, dim=0):
+    """int16 bf16 planes (size 3 along `dim`) -> float32 sum (exact when the planes came from one fp32 value)."""
+    return (p.to(torch.int32) << 16).view(torch.float32).sum(dim)
 
 
 def row_stats(x, out=None, eps=1e-5):

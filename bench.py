@@ -50,11 +50,17 @@ class OpTimer:
     def _sig(self, name, args, kw):
         if name == 'gemm':
             A, B, C = args[0], args[1], args[2]
+            if A.dtype == torch.int16:          # k-tiled bf16 planes (b, K/16, 3, rows, 16): the tri-mul contraction
+                nb, M, K, N = A.shape[0], A.shape[3], A.shape[1] * 16, B.shape[3]
+                kern = self.ops.gemm_kernel_name(M, N, K, nb, split=True, a_split=True)
+                return kern, 2.0 * nb * M * N * K, nb * (6.0 * (M + N) * K + 4.0 * M * N)
             nb = A.shape[0] if A.dim() == 3 else 1
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
-            kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, C.stride(-1) != 1)
-            return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K + M * N) + 4.0 * K * N
+            c_planes = C.dtype == torch.int16
+            kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
+                                             split=kw.get('B3') is not None)
+            return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * K * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
             return 'tri_attn_kernel', 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
@@ -66,7 +72,7 @@ class OpTimer:
     def __enter__(self):
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
-            if callable(fn) and not name.startswith('_') and name != 'gemm_kernel_name' and \
+            if callable(fn) and not name.startswith('_') and name not in ('gemm_kernel_name', 'gemm_split_eligible') and \
                     getattr(fn, '__module__', '') == self.ops.__name__:
                 self.saved[name] = fn
 

@@ -59,11 +59,29 @@ typedef struct AbxGemm {
     const float* rowscale; long long sRSb;         /* [b*sRSb + m] or NULL */
     const float* gate; long long sGb, sGm; int gate_sigmoid;   /* addressed like C: (m,n) at gate + b*sGb + m*sGm + n, or */
     const float* resid; long long sRb, sRm;        /* + n*sGm + m when c_transposed; resid likewise and may alias C */
+    /* Split-bf16 operands and output (csrc/gemm3.hip).  A value x is held as three bf16 planes with x = p0 + p1 + p2 exactly;
+     * the planes are k-TILED: element (row, k) of plane p at base + batch*sXb + (k/16)*sXk + p*sXp + row*sXr + k%16, i.e. the
+     * 16 k of one k-tile are contiguous (abx_split_weights writes [Kp/16][3][N][16]: sB3k = 3*N*16, sB3p = N*16, sB3n = 16). */
+    const unsigned short* B_split; long long sB3p, sB3n, sB3k, sB3b;   /* B as planes (sB3b = 0: shared weights); used instead of B */
+    const unsigned short* A_split; long long sA3p, sA3m, sA3k, sA3b;   /* A as planes, used instead of A: the TriangleMultiplication
+                                                      contraction takes both operands this way (K % 16 == 0) */
+    unsigned short* C_split; long long sCp, sCk; int c_split_L;   /* write the output as planes instead of C, laid out as the
+                                                      k-tiled OPERAND of the following contraction: with m = i*L + k (L =
+                                                      c_split_L, transposed store only), element (m, n) of plane p goes to
+                                                      C_split + b*sCb + n*sCm + (k/16)*sCk + p*sCp + i*16 + k%16 */
+    int a_pair_transpose;                          /* L > 0: M == L*L rows per batch are pair positions (i,k); row i*L + k of
+                                                      the GEMM reads source row k*L + i (k-contiguous A, split-bf16 path only) */
+    int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split
+                                                      into 3 bf16 pieces, 6 products, fp32 accumulate - csrc/gemm3.hip);
+                                                      1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) */
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
     int a_vec_ok, b_vec_ok, fast_ok;               /* filled by the library */
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
+/* fp32 weights W[n][k] (element strides s_n, s_k) -> out[Kp/16][3][N][16] bf16 planes with w = p0 + p1 + p2 exactly,
+ * Kp = (K+15)/16*16 (zero padded) */
+int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t stream);
 
 /* LayerNorm statistics (mean, rstd) per row for the LN-on-load GEMM prologue (torch.nn.LayerNorm, eps 1e-5).
  * s_k == 1: rows dense over batch (row stride s_row); else channel-major: element (b,row,k) at x + b*s_b + k*s_k + row. */

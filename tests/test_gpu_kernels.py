@@ -105,6 +105,170 @@ def test_gemm_ln_gate_resid_rowscale(ops):
     check(x, ref_ln, 2e-6, 'layernorm in place')
 
 
+def _host_planes(x):
+    """fp32 tensor (..., rows, K) -> int16 k-tiled bf16 planes (..., K/16, 3, rows, 16), x = p0 + p1 + p2 (RNE pieces)."""
+    p0 = x.bfloat16(); r = x - p0.float(); p1 = r.bfloat16(); p2 = (r - p1.float()).bfloat16()
+    pl = torch.stack([p0.view(torch.int16), p1.view(torch.int16), p2.view(torch.int16)], dim=-3)      # (..., 3, rows, K)
+    rows, K = x.shape[-2:]
+    assert K % 16 == 0
+    pl = pl.reshape(*x.shape[:-2], 3, rows, K // 16, 16)
+    return pl.movedim(-2, -4).contiguous()                                                           # (..., K/16, 3, rows, 16)
+
+
+def _planes_to_f64(pl):
+    """inverse of _host_planes: (..., K/16, 3, rows, 16) int16 -> float64 (..., rows, K)."""
+    f = (pl.to(torch.int32) << 16).view(torch.float32).double().sum(-3)                              # (..., K/16, rows, 16)
+    return f.movedim(-3, -2).reshape(*f.shape[:-3], f.shape[-2], -1)
+
+
+def test_gemm_split_bf16_weight_image(ops):
+    """abx_split_weights: W = p0 + p1 + p2 EXACTLY (three round-to-nearest bf16 pieces), k-tiled, zero padded rows."""
+    for K, N in ((192, 768), (52, 70), (128, 192)):
+        Wt = (torch.randn(K, N, generator=g(200)) * torch.logspace(-6, 3, N)[None]).to(DEV)
+        w3 = ops.split_weights(Wt)
+        Kp = (K + 15) // 16 * 16
+        assert w3.shape == (Kp // 16, 3, N, 16)
+        back = _planes_to_f64(w3.cpu())                                                              # (N, Kp)
+        assert torch.equal(back[:, :K], Wt.cpu().double().t()), 'split is not exact'
+        assert (back[:, K:] == 0).all()
+        # reference split on the host (torch bf16 conversion is round-to-nearest-even like v_cvt_pk_bf16_f32)
+        xp = torch.zeros(N, Kp); xp[:, :K] = Wt.cpu().t()
+        assert torch.equal(w3.cpu(), _host_planes(xp))
+
+
+def _err(x, ref):
+    d = (x.detach().cpu().double() - ref).abs()
+    return float(d.max() / ref.abs().max()), float(d.mean() / ref.abs().mean())
+
+
+def test_gemm_split_bf16_accuracy_vs_exact(ops):
+    """The split-bf16 kernels (gemm3.hip) against float64, next to the exact fp32 MFMA kernel on the same problem: the
+    split path must be as accurate as native fp32 (max error within 1.5x, mean error within 1.2x of the exact kernel)."""
+    for (M, N, K) in ((33000, 192, 192), (66000, 768, 192), (33000, 192, 768), (40000, 128, 192), (70000, 190, 100)):
+        A = (torch.randn(M, K, generator=g(201)) * 3 + 0.7)
+        W = torch.randn(N, K, generator=g(202)) / K ** 0.5
+        b = torch.randn(N, generator=g(203))
+        ref = A.double() @ W.double().t() + b.double()
+        Ad, Wt, bd = A.to(DEV), W.t().contiguous().to(DEV), b.to(DEV)
+        w3 = ops.split_weights(Wt)
+        o_exact = torch.empty(M, N, device=DEV); o_split = torch.full((M, N), float('nan'), device=DEV)
+        ops.gemm(Ad, Wt, o_exact, bias=bd, exact=True)
+        ops.gemm(Ad, Wt, o_split, bias=bd, B3=w3, exact=False)
+        e_x, e_s = _err(o_exact, ref), _err(o_split, ref)
+        assert e_s[0] <= 1.5 * e_x[0] + 1e-8 and e_s[1] <= 1.2 * e_x[1] + 1e-9, (M, N, K, e_x, e_s)
+        assert e_s[0] < 3e-6
+        if K % 16 == 0:
+            if ((M + 127) // 128) * ((N + 127) // 128) >= 512:
+                assert not torch.equal(o_split, o_exact), 'the split-bf16 kernel did not run'
+
+
+def test_gemm_split_bf16_fused_paths(ops):
+    """LayerNorm (inline statistics, mean >> sigma), relu-on-load, gate / residual, transposed store and the channel-major A
+    operand on the split-bf16 kernels, against float64."""
+    M, N, K = 40 * 1000, 192, 192
+    A = torch.randn(M, K, generator=g(204)) * 2 + 0.5
+    W = torch.randn(N, K, generator=g(205)) / K ** 0.5
+    b = torch.randn(N, generator=g(206)); ga = torch.randn(K, generator=g(207)); be = torch.randn(K, generator=g(208))
+    gate = torch.randn(M, N, generator=g(209)); res = torch.randn(M, N, generator=g(210))
+    rs = (torch.rand(M, generator=g(211)) > 0.3).float()
+    Wt, csum, bias2 = fold_ln(W, b, ga, be)
+    w3 = ops.split_weights(Wt)
+    ln = torch.nn.functional.layer_norm(A.double(), (K,), ga.double(), be.double(), 1e-5)
+    ref = ((ln @ W.double().t() + b.double()) * 0.5) * rs.double()[:, None] * torch.sigmoid(gate.double()) + res.double()
+    out = res.to(DEV).clone()
+    ops.gemm(A.to(DEV), Wt, out, bias=bias2, ln=(None, csum), alpha=0.5, rowscale=rs.to(DEV), gate=gate.to(DEV), resid=out, B3=w3)
+    check(out, ref, 3e-6, 'split gemm inline-LN + gate + resid')
+    stats = ops.row_stats(A.to(DEV))
+    out2 = res.to(DEV).clone()
+    ops.gemm(A.to(DEV), Wt, out2, bias=bias2, ln=(stats, csum), alpha=0.5, rowscale=rs.to(DEV), gate=gate.to(DEV), resid=out2, B3=w3)
+    check(out2, ref, 3e-6, 'split gemm LN(stats) + gate + resid')
+    Aoff = A * 0.05 + 300.0
+    refo = torch.nn.functional.layer_norm(Aoff.double(), (K,), ga.double(), be.double(), 1e-5) @ W.double().t() + b.double()
+    outo = torch.empty(M, N, device=DEV)
+    ops.gemm(Aoff.to(DEV), Wt, outo, bias=bias2, ln=(None, csum), B3=w3)
+    check(outo, refo, 2e-5, 'split gemm inline-LN with mean >> std')
+    # relu on load + relu out
+    W2 = W.t().contiguous().to(DEV)
+    ops.gemm(A.to(DEV), W2, outo, bias=b.to(DEV), a_relu=True, act=1, B3=ops.split_weights(W2))
+    check(outo, torch.relu(torch.relu(A.double()) @ W.double().t() + b.double()), 3e-6, 'split gemm relu-on-load')
+    # transposed store with LN, mask and channel-major gates; ragged pair length (L = 203: M = 41209 rows per sample)
+    B_, L_ = 2, 203
+    LL = L_ * L_
+    Z = torch.randn(B_, LL, K, generator=g(212))
+    Wp = torch.randn(128, K, generator=g(213)) / K ** 0.5
+    bp = torch.randn(128, generator=g(214))
+    GT = torch.rand(B_, 128, LL, generator=g(215))
+    pm = (torch.rand(B_ * LL, generator=g(216)) > 0.2).float()
+    Wt2, csum2, bias3 = fold_ln(Wp, bp, ga, be)
+    outT = torch.full((B_, 128, LL), float('nan'), device=DEV)
+    ops.gemm(Z.to(DEV), Wt2, outT.transpose(1, 2), bias=bias3, ln=(None, csum2), rowscale=pm.to(DEV),
+             gate=GT.to(DEV).transpose(1, 2), gate_sigmoid=False, B3=ops.split_weights(Wt2))
+    lnz = torch.nn.functional.layer_norm(Z.double(), (K,), ga.double(), be.double(), 1e-5)
+    refT = ((lnz @ Wp.double().t() + bp.double()) * pm.double().view(B_, LL, 1) * GT.double().transpose(1, 2)).transpose(1, 2)
+    check(outT, refT, 3e-6, 'split gemm transposed store')
+    # channel-major A (m-contiguous) with inline LN + gate + residual in place: the tri-mul output projection
+    B_, L_ = 2, 204
+    LL = L_ * L_
+    T = torch.randn(B_, 128, LL, generator=g(217)) * 4
+    Wo = torch.randn(192, 128, generator=g(218)) / 128 ** 0.5
+    bo = torch.randn(192, generator=g(219)); g2 = torch.randn(128, generator=g(220)); b2 = torch.randn(128, generator=g(221))
+    Wt3, csum3, bias4 = fold_ln(Wo, bo, g2, b2)
+    Gf = torch.rand(B_, LL, 192, generator=g(222))
+    z3 = torch.randn(B_, LL, 192, generator=g(223))
+    zd = z3.to(DEV).clone()
+    ops.gemm(T.to(DEV).transpose(1, 2), Wt3, zd, bias=bias4, ln=(None, csum3), gate=Gf.to(DEV), gate_sigmoid=False, resid=zd,
+             B3=ops.split_weights(Wt3))
+    lnt = torch.nn.functional.layer_norm(T.double().transpose(1, 2), (128,), g2.double(), b2.double(), 1e-5)
+    check(zd, (lnt @ Wo.double().t() + bo.double()) * Gf.double() + z3.double(), 3e-6, 'split gemm channel-major A')
+
+
+def test_gemm_split_bf16_contractions(ops):
+    """TriangleMultiplication einsum (seqformer.py:490-493) on the split-bf16 kernels: both operands as bf16 planes."""
+    for nb, L_ in ((640, 80), (512, 128), (260, 208), (130, 352)):
+        X = torch.randn(nb, L_, L_, generator=g(230)) * 2
+        Y = torch.randn(nb, L_, L_, generator=g(231))
+        Xd, Yd = X.to(DEV), Y.to(DEV)
+        out = torch.full((nb, L_, L_), float('nan'), device=DEV); oe = torch.empty(nb, L_, L_, device=DEV)
+        r_out = torch.einsum('bik,bjk->bij', X.double(), Y.double())
+        ops.gemm(_host_planes(X).to(DEV), _host_planes(Y).to(DEV), out)
+        ops.gemm(Xd, Yd.transpose(1, 2), oe, exact=True)
+        e_s, e_x = _err(out, r_out), _err(oe, r_out)
+        assert e_s[0] <= 1.5 * e_x[0] + 1e-8 and e_s[1] <= 1.2 * e_x[1] + 1e-9 and e_s[0] < 3e-6, ('NT', nb, L_, e_s, e_x)
+
+
+def test_gemm_split_bf16_plane_output_and_pair_transpose(ops):
+    """The projection GEMMs of the triangle multiplication: transposed store as bf16 planes (C_split) and the pair-transposed
+    row gather (a_pair_transpose) of the incoming variant."""
+    B_, L_, K, C_ = 5, 120, 192, 128
+    LL = L_ * L_
+    Z = torch.randn(B_, L_, L_, K, generator=g(240)) * 1.5 + 0.3
+    W = torch.randn(C_, K, generator=g(241)) / K ** 0.5
+    bias = torch.randn(C_, generator=g(242)); ga = torch.randn(K, generator=g(243)); be = torch.randn(K, generator=g(244))
+    GT = torch.rand(B_, C_, LL, generator=g(245))
+    pm = (torch.rand(B_, L_, L_, generator=g(246)) > 0.2).float()
+    Wt, csum, bias2 = fold_ln(W, bias, ga, be)
+    w3 = ops.split_weights(Wt)
+    ln = torch.nn.functional.layer_norm(Z.double(), (K,), ga.double(), be.double(), 1e-5)
+    proj = (ln @ W.double().t() + bias.double()) * pm.double()[..., None]                     # (B, L, L, C)
+    for transpose in (False, True):
+        zsrc = Z.to(DEV).view(B_, LL, K)
+        planes = torch.zeros(B_, C_, (L_ + 15) // 16, 3, L_, 16, dtype=torch.int16, device=DEV)
+        # gates / mask are indexed by the GEMM row (i.e. already in the transposed order when a_pair_transpose is used)
+        pmv = (pm.transpose(1, 2) if transpose else pm).reshape(-1).contiguous().to(DEV)
+        ops.gemm(zsrc, Wt, planes, bias=bias2, ln=(None, csum), rowscale=pmv,
+                 gate=GT.to(DEV).transpose(1, 2), gate_sigmoid=False, B3=w3, a_pair_transpose=L_ if transpose else 0)
+        got = _planes_to_f64(planes.cpu())[..., :L_].reshape(B_, C_, LL)                          # (B, C, L, Kp) -> (B, C, LL)
+        want = (proj.transpose(1, 2) if transpose else proj).reshape(B_, LL, C_).transpose(1, 2) * GT.double()
+        e = float((got - want).abs().max() / want.abs().max())
+        assert e < 3e-6, (transpose, e)
+        # the three planes carry EXACTLY the fp32 values the same GEMM stores as fp32; the k padding stays 0
+        o32 = torch.empty(B_, C_, LL, device=DEV)
+        ops.gemm(zsrc, Wt, o32.transpose(1, 2), bias=bias2, ln=(None, csum), rowscale=pmv,
+                 gate=GT.to(DEV).transpose(1, 2), gate_sigmoid=False, B3=w3, a_pair_transpose=L_ if transpose else 0)
+        assert torch.equal(got.float(), o32.cpu()), 'plane output differs from the fp32 output'
+        assert (_planes_to_f64(planes.cpu())[..., L_:] == 0).all()
+
+
 def test_gemm_layouts_batched_transposed(ops):
     nb, M, N, K = 5, 72, 72, 72       # L = 72 triangle contraction shapes (not multiples of the tiles)
     X = torch.randn(nb, M, K, generator=g(12))

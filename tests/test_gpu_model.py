@@ -172,6 +172,48 @@ def test_medium_complex_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
     close(ret['heads']['predicted_lddt']['pLDDT'], ref['heads']['predicted_lddt']['pLDDT'], 5e-3, 1e-4, 'pLDDT')
 
 
+def test_split_bf16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
+    """L = 120 (k padding: 120 -> 128), 5 samples in one chunk: large enough for the split-bf16 GEMM kernels, so the triangle
+    multiplication runs through the bf16-plane projections (C_split), the pair-transposed row gather of the incoming variant
+    and the plane contraction.  One full call (3 passes) HIP vs oracle, then the same call on the exact fp32 MFMA kernels."""
+    from oracle import abx_oracle as O
+    from abx_amd import sampler, ops
+    model, D = gpu_model
+    w = dict(L_heavy=50, L_light=44, L_antigen=26, cdr=(30, 39))
+    B = 5
+    assert ops.gemm_split_eligible(120 * 120, 128, 192, B)
+    b = _synthetic_batch(D, w, B=B, n_masked_tail=3)
+    t_ = torch.full((B,), 0.4040404040404041, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else tuple(x.cpu() for x in v) if isinstance(v, tuple) else v) for k, v in b.items()}
+
+    def run(exact):
+        bb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+        ops.GEMM_EXACT = exact
+        try:
+            model.max_chunk = 16
+            model.invalidate_static()
+            r = model(bb)
+            torch.cuda.synchronize()
+        finally:
+            ops.GEMM_EXACT = False
+        # the returned tensors live in the model's ping-pong buffers: copy them before the next call overwrites them
+        cp = lambda d: {k: (cp(v) if isinstance(v, dict) else v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+        return cp(r)
+
+    ret, rex = run(False), run(True)
+    ref = O.score_network(params, cpu, cfg, oracle_diffuser)
+    for tag, r in (('exact', rex), ('split', ret)):
+        f, fr = r['heads']['folding'], ref['heads']['folding']
+        agree = (r['heads']['sequence_module']['seq_0'].cpu() == ref['heads']['sequence_module']['seq_0']).float().mean()
+        assert agree == 1.0, f'{tag}: seq_0 agreement {agree}'
+        close(r['representations']['pair'], ref['representations']['pair'], 3e-4, 1e-4, tag + ' pair')
+        close(f['rigids'], fr['rigids'], 2e-4, 1e-4, tag + ' rigids')
+        close(f['final_atom14_positions'], fr['final_atom14_positions'], 1e-3, 1e-4, tag + ' atom14')
+        close(r['heads']['sequence_module']['logits'], ref['heads']['sequence_module']['logits'], 3e-4, 1e-4, tag + ' logits')
+    assert not torch.equal(ret['representations']['pair'], rex['representations']['pair']), 'both runs took the same kernels'
+
+
 def test_full_size_properties(gpu_model, cfg):
     """BASELINE-scale length (L = 352): finite outputs, sample-permutation equivariance, shared-context == per-sample
     context, chunking invariance (bit-exact: every kernel is batch-independent)."""

@@ -34,7 +34,19 @@ def main():
     ap.add_argument('--bc', type=int, default=10)
     ap.add_argument('--L', type=int, default=352)
     ap.add_argument('--only', default='')
+    ap.add_argument('--exact', action='store_true', help='exact fp32 MFMA GEMM kernels instead of the split-bf16 ones')
     a = ap.parse_args()
+    ops.GEMM_EXACT = a.exact
+    _gemm, _splits = ops.gemm, {}
+
+    def gemm_with_split(A, B, Cout, **kw):       # weight GEMMs get their pre-split bf16 image, like model/forward.py does
+        if not a.exact and B.dim() == 2 and B.stride(1) == 1 and B.shape[1] > 64 and 'B3' not in kw:
+            key = (B.data_ptr(), tuple(B.shape))
+            if key not in _splits:
+                _splits[key] = ops.split_weights(B)
+            kw['B3'] = _splits[key]
+        return _gemm(A, B, Cout, **kw)
+    ops.gemm = gemm_with_split
     Bc, L = a.bc, a.L
     LL, M2, M1 = L * L, Bc * L * L, Bc * L
     only = set(a.only.split(',')) if a.only else None
@@ -72,7 +84,9 @@ def main():
         left = torch.empty(Bc, 128, LL, device=DEV)
         W = r(192, 128) / 14
         bias, csum = r(128), r(128)
-        ms = timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(None, csum), rowscale=pm, gate=G[:, :, :128]))
+        GT = torch.rand(Bc, 256, LL, device=DEV)
+        ms = timeit(lambda: ops.gemm(z3, W, left.transpose(1, 2), bias=bias, ln=(None, csum), rowscale=pm,
+                                     gate=GT[:, :128].transpose(1, 2), gate_sigmoid=False))
         rec('gemm tri-mul proj (LN, gate, transposed store)', ms, 2.0 * M2 * 128 * 192, 4.0 * M2 * (192 + 128 + 128))
         lz, rz, tz = left.view(Bc * 128, L, L), torch.randn_like(left).view(Bc * 128, L, L), torch.empty(Bc * 128, L, L, device=DEV)
         ms = timeit(lambda: ops.gemm(lz, rz.transpose(1, 2), tz))
@@ -83,7 +97,8 @@ def main():
         st2 = ops.row_stats(tcm)
         W2 = r(128, 192) / 11
         b2, c2 = r(192), r(192)
-        ms = timeit(lambda: ops.gemm(tcm, W2, z3, bias=b2, ln=(None, c2), gate=G[:, :, 256:448], resid=z3))
+        Gf = torch.rand(Bc, LL, 192, device=DEV)
+        ms = timeit(lambda: ops.gemm(tcm, W2, z3, bias=b2, ln=(None, c2), gate=Gf, gate_sigmoid=False, resid=z3))
         rec('gemm tri-mul out (channel-major A, LN, gate)', ms, 2.0 * M2 * 192 * 128, 4.0 * M2 * (128 + 192 * 3))
         ms = timeit(lambda: ops.row_stats(z, stats))
         rec('row_stats (M2 x 192)', ms, 0, 4.0 * M2 * 192)
@@ -106,6 +121,19 @@ def main():
                     kw['ln'] = (stats, csum)
                 ms = timeit(lambda: ops.gemm(A, W, C, **kw))
                 rec(f'gemm {N}x{K} tune={tune} (noremap={tune & 1}, variant={tune >> 1})', ms, 2.0 * M2 * N * K)
+    if only and 'ksweep' in only:
+        for N in (192, 768, 128):
+            for K in (16, 64, 192, 384, 768, 1536):
+                A, W, C = r(M2, K), r(K, N) / K ** 0.5, torch.empty(M2, N, device=DEV)
+                ms = timeit(lambda: ops.gemm(A, W, C))
+                rec(f'ksweep N={N} K={K}', ms, 2.0 * M2 * N * K, 4.0 * M2 * (N + K))
+    if only and 'ablate' in only:
+        for N, K in ((192, 1536), (768, 768)):
+            A, W, C = r(M2, K), r(K, N) / K ** 0.5, torch.empty(M2, N, device=DEV)
+            for tune, tag in ((0, 'full'), (16, 'no MFMA'), (32, 'no A dma'), (64, 'no W dma'), (96, 'no dma'), (128, 'no split'),
+                              (16 + 128, 'no MFMA, no split'), (96 + 128, 'MFMA + LDS reads only'), (2, '128x128 tile')):
+                ms = timeit(lambda: ops.gemm(A, W, C, tune=tune))
+                rec(f'ablate N={N} K={K} {tag}', ms, 2.0 * M2 * N * K)
     if only and 'tm' in only:
         z = r(M2, 192); z3 = z.view(Bc, LL, 192)
         G = r(Bc, LL, 448)
