@@ -51,12 +51,11 @@ __device__ __forceinline__ int plane_off(int plane, int row, int half) {
     return plane * (ROWS * 32) + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
 }
 
-// DMA source pointers of one wave for a [3][ROWS][16] bf16 plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
+// DMA source byte offsets (from the operand's batch base) of one wave for a [3][ROWS][16] bf16 plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
 // Surplus chunks (image not a multiple of 4 KB) and rows past the matrix re-read a valid row; their LDS bytes are never used
 // for valid outputs.
 template <int ROWS, int NL>
-__device__ __forceinline__ void plane_sources(const unsigned short* base, long long s_plane, long long s_row, int r0, int R,
-                                              const char* (&src)[NL]) {
+__device__ __forceinline__ void plane_sources(long long s_plane, long long s_row, int r0, int R, unsigned (&off)[NL]) {
     // (the k-tile stride is applied by the caller: one k-tile = 16 consecutive k of every row)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -67,7 +66,7 @@ __device__ __forceinline__ void plane_sources(const unsigned short* base, long l
         const int row = rem >> 5, hp = (rem >> 4) & 1;
         const int half = hp ^ ((row >> 3) & 1);
         const int gr = min(r0 + row, R - 1);
-        src[i] = reinterpret_cast<const char*>(base + plane * s_plane + (long long)gr * s_row + 8 * half);
+        off[i] = (unsigned)((plane * s_plane + (long long)gr * s_row + 8 * half) * 2);
     }
 }
 
@@ -88,47 +87,52 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int h = lane >> 5;
 
-    // ---- per-lane DMA source pointers (tile 0); each k-tile advances them by 16 elements along k
-    const char* srcA[NLA];
-    const char* srcB[NLB];
+    // ---- DMA sources: a block-uniform base pointer (advanced per k-tile) plus per-lane 32-bit byte offsets, so the loads
+    // use the scalar-base addressing form and cost no vector address arithmetic in the loop
+    unsigned offsA[NLA], offsB[NLB];
+    const char* baseA;
     long long a_step;                                          // bytes per k-tile
     if constexpr (AMODE == 0) {
-        const float* Ab = g.A + (long long)b * g.sAb;
+        baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int r = (wave * NLA + i) * 16 + (lane >> 2), p = lane & 3;
             const int kq = p ^ ((r >> 2) & 3);                 // physical 16-byte slot p of row r holds logical k-quad kq
             long long gr = min(m0 + r, g.M - 1);
             if (g.a_pair_transpose > 0) gr = (gr % g.a_pair_transpose) * g.a_pair_transpose + gr / g.a_pair_transpose;
-            srcA[i] = reinterpret_cast<const char*>(Ab + gr * g.sAm + kq * 4);
+            offsA[i] = (unsigned)((gr * g.sAm + kq * 4) * 4);
         }
         a_step = BK * 4;
     } else if constexpr (AMODE == 1) {
-        const float* Ab = g.A + (long long)b * g.sAb;
+        baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int kl = (wave * NLA + i) * 2 + (lane >> 5), mq = lane & 31;     // LDS [k][BM]: 2 k-rows per instruction
             const int gm = min(m0 + mq * 4, g.M - 4);
-            srcA[i] = reinterpret_cast<const char*>(Ab + (long long)kl * g.sAk + gm);
+            offsA[i] = (unsigned)(((long long)kl * g.sAk + gm) * 4);
         }
         a_step = (long long)BK * g.sAk * 4;
     } else {
-        plane_sources<BM, NLA>(g.A_split + (long long)b * g.sA3b, g.sA3p, g.sA3m, m0, g.M, srcA);
+        baseA = reinterpret_cast<const char*>(g.A_split + (long long)b * g.sA3b);
+        plane_sources<BM, NLA>(g.sA3p, g.sA3m, m0, g.M, offsA);
         a_step = g.sA3k * 2;
     }
-    plane_sources<BN, NLB>(g.B_split + (long long)b * g.sB3b, g.sB3p, g.sB3n, n0, g.N, srcB);
+    const char* baseB = reinterpret_cast<const char*>(g.B_split + (long long)b * g.sB3b);
+    plane_sources<BN, NLB>(g.sB3p, g.sB3n, n0, g.N, offsB);
     const long long b_step = g.sB3k * 2;
     const int nk = g.K / BK;
 
     auto issue_a = [&](int tile) {          // tile index clamped by the caller
         char* dst = As + (tile % 3) * A_STAGE + wave * NLA * 1024;
+        const char* src = baseA + tile * a_step;
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) glds16(srcA[i] + tile * a_step, dst + i * 1024);
+        for (int i = 0; i < NLA; ++i) glds16(src + offsA[i], dst + i * 1024);
     };
     auto issue_b = [&](int tile) {
         char* dst = Bs + (tile & 1) * B_STAGE + wave * NLB * 1024;
+        const char* src = baseB + tile * b_step;
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) glds16(srcB[i] + tile * b_step, dst + i * 1024);
+        for (int i = 0; i < NLB; ++i) glds16(src + offsB[i], dst + i * 1024);
     };
 
     f32x16 acc[TM][TN];
@@ -172,16 +176,12 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
 
     for (int t = 0; t < nk; ++t) {
         // next tiles: B(t+1) first, then A(t+2): the wait at the end of this step leaves only A(t+2) outstanding
-        if (!(g.tune & 64)) issue_b(min(t + 1, nk - 1));
-        if (!(g.tune & 32)) issue_a(min(t + 2, nk - 1));
+        issue_b(min(t + 1, nk - 1));
+        issue_a(min(t + 2, nk - 1));
 
         const char* as = As + (t % 3) * A_STAGE;
         const char* bs = Bs + (t & 1) * B_STAGE;
-        bf16x8 a[TM][3], bb[TN][3];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bb[j][p] = *reinterpret_cast<const bf16x8*>(bs + offB[j] + p * (BN * 32));
+        bf16x8 a[TM][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if constexpr (AMODE == 2) {
@@ -214,10 +214,6 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
                     for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
                 }
                 unsigned q0[4], q1[4], q2[4];
-                if (g.tune & 128) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { q0[e] = __float_as_uint(x[2 * e]); q1[e] = __float_as_uint(x[2 * e + 1]); q2[e] = q0[e] ^ q1[e]; }
-                } else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], q0[e], q1[e], q2[e]);
                 a[i][0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
@@ -225,19 +221,27 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
                 a[i][2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
             }
         }
-        // six product terms, smallest first; consecutive MFMAs hit different accumulators
+        // six product terms, smallest first; the B fragments are fetched per group of JG sub-tiles (register budget);
+        // consecutive MFMAs hit different accumulators
         constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
         constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
-        if (!(g.tune & 16))
+        constexpr int JG = TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN;
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
+        for (int j0 = 0; j0 < TN; j0 += JG) {
+            bf16x8 bb[JG][3];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < JG; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j], 0, 0, 0);
-        if (g.tune & 96) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else wait_vm_and_barrier<NLA>();
+                for (int p = 0; p < 3; ++p) bb[j][p] = *reinterpret_cast<const bf16x8*>(bs + offB[j0 + j] + p * (BN * 32));
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < JG; ++j)
+                        acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
+        }
+        wait_vm_and_barrier<NLA>();
     }
     // drain the (redundant) tail DMA before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_STAGE = (A_IMG + 4095) / 4096 * 4096;
     constexpr int B_STAGE = (3 * BN * 32 + 4095) / 4096 * 4096;
     constexpr int OPER = (3 * A_STAGE + 2 * B_STAGE) / 4;                          // floats
-    constexpr int SCR = 4 * 32 * ((TS ? WM : WN) + 4);
+    constexpr int SCR = 4 * 32 * ((TS ? WM : (WN > 96 ? 96 : WN)) + 4);
     constexpr int EPI = 2 * BM + SCR;
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntn = (g.N + BN - 1) / BN;
@@ -339,10 +343,31 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     } else {
         if (!al16(g.A) || g.sAk % 4 != 0 || g.sAb % 4 != 0 || g.M % 4 != 0 || g.M < 4 || g.a_pair_transpose > 0) return 1;
     }
+    // 128x128 tiles run 3 blocks per CU (48 KB LDS, ~150 VGPRs), 128x192 tiles 2: the narrow tile wins whenever it wastes no
+    // columns (N = 768: q|k|v|gate, transition hidden); N = 192 / 448 take the wide tile
+    // per-lane DMA offsets are 32-bit: one batch of an operand must span less than 4 GB
+    if (!g.A_split && ((g.sAk == 1 ? (long long)g.M * g.sAm : (long long)g.K * g.sAk) >= (1LL << 30))) return 1;
+    if (g.A_split && (long long)(g.K / 16) * g.sA3k >= (1LL << 31)) return 1;
+    if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
     const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;
-    if (pad192 <= pad128 && !((g.tune >> 1) & 7)) *rc = launch3<128, 192, 64, 96, 2>(g, st);
-    else *rc = launch3<128, 128, 64, 64, 2>(g, st);
+    const int force = (g.tune >> 1) & 7;                       // 1: 128x128, 2: 128x192 (benchmarking)
+    const bool wide = force ? force == 2 : (pad192 <= pad128 && g.N % 128 != 0);
+    // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
+    // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
+    if (wide) *rc = launch3<128, 192, 32, 192, 2>(g, st);
+    else *rc = launch3<128, 128, 32, 128, 2>(g, st);
     return 0;
+}
+
+// resident workgroups per CU of the main instantiations (diagnostics for tools/kbench.py)
+extern "C" int abx_gemm3_occupancy(int which) {
+    int n = -1;
+    hipError_t e = hipErrorInvalidValue;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 0, false, 2>), 256, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, false, 2>), 256, 0);
+    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, true, 2>), 256, 0);
+    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 2, false, 2>), 256, 0);
+    return e == hipSuccess ? n : -(int)e - 1000;
 }
 
 extern "C" int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t st) {

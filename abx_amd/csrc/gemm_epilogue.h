@@ -90,44 +90,51 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
         }
     };
     if constexpr (!TS) {
-        // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][WN + 4] and leaves as float4 along n
-        constexpr int LW = WN + 4, C4 = WN / 4, NQ = 32 * C4 / 64;
+        // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][GW + 4] in column groups of GW <= 96
+        // and leaves as float4 along n
+        constexpr int TG = TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN;     // sub-tiles per column group
+        static_assert(TN % TG == 0, "column groups");
+        constexpr int GW = TG * 32, LW = GW + 4, C4 = GW / 4, NQ = 32 * C4 / 64;
         float* wsc = scratch + wave * (32 * LW);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
+            for (int jg = 0; jg < TN; jg += TG) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int mloc = 8 * rq + 4 * (lane >> 5) + c;
-                    const int ml = wm * WM + i * 32 + mloc;
+                for (int rq = 0; rq < 4; ++rq) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) wsc[mloc * LW + j * 32 + (lane & 31)] = epi1(acc[i][j][rq * 4 + c], ml, j);
+                    for (int c = 0; c < 4; ++c) {
+                        const int mloc = 8 * rq + 4 * (lane >> 5) + c;
+                        const int ml = wm * WM + i * 32 + mloc;
+#pragma unroll
+                        for (int j = 0; j < TG; ++j)
+                            wsc[mloc * LW + j * 32 + (lane & 31)] = epi1(acc[i][jg + j][rq * 4 + c], ml, jg + j);
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 6
+                for (int q = 0; q < NQ; ++q) {          // 6 rows of gate / residual loads in flight per lane, not NQ
+                    const int f = lane + 64 * q;
+                    const int row = f / C4, c4 = f % C4;
+                    const int m = m0 + wm * WM + i * 32 + row;
+                    const int n = n0 + wn * WN + jg * 32 + c4 * 4;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[row * LW + c4 * 4]);
+                    int cnt = 4;
+                    if (EDGE) {
+                        if (m >= g.M || n >= g.N) continue;
+                        cnt = min(4, g.N - n);
+                    }
+                    if (rs) {
+                        const float s = rs[m];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] *= s;
+                    }
+                    epi2_store(v, (long long)m * g.sCm + n, (long long)m * g.sGm + n, (long long)m * g.sRm + n, cnt, m, n);
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int f = lane + 64 * q;
-                const int row = f / C4, c4 = f % C4;
-                const int m = m0 + wm * WM + i * 32 + row;
-                const int n = n0 + wn * WN + c4 * 4;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[row * LW + c4 * 4]);
-                int cnt = 4;
-                if (EDGE) {
-                    if (m >= g.M || n >= g.N) continue;
-                    cnt = min(4, g.N - n);
-                }
-                if (rs) {
-                    const float s = rs[m];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] *= s;
-                }
-                epi2_store(v, (long long)m * g.sCm + n, (long long)m * g.sGm + n, (long long)m * g.sRm + n, cnt, m, n);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     } else {
         // transposed store (C, gate and resid are all addressed [n][m], m contiguous): each 32-column sub-tile goes through the

@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2516.6     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32-accurate product = 6 bf16 MFMA products (csrc/gemm3.hip)
 
 
 def algorithmic_bytes_per_sample_step(L):
@@ -260,6 +262,9 @@ def main():
         'metric': 'diffusion-steps/sec (100 samples, ~350-res complex)', 'value': value, 'unit': 'sample-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'dtype_note': 'fp32 storage and accumulation everywhere; the large pair-stack GEMMs evaluate each fp32 product from '
+                      '3-way bf16 operand splits (6 MFMA products, fp32 accumulate: as accurate as the native fp32 MFMA, '
+                      'tests/test_gpu_kernels.py), everything else is native fp32 / fp64',
         'config': {'workload': f'{args.workload}: L={L} (Lab {w["L_heavy"] + w["L_light"]} + antigen {w["L_antigen"]}), '
                                f'{B} samples/GPU of one complex, 1 step = ScoreNetwork (3 passes) + get_prev + reverse, '
                                'seeded random weights, ESM off', 'L': L, 'samples_per_gpu': B, 'chunk': args.chunk},
@@ -278,9 +283,19 @@ def main():
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
         if name.startswith('ipa_attn'):
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+        elif name.startswith('gemm3_kernel'):
+            # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs six bf16 MFMA
+            # products, so the ceiling is the dense bf16 peak / 6
+            roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_SPLIT_PEAK_TF, 'unit': 'TFLOP/s',
+                    'peak_note': 'dense bf16 MFMA peak 2516.6 TF / 6 products per fp32-accurate product; '
+                                 f'{fl / dur / 1e12 / MFMA_F32_PEAK_TF:.2f} of the native fp32 MFMA peak 157.3 TF'}
         else:
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s'}
-        roof.update(frac=roof['achieved'] / roof['peak'], traffic=None, kernel=name, calls_per_step=calls,
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc):             # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
+            traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
+        roof.update(frac=roof['achieved'] / roof['peak'], traffic=traffic, kernel=name, calls_per_step=calls,
                     avg_launch_ms=ms / calls, share_of_step=ms / total)
         result['roofline'] = roof
         result['op_profile_ms'] = [{'op': s[0], 'ms': round(s[1], 3), 'calls': s[2],

@@ -127,6 +127,15 @@ def main():
                 A, W, C = r(M2, K), r(K, N) / K ** 0.5, torch.empty(M2, N, device=DEV)
                 ms = timeit(lambda: ops.gemm(A, W, C))
                 rec(f'ksweep N={N} K={K}', ms, 2.0 * M2 * N * K, 4.0 * M2 * (N + K))
+    if only and 'shapes' in only:
+        for N, K in ((768, 192), (192, 768), (192, 192), (192, 128), (448, 192)):
+            A, W, C = r(M2, K), r(K, N) / K ** 0.5, torch.empty(M2, N, device=DEV)
+            bias, csum = r(N), r(N)
+            for tune, tag in ((0, 'default'), (2, '128x128'), (1, 'default, no xcd remap'), (3, '128x128 no remap')):
+                ms = timeit(lambda: ops.gemm(A, W, C, bias=bias, ln=(None, csum), tune=tune))
+                rec(f'shape N={N} K={K} {tag}', ms, 2.0 * M2 * N * K, 4.0 * M2 * (N + K))
+            ms = timeit(lambda: ops.gemm(A, W, C, bias=bias, ln=(None, csum), exact=True))
+            rec(f'shape N={N} K={K} exact fp32', ms, 2.0 * M2 * N * K, 4.0 * M2 * (N + K))
     if only and 'ablate' in only:
         for N, K in ((192, 1536), (768, 768)):
             A, W, C = r(M2, K), r(K, N) / K ** 0.5, torch.empty(M2, N, device=DEV)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""HBM bytes per launch per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) over
+the same bench command -> profiles/pmc_traffic.json, read by bench.py for roofline.traffic.
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py --steps 1 ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 1 ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json
+Corrections (MI355X_MICROARCH.md, HBM section; checked against a known byte count in profiles/r01c_pmc_gemm.txt):
+FETCH_SIZE is in KB and counts 128-byte requests as 64 bytes on gfx950 -> bytes = KB * 1024 * 2; WRITE_SIZE bytes = KB * 1024."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    name = re.sub(r'\(Abx\w+\)$', '', name)
+    name = re.sub(r'\(.*\)$', '', name)
+    return name.strip()
+
+
+def collect(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        per_dispatch = defaultdict(float)
+        names = {}
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') != counter:
+                continue
+            key = (f, row['Dispatch_Id'])
+            per_dispatch[key] += float(row['Counter_Value'])
+            names[key] = short(row['Kernel_Name'])
+        for k, v in per_dispatch.items():
+            acc[names[k]].append(v)
+    return acc
+
+
+def main(fetch_dir, write_dir, out):
+    fe, wr = collect(fetch_dir, 'FETCH_SIZE'), collect(write_dir, 'WRITE_SIZE')
+    res = {}
+    for k in sorted(set(fe) | set(wr)):
+        f = sum(fe.get(k, [0])) / max(len(fe.get(k, [])), 1) * 1024 * 2
+        w = sum(wr.get(k, [0])) / max(len(wr.get(k, [])), 1) * 1024
+        res[k] = {'launches': len(fe.get(k, [])), 'hbm_read_bytes_per_launch': f, 'hbm_write_bytes_per_launch': w,
+                  'hbm_bytes_per_launch': f + w}
+    json.dump(res, open(out, 'w'), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
+        print(f"{k[:70]:70s} n={v['launches']:5d} read {v['hbm_read_bytes_per_launch'] / 1e6:9.1f} MB write {v['hbm_write_bytes_per_launch'] / 1e6:9.1f} MB")
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:4])
