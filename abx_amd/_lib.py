@@ -51,6 +51,7 @@ class AbxTriAttn(C.Structure):
         ('out', c_f), ('ob', LL), ('os', LL), ('ol', LL),
         ('B', I), ('S', I), ('L', I), ('H', I), ('D', I),
         ('scale', F),
+        ('exact', I),
     ]
 
 

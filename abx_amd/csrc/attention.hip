@@ -214,6 +214,251 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
     }
 }
 
+// ---- triangle attention on the bf16 matrix cores (split-bf16, see gemm3.hip for the arithmetic) ------------------------------
+// Same (b, row s, head h) decomposition, online softmax and swapped S^T / O^T products as tri_attn_kernel, but both contractions
+// run on v_mfma_f32_16x16x32_bf16 with every fp32 operand written exactly as three bf16 pieces (6 products, fp32 accumulate:
+// fp32-accurate, 2.3x less matrix-core time than the exact v_mfma_f32_16x16x4_f32 kernel at head dim 48).
+//   K, V are split ONCE per block while they are staged, in chunks of 192 keys (so any L fits the LDS):
+//     K planes  [3][key][48 d]  bf16,  96-byte rows     -> A operand of S^T = K Q^T   (lane: key, 8 consecutive d)
+//     V^T planes [3][d][key']   bf16, 416-byte rows     -> A operand of O^T += V^T P  (lane: d, 8 keys in accumulator order)
+//   Q is split per query tile in registers, P per key tile in registers (the S^T accumulators of two 16-key sub-blocks are
+//   exactly the 8 keys a lane feeds to one PV MFMA; V^T is stored in that key order).
+//   The running (max, sum, O^T) of a wave's query tiles live in registers across the key chunks.
+constexpr int KCH = 192;                 // keys per chunk (3 tiles of 64)
+constexpr int KST = 96;                  // bytes per key row of a K plane: 32 * odd -> the 16-byte fragment reads (lane -> row, lane >> 4 -> 16-byte
+constexpr int VST = KCH * 2 + 32;        // column) of a ds_read_b128 lane group fall on 64 distinct banks; same for the V^T rows (416 = 32 * 13)
+constexpr int K_PLANE = KCH * KST, V_PLANE = TD * VST;
+
+template <int MAXQ>
+__global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Kp = reinterpret_cast<char*>(smem);
+    char* Vp = Kp + 3 * K_PLANE;
+    float* Ms = reinterpret_cast<float*>(Vp + 3 * V_PLANE);      // [KCH] additive key-mask codes of the chunk + 1 flag
+    const int L = a.L;
+    const int h = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
+    const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
+    const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
+    const int nqt = (L + 15) / 16;
+    const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && (L % 4 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
+    const float qscale = a.scale * LOG2E;
+
+    float m_run[MAXQ], l_run[MAXQ];
+    f32x4 o[MAXQ][3];
+#pragma unroll
+    for (int sl = 0; sl < MAXQ; ++sl) {
+        m_run[sl] = -INFINITY;
+        l_run[sl] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[sl][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int c0 = 0; c0 < L; c0 += KCH) {
+        const int nkeys = min(KCH, L - c0);                    // valid keys of this chunk
+        const int nkt = (nkeys + 63) / 64;
+        __syncthreads();                                        // the previous chunk has been consumed
+        // ---- stage + split K, V of keys [c0, c0 + nkt * 64): 12 float4 per key; padded keys are zero
+        for (int idx = tid; idx < nkt * 64 * (TD / 4); idx += TRI_THREADS) {
+            const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (kk < nkeys) {
+                const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
+                kv = *reinterpret_cast<const f32x4*>(a.k + off);
+                vv = *reinterpret_cast<const f32x4*>(a.v + off);
+            }
+            unsigned a0, a1, a2, b0, b1, b2;
+            split2(kv[0], kv[1], a0, a1, a2);
+            split2(kv[2], kv[3], b0, b1, b2);
+            char* kd = Kp + kk * KST + c4 * 8;
+            *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
+            *reinterpret_cast<u32x2*>(kd + K_PLANE) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(kd + 2 * K_PLANE) = u32x2{a2, b2};
+            // V^T: key position inside its 32-key group follows the S^T accumulator order (rows 4g + r of two 16-key sub-blocks)
+            const int o32 = kk & 31, og = (o32 & 15) >> 2, oe = (o32 & 3) + ((o32 >> 4) << 2);
+            const int pos = (kk & ~31) + og * 8 + oe;
+            split2(vv[0], vv[1], a0, a1, a2);
+            split2(vv[2], vv[3], b0, b1, b2);
+            unsigned short* vd = reinterpret_cast<unsigned short*>(Vp + (c4 * 4) * VST) + pos;
+            constexpr int VS2 = VST / 2, VP2 = V_PLANE / 2;
+            vd[0] = (unsigned short)(a0 & 0xffffu); vd[VS2] = (unsigned short)(a0 >> 16);
+            vd[2 * VS2] = (unsigned short)(b0 & 0xffffu); vd[3 * VS2] = (unsigned short)(b0 >> 16);
+            vd[VP2] = (unsigned short)(a1 & 0xffffu); vd[VP2 + VS2] = (unsigned short)(a1 >> 16);
+            vd[VP2 + 2 * VS2] = (unsigned short)(b1 & 0xffffu); vd[VP2 + 3 * VS2] = (unsigned short)(b1 >> 16);
+            vd[2 * VP2] = (unsigned short)(a2 & 0xffffu); vd[2 * VP2 + VS2] = (unsigned short)(a2 >> 16);
+            vd[2 * VP2 + 2 * VS2] = (unsigned short)(b2 & 0xffffu); vd[2 * VP2 + 3 * VS2] = (unsigned short)(b2 >> 16);
+        }
+        // key-mask clamps, applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit
+        // by finfo.min: every finite logit is >= finfo.min, so min() is that replacement), -inf beyond L
+        for (int kk = tid; kk < nkt * 64; kk += TRI_THREADS)
+            Ms[kk] = kk < nkeys ? ((!km || km[c0 + kk] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+        __syncthreads();
+
+#pragma unroll
+        for (int sl = 0; sl < MAXQ; ++sl) {
+            const int qt = wave + sl * (TRI_THREADS / 64);
+            if (qt >= nqt) break;
+            // ---- Q fragments (B operand of the swapped product), pre-scaled, split: lane holds Q[q][dbase + 8g .. +7]
+            const int qrow = qt * 16 + lq;
+            const bool qok = qrow < L;
+            bf16x8 qf[2][3];
+            {
+                const float* qp = a.q + base + (long long)(qok ? qrow : 0) * a.sl;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float x[8];
+                    const bool live = qok && (hh == 0 || g < 2);        // d 32..47 only: lane groups 2, 3 of the second step are 0
+                    const f32x4 lo = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 hi = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] = lo[e] * qscale; x[4 + e] = hi[e] * qscale; }
+                    unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], q0[e], q1[e], q2[e]);
+                    qf[hh][0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
+                    qf[hh][1] = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+                    qf[hh][2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                }
+            }
+            const float* brow = biasb ? biasb + (long long)(qok ? qrow : 0) * a.bias_sq + (long long)c0 * a.bias_sk : nullptr;
+            float mr = m_run[sl], lr = l_run[sl];
+            f32x4 oo[3] = {o[sl][0], o[sl][1], o[sl][2]};
+            constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
+
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int k0 = kt * 64;
+                // ---- bias of this tile (keys k0 + sub*16 + 4g + r), issued first
+                float bz[4][4];
+                if (bias_vec && c0 + k0 + 64 <= L) {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + k0 + sub * 16 + g * 4);
+                        bz[sub][0] = t4[0]; bz[sub][1] = t4[1]; bz[sub][2] = t4[2]; bz[sub][3] = t4[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = min(k0 + sub * 16 + g * 4 + r, nkeys - 1);
+                            bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
+                        }
+                }
+                // ---- S^T tiles: 4 sub-blocks of 16 keys x 2 d-steps x 6 products
+                f32x4 sc[4];
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const char* kr = Kp + (k0 + sub * 16 + lq) * KST + g * 16;
+                    bf16x8 ka[2][3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        ka[0][p] = *reinterpret_cast<const bf16x8*>(kr + p * K_PLANE);
+                        // d 32..47: lane groups 0, 1 read d 32 + 8g; groups 2, 3 re-read a valid address and are multiplied by Q = 0
+                        ka[1][p] = *reinterpret_cast<const bf16x8*>(kr + p * K_PLANE + 64 - (g >> 1) * 32);
+                    }
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[hh][TA[term]], qf[hh][TB[term]], c, 0, 0, 0);
+                    sc[sub] = c;
+                }
+                // ---- bias, mask, online softmax (base 2) of this lane's query column
+                float mx = -INFINITY;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fminf(fmaf(bz[sub][r], LOG2E, sc[sub][r]), mk[r]);
+                        sc[sub][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(mr, mx);
+                const float alpha = __builtin_amdgcn_exp2f(mr - m_new);
+                float rs = 0.f;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sc[sub][r] - m_new);
+                        sc[sub][r] = p;
+                        rs += p;
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                lr = lr * alpha + rs;
+                mr = m_new;
+                if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) oo[d][r] *= alpha;
+                }
+                // ---- O^T += V^T P: one MFMA step contracts the 32 keys of two sub-blocks
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    unsigned p0[4], p1[4], p2[4];
+                    split2(sc[2 * m][0], sc[2 * m][1], p0[0], p1[0], p2[0]);
+                    split2(sc[2 * m][2], sc[2 * m][3], p0[1], p1[1], p2[1]);
+                    split2(sc[2 * m + 1][0], sc[2 * m + 1][1], p0[2], p1[2], p2[2]);
+                    split2(sc[2 * m + 1][2], sc[2 * m + 1][3], p0[3], p1[3], p2[3]);
+                    bf16x8 pb[3];
+                    pb[0] = __builtin_bit_cast(bf16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+                    pb[1] = __builtin_bit_cast(bf16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
+                    pb[2] = __builtin_bit_cast(bf16x8, u32x4{p2[0], p2[1], p2[2], p2[3]});
+                    const char* vr = Vp + lq * VST + (k0 + m * 32 + g * 8) * 2;
+                    bf16x8 va[3][3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) va[d][p] = *reinterpret_cast<const bf16x8*>(vr + d * 16 * VST + p * V_PLANE);
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[d][TA[term]], pb[TB[term]], oo[d], 0, 0, 0);
+                }
+            }
+            m_run[sl] = mr;
+            l_run[sl] = lr;
+            o[sl][0] = oo[0]; o[sl][1] = oo[1]; o[sl][2] = oo[2];
+        }
+    }
+    // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
+#pragma unroll
+    for (int sl = 0; sl < MAXQ; ++sl) {
+        const int qt = wave + sl * (TRI_THREADS / 64);
+        const int qrow = qt * 16 + lq;
+        if (qt >= nqt || qrow >= L) continue;
+        const float inv = 1.0f / l_run[sl];
+        const long long go = base + (long long)qrow * a.sl;
+        float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int dd = d * 16 + g * 4;
+            f32x4 v = o[sl][d];
+            if (a.gate) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * (1.0f / (1.0f + expf(-gv[r])));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= inv;
+            }
+            *reinterpret_cast<f32x4*>(op + dd) = v;
+        }
+    }
+}
+
 // ---- sequence attention: block = (256 queries, h, b); K/V of (b,h) in LDS; one thread per query ----------------
 template <int D>
 __global__ __launch_bounds__(256) void seq_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
@@ -279,8 +524,27 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
+    if (!a.exact) {
+        // split-bf16 kernel: K / V staged in 192-key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
+        const size_t lds3 = (size_t)3 * K_PLANE + (size_t)3 * V_PLANE + (KCH + 4) * sizeof(float);
+        const int slots = ((a.L + 15) / 16 + TRI_THREADS / 64 - 1) / (TRI_THREADS / 64);
+        ABX_REQUIRE(slots <= 8, "abx_tri_attn_fwd: L too large (L <= 1536)");
+        static thread_local bool configured3 = false;
+        if (!configured3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
+            configured3 = true;
+        }
+        const dim3 grid(a.H, a.S, a.B), block(TRI_THREADS);
+        if (slots <= 2) hipLaunchKernelGGL(tri_attn3_kernel<2>, grid, block, lds3, st, a);
+        else if (slots <= 4) hipLaunchKernelGGL(tri_attn3_kernel<4>, grid, block, lds3, st, a);
+        else hipLaunchKernelGGL(tri_attn3_kernel<8>, grid, block, lds3, st, a);
+        return abx_check_launch("abx_tri_attn_fwd");
+    }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
-    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout (L <= 389)");
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout of the exact kernel (L <= 389)");
     static thread_local size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_attn_kernel),

@@ -206,7 +206,7 @@ def transpose_last2(x, out):
     return out
 
 
-def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False):
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None):
     """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
     already laid out [b,h,q,k] for this orientation (bias_is_qk=True); out (B*L*L, H*D)."""
     lib = _lib.load()
@@ -228,6 +228,7 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.os, a.ol = (L * C_, C_) if per_row else (C_, L * C_)
     a.B, a.S, a.L, a.H, a.D = B, L, L, H, D
     a.scale = float(D ** (-0.5))
+    a.exact = int(GEMM_EXACT if exact is None else exact)
     check(lib.abx_tri_attn_fwd(C.byref(a), _stream()), 'abx_tri_attn_fwd')
     return out
 

@@ -65,7 +65,10 @@ class OpTimer:
             return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * K * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
-            return 'tri_attn_kernel', 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
+            exact = self.ops.GEMM_EXACT if kw.get('exact') is None else kw['exact']
+            slots = ((L + 15) // 16 + 11) // 12
+            kern = 'tri_attn_kernel' if exact else f'tri_attn3_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}>'
+            return kern, 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
         if name == 'ipa_attn':
             Bc, L = args[-2], args[-1]
             return 'ipa_attn_kernel', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12)
@@ -283,7 +286,7 @@ def main():
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
         if name.startswith('ipa_attn'):
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
-        elif name.startswith('gemm3_kernel'):
+        elif name.startswith('gemm3_kernel') or name.startswith('tri_attn3_kernel'):
             # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs six bf16 MFMA
             # products, so the ceiling is the dense bf16 peak / 6
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_SPLIT_PEAK_TF, 'unit': 'TFLOP/s',

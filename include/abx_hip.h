@@ -105,6 +105,8 @@ typedef struct AbxTriAttn {
     float* out; long long ob, os, ol;               /* out (b,s,l,h*D+d) */
     int B, S, L, H, D;                              /* D must be 48 */
     float scale;
+    int exact;                                      /* 0: split-bf16 matrix-core kernel (fp32-accurate, any L <= 1536);
+                                                       1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
 } AbxTriAttn;
 int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);
 

@@ -351,10 +351,13 @@ def test_gemm_small_n_and_relu_input(ops):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False)])
-def test_tri_attn(ops, L, per_row):
+@pytest.mark.parametrize('exact', [False, True])
+@pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False), (200, True), (212, False)])
+def test_tri_attn(ops, L, per_row, exact):
+    """exact=False: split-bf16 kernel (K/V chunks of 192 keys: L = 200 / 212 cross a chunk boundary and carry the online
+    softmax state over it); exact=True: fp32 MFMA kernel."""
     from oracle import abx_oracle as O
-    B, H, D = 2, 4, 48
+    B, H, D = (2 if L < 128 else 1), 4, 48
     C = H * D
     x = torch.randn(B, L, L, 4 * C, generator=g(30))            # [q|k|v|gate] in natural (i,j) layout
     P = torch.randn(B, L, L, H, generator=g(31))                # bias projection in natural layout
@@ -362,7 +365,7 @@ def test_tri_attn(ops, L, per_row):
     mask[:, 0] = True
     out = torch.full((B * L * L, C), float('nan'), device=DEV)
     biasT = P.permute(0, 3, 1, 2).contiguous()                 # (B,H,i,j)
-    ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), biasT.to(DEV), mask.float().to(DEV), out, B, L, per_row)
+    ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), biasT.to(DEV), mask.float().to(DEV), out, B, L, per_row, exact=exact)
     xx = x if per_row else x.transpose(1, 2)
     PP = P if per_row else P.transpose(1, 2)
     q, k, v, gt = [t.reshape(B, L, L, H, D).permute(0, 1, 3, 2, 4).double() for t in torch.split(xx, C, dim=-1)]
@@ -374,11 +377,12 @@ def test_tri_attn(ops, L, per_row):
     # same through the key-contiguous bias copy the model uses for the ending node
     b2 = biasT.to(DEV) if per_row else ops.transpose_last2(biasT.to(DEV).view(B * H, L, L), torch.empty(B * H, L, L, device=DEV)).view(B, H, L, L)
     out2 = torch.full((B * L * L, C), float('nan'), device=DEV)
-    ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), b2, mask.float().to(DEV), out2, B, L, per_row, bias_is_qk=True)
+    ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), b2, mask.float().to(DEV), out2, B, L, per_row, bias_is_qk=True, exact=exact)
     check(out2.view(B, L, L, C), o, 5e-6, f'tri_attn (qk bias) L={L} per_row={per_row}')
 
 
-def test_tri_attn_all_keys_masked_row_and_spike(ops):
+@pytest.mark.parametrize('exact', [False, True])
+def test_tri_attn_all_keys_masked_row_and_spike(ops, exact):
     """Fully masked keys give the uniform softmax of finfo.min logits; a spiked key forces the online-softmax rescale."""
     from oracle import abx_oracle as O
     B, L, H, D = 1, 80, 4, 48
@@ -388,7 +392,8 @@ def test_tri_attn_all_keys_masked_row_and_spike(ops):
     P = torch.zeros(B, L, L, H)
     for mask in (torch.zeros(B, L, dtype=torch.bool), torch.ones(B, L, dtype=torch.bool)):
         out = torch.empty(B * L * L, C, device=DEV)
-        ops.tri_attn(x.view(-1, 4 * C).to(DEV), P.permute(0, 3, 1, 2).contiguous().to(DEV), mask.float().to(DEV), out, B, L, True)
+        ops.tri_attn(x.view(-1, 4 * C).to(DEV), P.permute(0, 3, 1, 2).contiguous().to(DEV), mask.float().to(DEV), out, B, L, True,
+                     exact=exact)
         q, k, v, gt = [t.reshape(B, L, L, H, D).permute(0, 1, 3, 2, 4).double() for t in torch.split(x, C, dim=-1)]
         o = O._attention(q, k, v, None, mask[:, None, :], D) * torch.sigmoid(x[..., 3 * C:].double())
         check(out.view(B, L, L, C), o, 5e-6, f'tri_attn mask all={bool(mask.all())}')
