@@ -93,22 +93,24 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     const char* baseA;
     long long a_step;                                          // bytes per k-tile
     if constexpr (AMODE == 0) {
-        baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb);
+        // offsets are relative to the tile's first row (to the batch base when the rows are pair-transposed)
+        const long long row0 = g.a_pair_transpose > 0 ? 0 : m0;
+        baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb + row0 * g.sAm);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int r = (wave * NLA + i) * 16 + (lane >> 2), p = lane & 3;
             const int kq = p ^ ((r >> 2) & 3);                 // physical 16-byte slot p of row r holds logical k-quad kq
             long long gr = min(m0 + r, g.M - 1);
             if (g.a_pair_transpose > 0) gr = (gr % g.a_pair_transpose) * g.a_pair_transpose + gr / g.a_pair_transpose;
-            offsA[i] = (unsigned)((gr * g.sAm + kq * 4) * 4);
+            offsA[i] = (unsigned)(((gr - row0) * g.sAm + kq * 4) * 4);
         }
         a_step = BK * 4;
     } else if constexpr (AMODE == 1) {
-        baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb);
+        baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb + m0);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int kl = (wave * NLA + i) * 2 + (lane >> 5), mq = lane & 31;     // LDS [k][BM]: 2 k-rows per instruction
-            const int gm = min(m0 + mq * 4, g.M - 4);
+            const int gm = min(m0 + mq * 4, g.M - 4) - m0;
             offsA[i] = (unsigned)(((long long)kl * g.sAk + gm) * 4);
         }
         a_step = (long long)BK * g.sAk * 4;
@@ -282,15 +284,20 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int SCR = 4 * 32 * ((TS ? WM : (WN > 96 ? 96 : WN)) + 4);
     constexpr int EPI = 2 * BM + SCR;
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
-    const int ntn = (g.N + BN - 1) / BN;
-    int wgid = blockIdx.x;
-    if (!(g.tune & 1)) {        // XCD-aware remap: the N-tiles of one M-panel run on the same XCD (see gemm.hip)
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    // 1-D grid over (batch, m-tile, n-tile).  XCD-aware remap (blocks are placed round-robin over the 8 XCDs): every XCD gets a
+    // contiguous range of tiles, so the N-tiles that share an A panel - and all tiles of one batch entry of the
+    // triangle-multiplication contraction - meet in one private L2.  Bijective for any grid size.
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    long long wgid = blockIdx.x;
+    if (!(g.tune & 1)) {
+        const long long nwg = gridDim.x, bid = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int mt = wgid / ntn, nt = wgid % ntn;
-    const int b = blockIdx.z;
+    const int per_batch = ntn * ntm;
+    const int b = (int)(wgid / per_batch);
+    const int rem = (int)(wgid - (long long)b * per_batch);
+    const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS>(g, smem, mt, nt, b);
     else gemm3_block<BM, BN, WM, WN, AMODE, true, TS>(g, smem, mt, nt, b);
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch3(const AbxGemm& g, hipStream_t st) {
     const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
-    dim3 grid((unsigned)(mt * ntn), 1, (unsigned)g.batch), block(256);
+    dim3 grid((unsigned)(mt * ntn * g.batch), 1, 1), block(256);
     const int amode = g.A_split ? 2 : (g.sAk == 1 ? 0 : 1);
     if (g.c_transposed) {
         if (amode != 0) { abx_set_error("abx_gemm: transposed store needs a k-contiguous fp32 A"); return ABX_ERR_ARG; }
@@ -345,8 +352,11 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     }
     // 128x128 tiles run 3 blocks per CU (48 KB LDS, ~150 VGPRs), 128x192 tiles 2: the narrow tile wins whenever it wastes no
     // columns (N = 768: q|k|v|gate, transition hidden); N = 192 / 448 take the wide tile
-    // per-lane DMA offsets are 32-bit: one batch of an operand must span less than 4 GB
-    if (!g.A_split && ((g.sAk == 1 ? (long long)g.M * g.sAm : (long long)g.K * g.sAk) >= (1LL << 30))) return 1;
+    // per-lane DMA offsets are 32-bit, relative to the tile's first row (k-contiguous A), to the batch base (pair-transposed
+    // rows, plane operands) or to the tile's first column (row-contiguous A)
+    if (!g.A_split && g.sAk == 1 && (g.a_pair_transpose > 0 ? (long long)g.M * g.sAm : 128LL * g.sAm) >= (1LL << 30)) return 1;
+    if (!g.A_split && g.sAk != 1 && 16LL * g.sAk + g.M >= (1LL << 30)) return 1;
+    if (((long long)g.M + 127) / 128 * (((long long)g.N + 127) / 128) * g.batch >= (1LL << 31)) return 1;
     if (g.A_split && (long long)(g.K / 16) * g.sA3k >= (1LL << 31)) return 1;
     if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
     const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;

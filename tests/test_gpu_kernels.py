@@ -162,6 +162,24 @@ def test_gemm_split_bf16_accuracy_vs_exact(ops):
                 assert not torch.equal(o_split, o_exact), 'the split-bf16 kernel did not run'
 
 
+def test_gemm_split_bf16_operand_larger_than_4gb(ops):
+    """The pair-stack GEMMs of a 20-sample chunk at L = 352 have A operands beyond 4 GB (2.48 M rows x 768): the DMA offsets
+    are tile-relative 32-bit values, so such problems must still run on the split kernels and be right at both ends."""
+    M, N, K = 1_450_000, 192, 768                    # M * K * 4 B = 4.45 GB
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    A = torch.randn(M, K, device=DEV, generator=gen)
+    W = torch.randn(K, N, device=DEV, generator=gen) / K ** 0.5
+    res = torch.randn(M, N, device=DEV, generator=gen)
+    out = res.clone()
+    ops.gemm(A, W, out, resid=out, B3=ops.split_weights(W))
+    oe = res.clone()
+    ops.gemm(A, W, oe, resid=oe, exact=True)
+    assert not torch.equal(out[:4096], oe[:4096]), 'the split-bf16 kernel did not run'
+    for sl in (slice(0, 4096), slice(M // 2, M // 2 + 4096), slice(M - 4096, M)):
+        ref = A[sl].double() @ W.double() + res[sl].double()
+        check(out[sl], ref, 3e-6, f'>4 GB operand rows {sl.start}')
+
+
 def test_gemm_split_bf16_fused_paths(ops):
     """LayerNorm (inline statistics, mean >> sigma), relu-on-load, gate / residual, transposed store and the channel-major A
     operand on the split-bf16 kernels, against float64."""
