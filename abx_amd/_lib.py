@@ -92,6 +92,7 @@ _PROTOS = {
     'abx_init': (I, [I]),
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
     'abx_split_weights': (I, [c_f, LL, LL, I, I, C.c_void_p, _S]),
+    'abx_gemm3_occupancy': (I, [I]),
     'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),
     'abx_layernorm': (I, [c_f, LL, LL, I, c_f, c_f, F, c_f, LL, c_f, LL, _S]),
     'abx_tri_attn_fwd': (I, [C.POINTER(AbxTriAttn), _S]),

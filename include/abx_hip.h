@@ -82,6 +82,9 @@ int abx_gemm(const AbxGemm* desc, hipStream_t stream);
 /* fp32 weights W[n][k] (element strides s_n, s_k) -> out[Kp/16][3][N][16] bf16 planes with w = p0 + p1 + p2 exactly,
  * Kp = (K+15)/16*16 (zero padded) */
 int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t stream);
+/* diagnostics: resident workgroups per CU of the main split-bf16 GEMM instantiations (0: 128x192, 1: 128x128,
+ * 2: 128x128 transposed store, 3: 128x192 plane operands); negative on error */
+int abx_gemm3_occupancy(int which);
 
 /* LayerNorm statistics (mean, rstd) per row for the LN-on-load GEMM prologue (torch.nn.LayerNorm, eps 1e-5).
  * s_k == 1: rows dense over batch (row stride s_row); else channel-major: element (b,row,k) at x + b*s_b + k*s_k + row. */
