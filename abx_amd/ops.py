@@ -38,7 +38,7 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     exact = GEMM_EXACT if exact is None else exact
     blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
     wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128
-    if not exact and split and N > 64 and blocks128 >= 512 and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
+    if not exact and split and N > 64 and blocks128 >= 256 and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
         amode = 2 if a_split else (0 if a_kcontig else 1)
         cfg = (128, 192, 32, 192) if (wide192 and N % 128 != 0) else (128, 128, 32, 128)
         return f'gemm3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {amode}, {b(transposed)}, 2>'
@@ -58,7 +58,7 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
 def gemm_split_eligible(M, N, K, batch=1):
     """True when abx_gemm serves an (aligned) problem of this size on the split-bf16 kernels (mirror of
     abx_gemm3_dispatch in csrc/gemm3.hip)."""
-    return (not GEMM_EXACT) and N > 64 and K % 16 == 0 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= 512
+    return (not GEMM_EXACT) and N > 64 and K % 16 == 0 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256
 
 
 def split_weights(Wt):
