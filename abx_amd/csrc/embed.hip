@@ -60,6 +60,66 @@ __global__ __launch_bounds__(256) void assemble_seq_kernel(const float* __restri
     }
 }
 
+// Model dimensions (C = 128, E = 32 -> W = 192): 16 lanes per (b,i,j) row, three float4 per lane, 4 rows per wave; every
+// access is 16 bytes, the LayerNorm reductions stay inside the 16-lane group.
+__global__ __launch_bounds__(256) void assemble_pair192_kernel(const float* __restrict__ pair_static, long long ps_b,
+                                                               const float* __restrict__ temb, const float* __restrict__ prev,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const long long* __restrict__ prev_pos,
+                                                               const float* __restrict__ pos_table, float* __restrict__ out,
+                                                               long long rows, long long LL) {
+    constexpr int C = 128, E = 32, W = 192;
+    const int l16 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= rows) return;
+    const int b = (int)(row / LL);
+    const long long ij = row % LL;
+    f32x4 x[3];
+    float mean = 0.f, rstd = 0.f;
+    if (prev) {
+        const f32x4* pr = reinterpret_cast<const f32x4*>(prev + row * W);
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            x[u] = pr[l16 + 16 * u];
+            s += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        mean = s / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d = x[u][c] - mean;
+                q = fmaf(d, d, q);
+            }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        rstd = 1.0f / sqrtf(q / (float)W + 1e-5f);
+    }
+    const f32x4* st = reinterpret_cast<const f32x4*>(pair_static + (long long)b * ps_b + ij * C);
+    const f32x4* pt = prev_pos ? reinterpret_cast<const f32x4*>(pos_table + prev_pos[row] * W) : nullptr;
+    f32x4* op = reinterpret_cast<f32x4*>(out + row * W);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int q4 = l16 + 16 * u;                     // float4 index inside the row: 0..31 static part, 32..47 the two time embeddings
+        f32x4 v = q4 < C / 4 ? st[q4] : reinterpret_cast<const f32x4*>(temb + b * E)[(q4 - C / 4) % (E / 4)];
+        if (prev) {
+            const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[q4], be = reinterpret_cast<const f32x4*>(beta)[q4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += (x[u][c] - mean) * rstd * ga[c] + be[c];
+        }
+        if (pt) {
+            const f32x4 pv = pt[q4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += pv[c];
+        }
+        op[q4] = v;
+    }
+}
+
 // one wave per (b,i,j) row; W = C + 2E = 192 handled as W/64 = 3 elements per lane.
 __global__ __launch_bounds__(256) void assemble_pair_kernel(const float* __restrict__ pair_static, long long ps_b,
                                                             const float* __restrict__ temb, const float* __restrict__ prev,
@@ -299,6 +359,13 @@ extern "C" int abx_assemble_pair(const float* pair_static, long long ps_b, const
     ABX_REQUIRE(!prev_pair || (gamma && beta), "abx_assemble_pair: LN params missing");
     ABX_REQUIRE(!prev_pos || pos_table, "abx_assemble_pair: pos table missing");
     const long long rows = (long long)B * L * L;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (C == 128 && E == 32 && !stats_out && ps_b % 4 == 0 && al16(pair_static) && al16(temb) && al16(out) &&
+        (!prev_pair || (al16(prev_pair) && al16(gamma) && al16(beta))) && (!prev_pos || al16(pos_table))) {
+        hipLaunchKernelGGL(assemble_pair192_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, pair_static, ps_b, temb,
+                           prev_pair, gamma, beta, prev_pos, pos_table, out, rows, (long long)L * L);
+        return abx_check_launch("abx_assemble_pair");
+    }
     hipLaunchKernelGGL(assemble_pair_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, pair_static, ps_b, temb,
                        prev_pair, gamma, beta, prev_pos, pos_table, out, stats_out, rows, (long long)L * L, C, E);
     return abx_check_launch("abx_assemble_pair");

@@ -364,6 +364,40 @@ __global__ __launch_bounds__(256) void layernorm_kc(const float* __restrict__ x,
     }
 }
 
+// K == 128 (the IPA pair representation, B*L*L rows): 32 lanes x float4 per row, two rows per wave, 16-byte accesses.
+__global__ __launch_bounds__(256) void layernorm128_kernel(const float* __restrict__ x, long long s_row, long long rows,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float* __restrict__ out, long long s_out,
+                                                           const float* __restrict__ res, long long s_res) {
+    const int l32 = threadIdx.x & 31;
+    const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x + row * s_row)[l32];
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / 128.0f;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float d = v[c] - mean;
+        q = fmaf(d, d, q);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / 128.0f + eps);
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[l32], be = reinterpret_cast<const f32x4*>(beta)[l32];
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = (v[c] - mean) * rstd * ga[c] + be[c];
+    if (res) {
+        const f32x4 rv = reinterpret_cast<const f32x4*>(res + row * s_res)[l32];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] += rv[c];
+    }
+    reinterpret_cast<f32x4*>(out + row * s_out)[l32] = r;
+}
+
 template <int BM, int BN, int WM, int WN, int BK = 16, int MINW = 3>
 int launch_cfg(const AbxGemm& g, hipStream_t st) {
     const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
@@ -461,6 +495,13 @@ extern "C" int abx_row_stats(const float* x, long long s_b, long long s_row, lon
 extern "C" int abx_layernorm(const float* x, long long s_row, long long rows, int K, const float* gamma, const float* beta,
                              float eps, float* out, long long s_out, const float* res, long long s_res, hipStream_t st) {
     ABX_REQUIRE(x && out && gamma && beta && rows > 0 && K > 0, "abx_layernorm: bad args");
+    auto al16v = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (K == 128 && s_row % 4 == 0 && s_out % 4 == 0 && al16v(x) && al16v(out) && al16v(gamma) && al16v(beta) &&
+        (!res || (al16v(res) && s_res % 4 == 0))) {
+        hipLaunchKernelGGL(layernorm128_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, x, s_row, rows, gamma, beta, eps,
+                           out, s_out, res, s_res);
+        return abx_check_launch("abx_layernorm");
+    }
     hipLaunchKernelGGL(layernorm_kc, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, s_row, (int)rows, K, gamma, beta,
                        eps, out, s_out, res, s_res);
     return abx_check_launch("abx_layernorm");

@@ -103,6 +103,15 @@ def test_gemm_ln_gate_resid_rowscale(ops):
     x = A.to(DEV).clone()
     ops.layernorm(x, ga.to(DEV), be.to(DEV), out=x)
     check(x, ref_ln, 2e-6, 'layernorm in place')
+    # K = 128 takes the 16-byte-vector kernel (in place, with residual, strided rows, odd row count)
+    x128 = torch.randn(1003, 160, generator=g(97)) * 3 + 1
+    g128, b128, r128 = torch.randn(128, generator=g(98)), torch.randn(128, generator=g(99)), torch.randn(1003, 128, generator=g(100))
+    xv = x128.to(DEV)[:, 16:144]                              # row stride 160, 16-byte aligned start
+    o128 = ops.layernorm(xv, g128.to(DEV), b128.to(DEV), res=r128.to(DEV))
+    ref128 = torch.nn.functional.layer_norm(x128[:, 16:144].double(), (128,), g128.double(), b128.double(), 1e-5) + r128.double()
+    check(o128, ref128, 2e-6, 'layernorm K=128 vector kernel')
+    ops.layernorm(xv, g128.to(DEV), b128.to(DEV), out=xv)
+    check(xv, ref128 - r128.double(), 2e-6, 'layernorm K=128 in place')
 
 
 def _host_planes(x):
@@ -499,6 +508,11 @@ def test_embedding_assembly(ops, params):
     pa2 = pa.double().view(-1, 192)
     check(pst[:, 0], pa2.mean(-1), 2e-6, 'assemble_pair fused stats mean')
     check(pst[:, 1], 1 / torch.sqrt(pa2.var(-1, unbiased=False) + 1e-5), 2e-6, 'assemble_pair fused stats rstd')
+    # without the fused statistics the model dimensions (128 + 2*32) take the 16-byte-vector kernel
+    po2 = torch.full_like(po, float('nan'))
+    ops.assemble_pair(pair_static.to(DEV), temb, prev_pair.to(DEV), P[O.P_SEQF + 'prev_pair_norm.weight'],
+                      P[O.P_SEQF + 'prev_pair_norm.bias'], prev_pos.to(DEV), P[O.P_SEQF + 'proj_prev_pos.weight'], po2, B, L, 128, 32)
+    check(po2, pa, 2e-6, 'assemble_pair (vector kernel)')
     # shared (broadcast) static context
     ops.assemble_pair(pair_static[:1].contiguous().to(DEV), temb, None, None, None, None, None, po, B, L, 128, 32)
     check(po[1, ..., :128], pair_static[0], 0, 'assemble_pair broadcast')
