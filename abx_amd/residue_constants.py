@@ -35,3 +35,13 @@ restype_atom14_is_ambiguous = _T['restype_atom14_is_ambiguous']
 chi_angles_atom_indices = _T['chi_angles_atom_indices']
 chi_angles_mask = _T['chi_angles_mask']
 chi_pi_periodic = _T['chi_pi_periodic']
+
+# ---- names (output writer only; abx/common/residue_constants.py: restype_1to3, restype_name_to_atom14_names) -------------
+atom_type_num = len(atom_types)
+restype_1to3 = {'A': 'ALA', 'R': 'ARG', 'N': 'ASN', 'D': 'ASP', 'C': 'CYS', 'Q': 'GLN', 'E': 'GLU', 'G': 'GLY', 'H': 'HIS',
+                'I': 'ILE', 'L': 'LEU', 'K': 'LYS', 'M': 'MET', 'F': 'PHE', 'P': 'PRO', 'S': 'SER', 'T': 'THR', 'W': 'TRP',
+                'Y': 'TYR', 'V': 'VAL'}
+restype_name_to_atom14_names = {
+    restype_1to3[r]: [atom_types[int(restype_atom14_to_atom37[i, j])] if restype_atom14_mask[i, j] else '' for j in range(14)]
+    for i, r in enumerate(restypes)}
+restype_name_to_atom14_names['UNK'] = [''] * 14

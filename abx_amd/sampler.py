@@ -23,9 +23,11 @@ def set_t_feats(feats, diffuser, t, ones):
 
 
 def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_t=0.01, center=True, self_condition=True,
-              noise_scale=1.0, eps=1e-8, noise_fn=None, sample_ids=None, on_step=None):
+              noise_scale=1.0, eps=1e-8, noise_fn=None, sample_ids=None, on_step=None, on_record=None):
     """Returns the trajectory: list of dicts {seq (B,Lab) i64, atom14_results (B,Lab,14,3), pLDDT (B,Lab), time,
-    rigids_t, seq_t}; only the last element unless mode == 'trajectory'.  All tensors stay on the device."""
+    rigids_t, seq_t}; only the last element unless mode == 'trajectory'.  All tensors stay on the device.
+    on_record(rec): called for every element that enters the trajectory, e.g. `abx_amd.io.TrajectoryWriter.submit` to dump the
+    per-step PDB files asynchronously (device->host copy on a side stream, formatting and disk I/O on a worker thread)."""
     model_conf = config.model
     sc_conf = model_conf.heads.diffusion_module
     batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_init.items()}
@@ -76,6 +78,8 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
                    'pLDDT': torch.tile(pl[:, None], (1, Lab)), 'time': float(t), 'rigids_t': rigids_t, 'seq_t': seq_t}
             if mode == 'trajectory' or k == len(steps) - 1:
                 traj.append({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in rec.items()})
+                if on_record is not None:
+                    on_record(traj[-1])
             if on_step is not None:
                 on_step(k, t, batch, out)
     return traj

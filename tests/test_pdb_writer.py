@@ -1,0 +1,85 @@
+"""Output writer: record format rules of the PDBIO restatement, coordinate / sequence round trip, the
+asynchronous writer against the synchronous one.  Host-side only (no GPU needed)."""
+import os
+
+import numpy as np
+import torch
+
+from abx_amd import residue_constants as rc
+from abx_amd.io import TrajectoryWriter, format_pdb, index_to_str_seq, postprocess_trajectory
+
+
+def _parse(text):
+    atoms = []
+    for ln in text.splitlines():
+        if ln.startswith('ATOM'):
+            atoms.append(dict(serial=int(ln[6:11]), name=ln[12:16], resname=ln[17:20], chain=ln[21], resseq=int(ln[22:26]),
+                              xyz=(float(ln[30:38]), float(ln[38:46]), float(ln[46:54])), occ=float(ln[54:60]),
+                              bf=float(ln[60:66]), element=ln[76:78]))
+    return atoms
+
+
+def _complex(nh=7, nl=5, nag=(4, 3), seed=0):
+    g = np.random.default_rng(seed)
+    seq_h = ''.join(g.choice(rc.restypes, nh))
+    seq_l = ''.join(g.choice(rc.restypes, nl))
+    coord = g.normal(size=(nh + nl, 14, 3)) * 20
+    plddt = g.uniform(0.3, 0.9, size=(nh + nl))
+    n = sum(nag)
+    ag = dict(antigen_str_seq=''.join(g.choice(rc.restypes, n)), antigen_coords=g.normal(size=(n, 14, 3)) * 20,
+              antigen_coord_mask=np.ones((n, 14), bool), antigen_chain_ids=np.concatenate([np.full(k, i + 2) for i, k in enumerate(nag)]),
+              antigen_chains=['A', 'B'][:len(nag)])
+    ag['antigen_coord_mask'][1, rc.atom_order['CA']] = False        # a residue without CA is dropped (make_chain mask)
+    return seq_h, seq_l, coord, plddt, ag
+
+
+def test_format_rules_and_round_trip():
+    seq_h, seq_l, coord, plddt, ag = _complex()
+    text = format_pdb(seq_h, 'H', seq_l, 'L', coord, plddt, ag)
+    lines = text.splitlines()
+    assert lines[-1] == 'END   ' and all(len(ln) == 80 for ln in lines if ln.startswith(('ATOM', 'TER')))
+    atoms = _parse(text)
+    # serials: consecutive from 1; a TER record takes the next serial without consuming it
+    assert [a['serial'] for a in atoms] == list(range(1, len(atoms) + 1))
+    ters = [ln for ln in lines if ln.startswith('TER')]
+    assert len(ters) == 4 and [ln[21] for ln in ters] == ['H', 'L', 'A', 'B']
+    h_atoms = [a for a in atoms if a['chain'] == 'H']
+    assert int(ters[0][6:11]) == len(h_atoms) + 1
+    # residues numbered from 1 per chain, atom14 order, names in PDB column alignment, element = first letter
+    k = 0
+    for i, aa in enumerate(seq_h + seq_l):
+        chain, resseq = ('H', i + 1) if i < len(seq_h) else ('L', i + 1 - len(seq_h))
+        for j, nm in enumerate(rc.restype_name_to_atom14_names[rc.restype_1to3[aa]]):
+            if nm == '':
+                continue
+            a = atoms[k]; k += 1
+            assert (a['chain'], a['resseq'], a['resname']) == (chain, resseq, rc.restype_1to3[aa])
+            assert a['name'] == (nm if len(nm) == 4 else ' ' + nm).ljust(4) and a['element'].strip() == nm[0]
+            assert np.allclose(a['xyz'], np.round(coord[i, j], 3), atol=5.1e-4) and a['occ'] == 1.0
+            assert abs(a['bf'] - plddt[i]) < 5.1e-3
+    # antigen: residue 2 of chain A (no CA) is skipped, B-factors = pLDDT[0]
+    a_res = sorted({a['resseq'] for a in atoms if a['chain'] == 'A'})
+    assert a_res == [1, 3, 4]
+    assert all(abs(a['bf'] - plddt[0]) < 5.1e-3 for a in atoms if a['chain'] in 'AB')
+    assert index_to_str_seq([0, 19, 20, 7]) == 'AVXG'
+
+
+def test_async_writer_matches_sync(tmp_path):
+    B, nh, nl = 3, 6, 4
+    meta = dict(name=[f'cx{i}_H_L_AB' for i in range(B)], str_heavy_seq=['A' * nh] * B, str_light_seq=['G' * nl] * B)
+    g = torch.Generator().manual_seed(1)
+    traj = [dict(seq=torch.randint(0, 20, (B, nh + nl), generator=g), atom14_results=torch.randn(B, nh + nl, 14, 3, generator=g) * 10,
+                 pLDDT=torch.rand(B, nh + nl, generator=g), time=t) for t in (1.0, 0.5, 0.01)]
+    d1, d2 = str(tmp_path / 'sync'), str(tmp_path / 'async')
+    f1 = postprocess_trajectory(meta, traj, d1)
+    w = TrajectoryWriter(meta, d2, multi=True)
+    for rec in traj:
+        w.submit(rec)
+    f2 = w.close()
+    assert sorted(os.path.basename(f) for f in f1) == sorted(os.path.basename(f) for f in f2) and len(f1) == 9
+    assert os.path.basename(f1[0]) == 'cx0_H_L_AB@1.0000.pdb'
+    for a, b in zip(sorted(f1), sorted(f2)):
+        assert open(a).read() == open(b).read()
+    # a single-record trajectory writes {name}.pdb (inference.py:129-132)
+    f3 = postprocess_trajectory(meta, traj[-1:], str(tmp_path / 'final'))
+    assert os.path.basename(f3[0]) == 'cx0_H_L_AB.pdb'
