@@ -11,7 +11,7 @@
 // Data movement is all asynchronous global->LDS DMA (global_load_lds_dwordx4): no operand passes through VGPRs on its way
 // to LDS, so nothing the compiler schedules can drain the prefetch queue; the k-loop counts its own outstanding loads
 // (s_waitcnt vmcnt(N) + raw s_barrier).
-//   A  fp32, k-contiguous rows (AMODE 0): ring of 3 stages [BM][16] fp32 (64-byte rows, 16-byte slots XOR-swizzled through
+//   A  fp32, k-contiguous rows (AMODE 0): ring of 3 (128x192 tiles) or 2 (128x128 tiles, 4 blocks/CU) stages [BM][16] fp32 (64-byte rows, 16-byte slots XOR-swizzled through
 //      the SOURCE address).  Every wave reads its own rows as fp32 fragments and splits them in registers right in front of
 //      the MFMAs; the LayerNorm statistics (inline mode), the mean shift and relu-on-load are applied to those registers.
 //      Optional pair transposition of the rows (a_pair_transpose): the DMA source address is per lane, so the incoming
@@ -83,8 +83,12 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     constexpr int B_IMG = 3 * BN * 32;
     constexpr int NLB = (B_IMG + 4095) / 4096;
     constexpr int B_STAGE = NLB * 4096;
-    char* As = reinterpret_cast<char*>(smem);                 // ring of 3 stages
-    char* Bs = As + 3 * A_STAGE;                              // 2 stages
+    // A ring depth: 3 (one A tile stays in flight across the step barrier) for the wide tiles; the 128x128 tiles take 2 stages,
+    // which brings the block to 40 KB of LDS = 4 resident blocks per CU: with K <= 192 the fixed per-tile latencies (dispatch,
+    // first DMA, epilogue) weigh more than the depth of the pipeline and are hidden by the extra resident block
+    constexpr int RING = (BN == 128 && AMODE != 2) ? 2 : 3;
+    char* As = reinterpret_cast<char*>(smem);                 // RING stages
+    char* Bs = As + RING * A_STAGE;                           // 2 stages
     const int m0 = mt * BM, n0 = nt * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -128,7 +132,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     const int nk = g.K / BK;
 
     auto issue_a = [&](int tile) {          // tile index clamped by the caller
-        char* dst = As + (tile % 3) * A_STAGE + wave * NLA * 1024;
+        char* dst = As + (tile % RING) * A_STAGE + wave * NLA * 1024;
         const char* src = baseA + tile * a_step;
 #pragma unroll
         for (int i = 0; i < NLA; ++i) glds16(src + offsA[i], dst + i * 1024);
@@ -157,8 +161,12 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     // prologue: A(0), B(0), A(1) in this order; the k-loop keeps exactly one A tile (NLA loads) in flight across its barrier
     issue_a(0);
     issue_b(0);
-    issue_a(min(1, nk - 1));
-    wait_vm_and_barrier<NLA>();
+    if constexpr (RING == 3) {
+        issue_a(min(1, nk - 1));
+        wait_vm_and_barrier<NLA>();
+    } else {
+        wait_vm_and_barrier<0>();
+    }
 
     // per-lane LDS fragment offsets
     int offA[TM][AMODE == 0 ? 2 : 1];
@@ -182,9 +190,9 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     for (int t = 0; t < nk; ++t) {
         // next tiles: B(t+1) first, then A(t+2): the wait at the end of this step leaves only A(t+2) outstanding
         issue_b(min(t + 1, nk - 1));
-        issue_a(min(t + 2, nk - 1));
+        issue_a(min(t + RING - 1, nk - 1));
 
-        const char* as = As + (t % 3) * A_STAGE;
+        const char* as = As + (t % RING) * A_STAGE;
         const char* bs = Bs + (t & 1) * B_STAGE;
         bf16x8 a[TM][3];
 #pragma unroll
@@ -246,7 +254,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
                     for (int j = 0; j < JG; ++j)
                         acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
         }
-        wait_vm_and_barrier<NLA>();
+        wait_vm_and_barrier<RING == 3 ? NLA : 0>();
     }
     // drain the (redundant) tail DMA before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -283,8 +291,10 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;
     constexpr int A_STAGE = (A_IMG + 4095) / 4096 * 4096;
     constexpr int B_STAGE = (3 * BN * 32 + 4095) / 4096 * 4096;
-    constexpr int OPER = (3 * A_STAGE + 2 * B_STAGE) / 4;                          // floats
-    constexpr int SCR = 4 * 32 * ((TS ? WM : (WN > 96 ? 96 : WN)) + 4);
+    constexpr int RING = (BN == 128 && AMODE != 2) ? 2 : 3;
+    constexpr int OPER = (RING * A_STAGE + 2 * B_STAGE) / 4;                       // floats
+    constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;      // epilogue column group (gemm_epilogue.h)
+    constexpr int SCR = 4 * 32 * ((TS ? WM : TGW * 32) + 4);
     constexpr int EPI = 2 * BM + SCR;
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     // 1-D grid over (batch, m-tile, n-tile).  XCD-aware remap (blocks are placed round-robin over the 8 XCDs): every XCD gets a
@@ -368,7 +378,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
     // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
     if (wide) *rc = launch3<128, 192, 32, 192, 2>(g, st);
-    else *rc = launch3<128, 128, 32, 128, 2>(g, st);
+    else *rc = launch3<128, 128, 32, 128, 4>(g, st);
     return 0;
 }
 
@@ -377,8 +387,8 @@ extern "C" int abx_gemm3_occupancy(int which) {
     int n = -1;
     hipError_t e = hipErrorInvalidValue;
     if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 0, false, 2>), 256, 0);
-    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, false, 2>), 256, 0);
-    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, true, 2>), 256, 0);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, false, 4>), 256, 0);
+    else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, true, 4>), 256, 0);
     else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 2, false, 2>), 256, 0);
     return e == hipSuccess ? n : -(int)e - 1000;
 }
