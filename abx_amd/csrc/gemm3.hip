@@ -82,11 +82,14 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     constexpr int A_STAGE = NLA * 4096;
     constexpr int B_IMG = 3 * BN * 32;
     constexpr int NLB = (B_IMG + 4095) / 4096;
-    constexpr int B_STAGE = NLB * 4096;
-    // A ring depth: 3 (one A tile stays in flight across the step barrier) for the wide tiles; the 128x128 tiles take 2 stages,
-    // which brings the block to 40 KB of LDS = 4 resident blocks per CU: with K <= 192 the fixed per-tile latencies (dispatch,
-    // first DMA, epilogue) weigh more than the depth of the pipeline and are hidden by the extra resident block
-    constexpr int RING = (BN == 128 && AMODE != 2) ? 2 : 3;
+    // with counted waits every wave must issue the same number of DMA instructions (stage padded to 4 KB multiples); the
+    // 2-stage protocol waits for everything, so the surplus chunks are simply skipped and the stage is the bare image
+    constexpr int B_STAGE = (AMODE != 2) ? B_IMG : NLB * 4096;
+    // A ring depth: 2 for the fp32-A kernels (40 KB of LDS = 4 resident blocks per CU with 128x128 tiles, 52 KB = 3 with
+    // 128x192): with K <= 192 the fixed per-tile latencies (dispatch, first DMA, epilogue) weigh more than the depth of the
+    // pipeline and are hidden by the extra resident block; 3 (one A tile stays in flight across the step barrier) for the
+    // plane-operand contraction
+    constexpr int RING = (AMODE != 2) ? 2 : 3;
     char* As = reinterpret_cast<char*>(smem);                 // RING stages
     char* Bs = As + RING * A_STAGE;                           // 2 stages
     const int m0 = mt * BM, n0 = nt * BN;
@@ -141,7 +144,8 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
         char* dst = Bs + (tile & 1) * B_STAGE + wave * NLB * 1024;
         const char* src = baseB + tile * b_step;
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) glds16(src + offsB[i], dst + i * 1024);
+        for (int i = 0; i < NLB; ++i)
+            if (B_STAGE == NLB * 4096 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + offsB[i], dst + i * 1024);
     };
 
     f32x16 acc[TM][TN];
@@ -290,8 +294,8 @@ template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;
     constexpr int A_STAGE = (A_IMG + 4095) / 4096 * 4096;
-    constexpr int B_STAGE = (3 * BN * 32 + 4095) / 4096 * 4096;
-    constexpr int RING = (BN == 128 && AMODE != 2) ? 2 : 3;
+    constexpr int B_STAGE = (AMODE != 2) ? 3 * BN * 32 : (3 * BN * 32 + 4095) / 4096 * 4096;
+    constexpr int RING = (AMODE != 2) ? 2 : 3;
     constexpr int OPER = (RING * A_STAGE + 2 * B_STAGE) / 4;                       // floats
     constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;      // epilogue column group (gemm_epilogue.h)
     constexpr int SCR = 4 * 32 * ((TS ? WM : TGW * 32) + 4);
@@ -377,7 +381,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     const bool wide = force ? force == 2 : (pad192 <= pad128 && g.N % 128 != 0);
     // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
     // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
-    if (wide) *rc = launch3<128, 192, 32, 192, 2>(g, st);
+    if (wide) *rc = launch3<128, 192, 32, 192, 3>(g, st);
     else *rc = launch3<128, 128, 32, 128, 4>(g, st);
     return 0;
 }
@@ -386,10 +390,10 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
 extern "C" int abx_gemm3_occupancy(int which) {
     int n = -1;
     hipError_t e = hipErrorInvalidValue;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 0, false, 2>), 256, 0);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 0, false, 3>), 256, 0);
     else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, false, 4>), 256, 0);
     else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, true, 4>), 256, 0);
-    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 2, false, 2>), 256, 0);
+    else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 2, false, 3>), 256, 0);
     return e == hipSuccess ? n : -(int)e - 1000;
 }
 
