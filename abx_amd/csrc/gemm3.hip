@@ -9,14 +9,14 @@
 // cores run 16/6 = 2.7x faster than their fp32 rate.  The exact kernel remains selectable (AbxGemm.exact).
 //
 // Data movement is all asynchronous global->LDS DMA (global_load_lds_dwordx4): no operand passes through VGPRs on its way
-// to LDS, so nothing the compiler schedules can drain the prefetch queue; the k-loop counts its own outstanding loads
-// (s_waitcnt vmcnt(N) + raw s_barrier).
-//   A  fp32, k-contiguous rows (AMODE 0): ring of 3 (128x192 tiles) or 2 (128x128 tiles, 4 blocks/CU) stages [BM][16] fp32 (64-byte rows, 16-byte slots XOR-swizzled through
+// to LDS (no staging registers, no ds_write pass, no vector address arithmetic); the k-loop waits with an explicit
+// s_waitcnt + raw s_barrier and is double buffered.
+//   A  fp32, k-contiguous rows (AMODE 0): 2 stages [BM][16] fp32 (64-byte rows, 16-byte slots XOR-swizzled through
 //      the SOURCE address).  Every wave reads its own rows as fp32 fragments and splits them in registers right in front of
 //      the MFMAs; the LayerNorm statistics (inline mode), the mean shift and relu-on-load are applied to those registers.
 //      Optional pair transposition of the rows (a_pair_transpose): the DMA source address is per lane, so the incoming
 //      TriangleMultiplication reads z[k][i] rows in (i,k) order for free.
-//   A  fp32, row-contiguous / channel-major (AMODE 1): ring of 3 stages [16 k][BM] fp32, fragments by 4-byte LDS reads.
+//   A  fp32, row-contiguous / channel-major (AMODE 1): 2 stages [16 k][BM] fp32, fragments by 4-byte LDS reads.
 //   A  pre-split bf16 planes (AMODE 2) and B always pre-split planes, k-TILED in memory: [K/16][3][rows][16] so that the
 //      32 bytes a row contributes to a k-tile sit next to the neighbouring rows' (full 128-byte lines per DMA instead of a
 //      quarter line per row, which the 32 KB L1 cannot keep until the next k-tile): weights from abx_split_weights, or
@@ -79,17 +79,17 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     constexpr int WAVES_N = BN / WN;
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;                  // bytes per A stage
     constexpr int NLA = (A_IMG + 4095) / 4096;                                  // DMA instructions per wave per A tile
-    constexpr int A_STAGE = NLA * 4096;
+    constexpr int A_STAGE = A_IMG;
     constexpr int B_IMG = 3 * BN * 32;
     constexpr int NLB = (B_IMG + 4095) / 4096;
     // with counted waits every wave must issue the same number of DMA instructions (stage padded to 4 KB multiples); the
     // 2-stage protocol waits for everything, so the surplus chunks are simply skipped and the stage is the bare image
-    constexpr int B_STAGE = (AMODE != 2) ? B_IMG : NLB * 4096;
-    // A ring depth: 2 for the fp32-A kernels (40 KB of LDS = 4 resident blocks per CU with 128x128 tiles, 52 KB = 3 with
-    // 128x192): with K <= 192 the fixed per-tile latencies (dispatch, first DMA, epilogue) weigh more than the depth of the
-    // pipeline and are hidden by the extra resident block; 3 (one A tile stays in flight across the step barrier) for the
-    // plane-operand contraction
-    constexpr int RING = (AMODE != 2) ? 2 : 3;
+    constexpr int B_STAGE = B_IMG;
+    // Two stages per operand: tile t + 1 is fetched (DMA) while tile t is consumed and waited for at the end of the step.  A
+    // deeper ring (one tile in flight across the barrier, counted vmcnt) was measured slower: with K <= 192 the fixed
+    // per-tile latencies (dispatch, first DMA, epilogue) weigh more than pipeline depth, and the smaller LDS footprint buys a
+    // third / fourth resident block per CU (40 KB with 128x128 tiles, 52 KB with 128x192) that hides them.
+    constexpr int RING = 2;
     char* As = reinterpret_cast<char*>(smem);                 // RING stages
     char* Bs = As + RING * A_STAGE;                           // 2 stages
     const int m0 = mt * BM, n0 = nt * BN;
@@ -138,14 +138,15 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
         char* dst = As + (tile % RING) * A_STAGE + wave * NLA * 1024;
         const char* src = baseA + tile * a_step;
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) glds16(src + offsA[i], dst + i * 1024);
+        for (int i = 0; i < NLA; ++i)
+            if (A_IMG % 4096 == 0 || (wave * NLA + i) * 1024 < A_IMG) glds16(src + offsA[i], dst + i * 1024);
     };
     auto issue_b = [&](int tile) {
         char* dst = Bs + (tile & 1) * B_STAGE + wave * NLB * 1024;
         const char* src = baseB + tile * b_step;
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
-            if (B_STAGE == NLB * 4096 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + offsB[i], dst + i * 1024);
+            if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + offsB[i], dst + i * 1024);
     };
 
     f32x16 acc[TM][TN];
@@ -162,15 +163,10 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
 #pragma unroll
     for (int i = 0; i < TM; ++i) ls[i] = lq[i] = lshift[i] = 0.f;
 
-    // prologue: A(0), B(0), A(1) in this order; the k-loop keeps exactly one A tile (NLA loads) in flight across its barrier
+    // prologue
     issue_a(0);
     issue_b(0);
-    if constexpr (RING == 3) {
-        issue_a(min(1, nk - 1));
-        wait_vm_and_barrier<NLA>();
-    } else {
-        wait_vm_and_barrier<0>();
-    }
+    wait_vm_and_barrier<0>();
 
     // per-lane LDS fragment offsets
     int offA[TM][AMODE == 0 ? 2 : 1];
@@ -192,7 +188,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     for (int j = 0; j < TN; ++j) offB[j] = plane_off<BN>(0, wn * WN + j * 32 + (lane & 31), h);
 
     for (int t = 0; t < nk; ++t) {
-        // next tiles: B(t+1) first, then A(t+2): the wait at the end of this step leaves only A(t+2) outstanding
+        // next tiles
         issue_b(min(t + 1, nk - 1));
         issue_a(min(t + RING - 1, nk - 1));
 
@@ -258,7 +254,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
                     for (int j = 0; j < JG; ++j)
                         acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
         }
-        wait_vm_and_barrier<RING == 3 ? NLA : 0>();
+        wait_vm_and_barrier<0>();
     }
     // drain the (redundant) tail DMA before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -293,9 +289,9 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
 template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;
-    constexpr int A_STAGE = (A_IMG + 4095) / 4096 * 4096;
-    constexpr int B_STAGE = (AMODE != 2) ? 3 * BN * 32 : (3 * BN * 32 + 4095) / 4096 * 4096;
-    constexpr int RING = (AMODE != 2) ? 2 : 3;
+    constexpr int A_STAGE = A_IMG;
+    constexpr int B_STAGE = 3 * BN * 32;
+    constexpr int RING = 2;
     constexpr int OPER = (RING * A_STAGE + 2 * B_STAGE) / 4;                       // floats
     constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;      // epilogue column group (gemm_epilogue.h)
     constexpr int SCR = 4 * 32 * ((TS ? WM : TGW * 32) + 4);
@@ -378,7 +374,8 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
     const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;
     const int force = (g.tune >> 1) & 7;                       // 1: 128x128, 2: 128x192 (benchmarking)
-    const bool wide = force ? force == 2 : (pad192 <= pad128 && g.N % 128 != 0);
+    // (the plane x plane contraction at L = 352 pads to 384 either way: the wide tile measured 10 % faster)
+    const bool wide = force ? force == 2 : (g.A_split ? pad192 <= pad128 : (pad192 <= pad128 && g.N % 128 != 0));
     // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
     // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
     if (wide) *rc = launch3<128, 192, 32, 192, 3>(g, st);

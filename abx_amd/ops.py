@@ -40,7 +40,9 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128
     if not exact and split and N > 64 and blocks128 >= 256 and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
         amode = 2 if a_split else (0 if a_kcontig else 1)
-        cfg = (128, 192, 32, 192, 3) if (wide192 and N % 128 != 0) else (128, 128, 32, 128, 4)
+        pad128, pad192 = ((N + 127) // 128) * 128, ((N + 191) // 192) * 192
+        wide = pad192 <= pad128 if a_split else (wide192 and N % 128 != 0)
+        cfg = (128, 192, 32, 192, 3) if wide else (128, 128, 32, 128, 4)
         return f'gemm3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {amode}, {b(transposed)}, {cfg[4]}>'
     if N <= 32:
         cfg = (128, 32, 32, 32, 3)
