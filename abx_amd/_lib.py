@@ -33,7 +33,9 @@ class AbxGemm(C.Structure):
         ('resid', c_f), ('sRb', LL), ('sRm', LL),
         ('B_split', C.c_void_p), ('sB3p', LL), ('sB3n', LL), ('sB3k', LL), ('sB3b', LL),
         ('A_split', C.c_void_p), ('sA3p', LL), ('sA3m', LL), ('sA3k', LL), ('sA3b', LL),
+        ('batch_inner', I), ('sA3i', LL), ('sB3i', LL),
         ('C_split', C.c_void_p), ('sCp', LL), ('sCk', LL), ('c_split_L', I),
+        ('glu', I),
         ('a_pair_transpose', I),
         ('exact', I),
         ('tune', I),

@@ -429,6 +429,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(gp != nullptr, "abx_gemm: null descriptor");
     AbxGemm g = *gp;
     ABX_REQUIRE((g.A || g.A_split) && (g.B || g.B_split) && (g.C || g.C_split), "abx_gemm: null operand");
+    ABX_REQUIRE(!g.glu || (g.c_transposed && g.N % 128 == 0 && !g.gate), "abx_gemm: glu needs a transposed store, N % 128 == 0, no gate");
     ABX_REQUIRE(!g.C_split || (g.c_transposed && g.c_split_L > 0 && g.c_split_L % 4 == 0 && g.M == (long long)g.c_split_L * g.c_split_L &&
                                g.sCm >= g.M),
                 "abx_gemm: C_split needs the transposed store of a pair tensor (M = L*L, L % 4 == 0)");
@@ -457,6 +458,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(g.A && g.B, "abx_gemm: split-bf16 operands given but the problem does not qualify for the split kernels "
                             "(K % 16, alignment, size) and no fp32 operands were passed for the exact kernel");
     ABX_REQUIRE(g.a_pair_transpose <= 0, "abx_gemm: a_pair_transpose is served by the split-bf16 kernels only");
+    ABX_REQUIRE(!g.glu, "abx_gemm: glu is served by the split-bf16 kernels only (large problems, K % 16 == 0)");
     const long long mt128 = ((long long)g.M + 127) / 128;
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);

@@ -125,11 +125,14 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
         }
         a_step = (long long)BK * g.sAk * 4;
     } else {
-        baseA = reinterpret_cast<const char*>(g.A_split + (long long)b * g.sA3b);
+        baseA = reinterpret_cast<const char*>(g.A_split + (g.batch_inner > 0 ? (long long)(b / g.batch_inner) * g.sA3b + (long long)(b % g.batch_inner) * g.sA3i
+                                                                                  : (long long)b * g.sA3b));
         plane_sources<BM, NLA>(g.sA3p, g.sA3m, m0, g.M, offsA);
         a_step = g.sA3k * 2;
     }
-    const char* baseB = reinterpret_cast<const char*>(g.B_split + (long long)b * g.sB3b);
+    const char* baseB = reinterpret_cast<const char*>(
+        g.B_split + ((g.batch_inner > 0 && g.A_split) ? (long long)(b / g.batch_inner) * g.sB3b + (long long)(b % g.batch_inner) * g.sB3i
+                                                      : (long long)b * g.sB3b));
     plane_sources<BN, NLB>(g.sB3p, g.sB3n, n0, g.N, offsB);
     const long long b_step = g.sB3k * 2;
     const int nk = g.K / BK;
@@ -357,6 +360,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if (!al16(g.B_split) || g.sB3n % 8 != 0 || g.sB3p % 8 != 0 || g.sB3b % 8 != 0 || g.sB3k % 8 != 0) return 1;
     if (g.A_split) {
         if (!al16(g.A_split) || g.sA3m % 8 != 0 || g.sA3p % 8 != 0 || g.sA3b % 8 != 0 || g.sA3k % 8 != 0 || g.c_transposed) return 1;
+        if (g.batch_inner > 0 && (g.sA3i % 8 != 0 || g.sB3i % 8 != 0)) return 1;
     } else if (g.sAk == 1) {
         if (!al16(g.A) || g.sAm % 4 != 0 || g.sAb % 4 != 0) return 1;
         if (g.a_pair_transpose > 0 && (long long)g.a_pair_transpose * g.a_pair_transpose != g.M) return 1;
@@ -375,7 +379,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;
     const int force = (g.tune >> 1) & 7;                       // 1: 128x128, 2: 128x192 (benchmarking)
     // (the plane x plane contraction at L = 352 pads to 384 either way: the wide tile measured 10 % faster)
-    const bool wide = force ? force == 2 : (g.A_split ? pad192 <= pad128 : (pad192 <= pad128 && g.N % 128 != 0));
+    const bool wide = g.glu ? false : force ? force == 2 : (g.A_split ? pad192 <= pad128 : (pad192 <= pad128 && g.N % 128 != 0));
     // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
     // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
     if (wide) *rc = launch3<128, 192, 32, 192, 3>(g, st);

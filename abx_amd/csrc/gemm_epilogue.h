@@ -143,8 +143,15 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
         constexpr int LWT = WM + 4, M4 = WM / 4, NQ = 32 * M4 / 64;
         float* wsc = scratch + wave * (32 * LWT);
         const bool rs_vec = g.rs_vec_ok != 0;
+        // glu: the tile's sub-tiles come in (value, gate) pairs (2jo, 2jo + 1) of the SAME output channels (the weights are
+        // packed that way): out = value * sigmoid(gate), N / 2 output columns - the gated projections of the triangle
+        // multiplication (seqformer.py:480-485) without a round trip of the gates through HBM
+        const bool glu = g.glu != 0;
+        const int jstep = glu ? 2 : 1;
+        const int Nout = glu ? g.N / 2 : g.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+            if (glu && (j & 1)) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -153,6 +160,15 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                     f32x4 v;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = epi1(acc[i][j][rq * 4 + c], wm * WM + mloc + c, j);
+                    if (glu) {
+                        if constexpr (TN % 2 == 0) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float gv = epi1(acc[i][(j | 1) < TN ? (j | 1) : j][rq * 4 + c], wm * WM + mloc + c, (j | 1) < TN ? (j | 1) : j);
+                                v[c] *= 1.0f / (1.0f + expf(-gv));
+                            }
+                        }
+                    }
                     *reinterpret_cast<f32x4*>(&wsc[(lane & 31) * LWT + mloc]) = v;
                 }
             }
@@ -162,12 +178,12 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             for (int q = 0; q < NQ; ++q) {
                 const int f = lane + 64 * q;
                 const int nl = f / M4, m4 = f % M4;
-                const int n = n0 + wn * WN + j * 32 + nl;
+                const int n = (n0 + wn * WN + j * 32) / jstep + nl;
                 const int m = m0 + wm * WM + m4 * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(&wsc[nl * LWT + m4 * 4]);
                 int cnt = 4;
                 if (EDGE) {
-                    if (m >= g.M || n >= g.N) continue;
+                    if (m >= g.M || n >= Nout) continue;
                     cnt = min(4, g.M - m);
                 }
                 if (rs) {

@@ -53,6 +53,11 @@ class Packed:
                 lin(name[:-7])
         for tm in ('triangle_multiplication_outgoing', 'triangle_multiplication_incoming'):
             fused(P_BLK + tm + '.lr_gates', [P_BLK + tm + s for s in ('.left_gate', '.right_gate')])
+            fused(P_BLK + tm + '.lr_proj', [P_BLK + tm + s for s in ('.left_proj', '.right_proj')])
+            # gated projections in one GEMM: (value, gate) column pairs of the same 256 channels (ops.pack_glu_weights)
+            self.wt[P_BLK + tm + '.lr_glu'], self.b[P_BLK + tm + '.lr_glu'] = ops.pack_glu_weights(
+                self.wt[P_BLK + tm + '.lr_proj'], self.wt[P_BLK + tm + '.lr_gates'],
+                self.b.get(P_BLK + tm + '.lr_proj'), self.b.get(P_BLK + tm + '.lr_gates'))
         for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
             fused(P_BLK + ta + '.qkvg', [P_BLK + ta + s for s in ('.attn.proj_q', '.attn.proj_k', '.attn.proj_v', '.attn.gate')])
         fused(P_BLK + 'outer_product_mean.lr', [P_BLK + 'outer_product_mean.left_proj', P_BLK + 'outer_product_mean.right_proj'])
@@ -283,20 +288,17 @@ class Engine:
             GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
             Gf = w768.view(-1)[Bc * 256 * LL:Bc * 448 * LL].view(Bc, LL, 192)
             pt = L if (planes and not outgoing) else 0
-            _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2, a_pair_transpose=pt)
             _ln_lin(P, pre + 'final_gate', pre + 'norm', None, z3, Gf, act=2)
             tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
             tz = tt.view(Bc * 128, L, L)
             if planes:
+                # one GEMM: [left | right] projections * sigmoid(their gates) * pair mask -> plane operands of the contraction
                 KT = (L + 15) // 16
-                lp = ws.get('tm_left', (Bc, 128, KT, 3, L, 16), torch.int16, zero=(L % 16 != 0))
-                rp = ws.get('tm_right', (Bc, 128, KT, 3, L, 16), torch.int16, zero=(L % 16 != 0))
-                _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, lp, rowscale=pmask,
-                        gate=GT[:, 0:128].transpose(1, 2), gate_sigmoid=False, a_pair_transpose=pt)
-                _ln_lin(P, pre + 'right_proj', pre + 'norm', None, z3, rp, rowscale=pmask,
-                        gate=GT[:, 128:256].transpose(1, 2), gate_sigmoid=False, a_pair_transpose=pt)
-                ops.gemm(lp.view(Bc * 128, KT, 3, L, 16), rp.view(Bc * 128, KT, 3, L, 16), tz)
+                lrp = ws.get('tm_lr', (Bc, 256, KT, 3, L, 16), torch.int16, zero=(L % 16 != 0))
+                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, z3, lrp, rowscale=pmask, glu=True, a_pair_transpose=pt)
+                ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz.view(Bc * 128, L, L))
             else:
+                _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2)
                 left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
                 right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
                 _ln_lin(P, pre + 'left_proj', pre + 'norm', None, z3, left.transpose(1, 2), rowscale=pmask,

@@ -63,6 +63,20 @@ def gemm_split_eligible(M, N, K, batch=1):
     return (not GEMM_EXACT) and N > 64 and K % 16 == 0 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256
 
 
+def pack_glu_weights(Wv, Wg, bv=None, bg=None):
+    """Column order of a glu GEMM: 32-column blocks [v0 | g0 | v1 | g1 | ...] of value weights Wv (K, C) and gate weights
+    Wg (K, C) for the same C output channels (C % 64 == 0).  Returns (W (K, 2C), bias (2C) or None)."""
+    K, C_ = Wv.shape
+    assert Wg.shape == (K, C_) and C_ % 64 == 0
+    W = torch.stack([Wv.reshape(K, C_ // 32, 32), Wg.reshape(K, C_ // 32, 32)], dim=2).reshape(K, 2 * C_).contiguous()
+    b = None
+    if bv is not None or bg is not None:
+        z = torch.zeros(C_, device=Wv.device, dtype=Wv.dtype)
+        b = torch.stack([(bv if bv is not None else z).reshape(C_ // 32, 32), (bg if bg is not None else z).reshape(C_ // 32, 32)],
+                        dim=1).reshape(2 * C_).contiguous()
+    return W, b
+
+
 def split_weights(Wt):
     """Wt (K, N) packed weight (n-contiguous) -> int16 tensor [Kp/16][3][N][16] of k-tiled bf16 planes with
     W = p0 + p1 + p2 exactly (operand image of the split-bf16 GEMM kernels); Kp = K rounded up to 16."""
@@ -75,7 +89,7 @@ def split_weights(Wt):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -83,15 +97,26 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     Split-bf16 operands (int16 tensors of k-tiled bf16 planes, x = p0 + p1 + p2): B3 (K/16,3,N,16) = split_weights(B);
     A (b,K/16,3,M,16) and B (b,K/16,3,N,16) both as planes: the TriangleMultiplication contraction; Cout (b,N,L/16,3,L,16)
     int16 (M = L*L pair rows, m = i*L + k): the output is written as the plane operand [n][k/16][plane][i][16] of that
-    contraction (transposed store).  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i."""
+    contraction (transposed store).  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i.
+    glu=True: B holds (value, gate) column pairs (pack_glu_weights); Cout has N/2 channels = value * sigmoid(gate)."""
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
+    if a_planes and A.dim() == 6:      # (Bo, Bi, K/16, 3, M, 16): two-level batch (channel slices of a wider per-sample tensor)
+        assert B.dtype == torch.int16 and B.dim() == 6 and B.shape[:2] == A.shape[:2]
+        g.batch_inner, g.sA3i, g.sB3i = A.shape[1], A.stride(1), B.stride(1)
+        bo_a, bo_b = A.stride(0), B.stride(0)
+        A = A.as_strided((A.shape[0] * A.shape[1],) + tuple(A.shape[2:]), (0,) + tuple(A.stride()[2:]), A.storage_offset())
+        B = B.as_strided((B.shape[0] * B.shape[1],) + tuple(B.shape[2:]), (0,) + tuple(B.stride()[2:]), B.storage_offset())
+    else:
+        bo_a = bo_b = None
     if a_planes:
         assert A.dim() == 5 and A.shape[2] == 3 and A.shape[4] == 16 and A.stride(4) == 1
         nb, KT, _, M, _ = A.shape
         K = KT * 16
         g.A_split, g.sA3b, g.sA3k, g.sA3p, g.sA3m = _p(A), (A.stride(0) if nb > 1 else 0), A.stride(1), A.stride(2), A.stride(3)
+        if bo_a is not None:
+            g.sA3b = bo_a
     else:
         if A.dim() == 2:
             A = A.unsqueeze(0)
@@ -102,6 +127,8 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         assert B.dim() == 5 and B.shape[2] == 3 and B.shape[4] == 16 and B.stride(4) == 1 and B.shape[1] * 16 == K and B.shape[0] == nb
         N = B.shape[3]
         g.B_split, g.sB3b, g.sB3k, g.sB3p, g.sB3n = _p(B), (B.stride(0) if nb > 1 else 0), B.stride(1), B.stride(2), B.stride(3)
+        if bo_b is not None:
+            g.sB3b = bo_b
     else:
         if B.dim() == 2:
             B = B.unsqueeze(0)
@@ -109,16 +136,17 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         N = B.shape[2]
         _f32(B)
         g.B, g.sBb, g.sBk, g.sBn = _p(B), (B.stride(0) if B.shape[0] > 1 else 0), B.stride(1), B.stride(2)
+    No = N // 2 if glu else N
     if c_planes:
         L = Cout.shape[4]
-        assert Cout.dim() == 6 and Cout.shape == (nb, N, (L + 15) // 16, 3, L, 16) and M == L * L, (Cout.shape, nb, M, N)
+        assert Cout.dim() == 6 and Cout.shape == (nb, No, (L + 15) // 16, 3, L, 16) and M == L * L, (Cout.shape, nb, M, N)
         assert Cout.stride(5) == 1 and Cout.stride(4) == 16
         g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), L
         g.c_transposed = 1
     else:
         if Cout.dim() == 2:
             Cout = Cout.unsqueeze(0)
-        assert Cout.shape == (nb, M, N), (Cout.shape, (nb, M, N))
+        assert Cout.shape == (nb, M, No), (Cout.shape, (nb, M, No))
         _f32(Cout)
         g.C = _p(Cout)
         Cl = Cout
@@ -130,6 +158,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             g.c_transposed, g.sCm = 1, Cl.stride(2)
     g.M, g.N, g.K, g.batch = M, N, K, nb
     g.a_pair_transpose = int(a_pair_transpose)
+    g.glu = int(bool(glu))
     if ln is not None:
         stats, csum = ln                     # stats None: the kernel derives (mean, rstd) from its own A stream
         assert csum.numel() == N

@@ -53,7 +53,10 @@ class OpTimer:
         if name == 'gemm':
             A, B, C = args[0], args[1], args[2]
             if A.dtype == torch.int16:          # k-tiled bf16 planes (b, K/16, 3, rows, 16): the tri-mul contraction
-                nb, M, K, N = A.shape[0], A.shape[3], A.shape[1] * 16, B.shape[3]
+                if A.dim() == 6:        # two-level batch (channel slices)
+                    nb, M, K, N = A.shape[0] * A.shape[1], A.shape[4], A.shape[2] * 16, B.shape[4]
+                else:
+                    nb, M, K, N = A.shape[0], A.shape[3], A.shape[1] * 16, B.shape[3]
                 kern = self.ops.gemm_kernel_name(M, N, K, nb, split=True, a_split=True)
                 return kern, 2.0 * nb * M * N * K, nb * (6.0 * (M + N) * K + 4.0 * M * N)
             nb = A.shape[0] if A.dim() == 3 else 1

@@ -65,10 +65,17 @@ typedef struct AbxGemm {
     const unsigned short* B_split; long long sB3p, sB3n, sB3k, sB3b;   /* B as planes (sB3b = 0: shared weights); used instead of B */
     const unsigned short* A_split; long long sA3p, sA3m, sA3k, sA3b;   /* A as planes, used instead of A: the TriangleMultiplication
                                                       contraction takes both operands this way (K % 16 == 0) */
+    int batch_inner; long long sA3i, sB3i;         /* batch_inner > 0: two-level batch of the plane operands, entry b sits at
+                                                      (b / batch_inner) * sX3b + (b % batch_inner) * sX3i (left / right channels of
+                                                      one sample inside a wider channel tensor) */
     unsigned short* C_split; long long sCp, sCk; int c_split_L;   /* write the output as planes instead of C, laid out as the
                                                       k-tiled OPERAND of the following contraction: with m = i*L + k (L =
                                                       c_split_L, transposed store only), element (m, n) of plane p goes to
                                                       C_split + b*sCb + n*sCm + (k/16)*sCk + p*sCp + i*16 + k%16 */
+    int glu;                                       /* transposed store only: the N columns are (value, gate) pairs of 32-column blocks
+                                                      [v0 | g0 | v1 | g1 | ...] of the same N/2 output channels (weights packed that
+                                                      way); out = epi(value) * sigmoid(epi(gate)), C / C_split have N/2 channels.
+                                                      Needs a kernel whose wave tile holds both blocks (split-bf16 128x128 tiles) */
     int a_pair_transpose;                          /* L > 0: M == L*L rows per batch are pair positions (i,k); row i*L + k of
                                                       the GEMM reads source row k*L + i (k-contiguous A, split-bf16 path only) */
     int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split

@@ -296,6 +296,41 @@ def test_gemm_split_bf16_plane_output_and_pair_transpose(ops):
         assert (_planes_to_f64(planes.cpu())[..., L_:] == 0).all()
 
 
+def test_gemm_split_bf16_glu_and_two_level_batch(ops):
+    """The gated projections of the triangle multiplication as ONE glu GEMM (value * sigmoid(gate) from (value, gate) column
+    pairs, plane output, pair mask, pair-transposed rows) and the contraction over channel slices of that tensor
+    (two-level batch of the plane operands)."""
+    B_, L_, K, C_ = 5, 120, 192, 256
+    LL = L_ * L_
+    Z = torch.randn(B_, L_, L_, K, generator=g(250)) * 1.5 + 0.3
+    Wv = torch.randn(C_, K, generator=g(251)) / K ** 0.5; Wg = torch.randn(C_, K, generator=g(252)) / K ** 0.5
+    bv = torch.randn(C_, generator=g(253)); bg = torch.randn(C_, generator=g(254))
+    ga = torch.randn(K, generator=g(255)); be = torch.randn(K, generator=g(256))
+    pm = (torch.rand(B_, L_, L_, generator=g(257)) > 0.2).float()
+    pm = pm * pm.transpose(1, 2)
+    Wp, bp = ops.pack_glu_weights(Wv.t().contiguous(), Wg.t().contiguous(), bv, bg)
+    assert Wp.shape == (K, 2 * C_) and torch.equal(Wp[:, 0:32], Wv.t()[:, 0:32]) and torch.equal(Wp[:, 32:64], Wg.t()[:, 0:32])
+    Wt, csum, bias2 = fold_ln(Wp.t().contiguous(), bp, ga, be)
+    w3 = ops.split_weights(Wt)
+    ln = torch.nn.functional.layer_norm(Z.double(), (K,), ga.double(), be.double(), 1e-5)
+    val = (ln @ Wv.double().t() + bv.double()) * torch.sigmoid(ln @ Wg.double().t() + bg.double()) * pm.double()[..., None]   # (B,L,L,C)
+    KT = (L_ + 15) // 16
+    for transpose in (False, True):
+        planes = torch.zeros(B_, C_, KT, 3, L_, 16, dtype=torch.int16, device=DEV)
+        ops.gemm(Z.to(DEV).view(B_, LL, K), Wt, planes, bias=bias2, ln=(None, csum), rowscale=pm.reshape(-1).contiguous().to(DEV),
+                 glu=True, B3=w3, a_pair_transpose=L_ if transpose else 0)
+        got = _planes_to_f64(planes.cpu())[..., :L_]                                    # (B, C, i, k)
+        want = (val.transpose(1, 2) if transpose else val).permute(0, 3, 1, 2)
+        e = float((got - want).abs().max() / want.abs().max())
+        assert e < 3e-6, (transpose, e)
+        # contraction over the channel halves: out[b,c,i,j] = sum_k left[b,c,i,k] right[b,c,j,k]
+        out = torch.full((B_ * 128, L_, L_), float('nan'), device=DEV)
+        ops.gemm(planes[:, 0:128], planes[:, 128:256], out)
+        ref = torch.einsum('bcik,bcjk->bcij', got[:, :128], got[:, 128:])
+        e = float((out.cpu().double().view(B_, 128, L_, L_) - ref).abs().max() / ref.abs().max())
+        assert e < 3e-6, ('contraction', transpose, e)
+
+
 def test_gemm_layouts_batched_transposed(ops):
     nb, M, N, K = 5, 72, 72, 72       # L = 72 triangle contraction shapes (not multiples of the tiles)
     X = torch.randn(nb, M, K, generator=g(12))
