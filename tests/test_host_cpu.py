@@ -149,3 +149,31 @@ def test_gather_results_gloo_world2():
                              env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert out.stdout.count('OK') == 2
+
+
+def test_glu_weight_packing_and_kernel_name_mirror():
+    """Host-side helpers of the split-bf16 path (no GPU): the (value, gate) column interleave of a glu GEMM and the
+    kernel-selection mirror that bench.py uses to label launches."""
+    import torch
+    from abx_amd import ops
+    K, C_ = 8, 128
+    Wv = torch.arange(K * C_, dtype=torch.float32).view(K, C_)
+    Wg = -Wv
+    bv, bg = torch.arange(C_, dtype=torch.float32), -torch.arange(C_, dtype=torch.float32)
+    W, b = ops.pack_glu_weights(Wv, Wg, bv, bg)
+    assert W.shape == (K, 2 * C_) and b.shape == (2 * C_,)
+    for blk in range(C_ // 32):
+        assert torch.equal(W[:, 64 * blk:64 * blk + 32], Wv[:, 32 * blk:32 * blk + 32])
+        assert torch.equal(W[:, 64 * blk + 32:64 * blk + 64], Wg[:, 32 * blk:32 * blk + 32])
+        assert torch.equal(b[64 * blk:64 * blk + 32], bv[32 * blk:32 * blk + 32])
+        assert torch.equal(b[64 * blk + 32:64 * blk + 64], bg[32 * blk:32 * blk + 32])
+    W2, b2 = ops.pack_glu_weights(Wv, Wg)
+    assert b2 is None and torch.equal(W2, W)
+    M2 = 20 * 352 * 352
+    assert ops.gemm_kernel_name(M2, 768, 192, 1, split=True) == 'gemm3_kernel<128, 128, 32, 128, 0, false, 4>'
+    assert ops.gemm_kernel_name(M2, 192, 768, 1, split=True) == 'gemm3_kernel<128, 192, 32, 192, 0, false, 3>'
+    assert ops.gemm_kernel_name(M2, 192, 128, 1, a_kcontig=False, split=True) == 'gemm3_kernel<128, 192, 32, 192, 1, false, 3>'
+    assert ops.gemm_kernel_name(352, 352, 352, 2560, split=True, a_split=True) == 'gemm3_kernel<128, 192, 32, 192, 2, false, 3>'
+    assert ops.gemm_kernel_name(7040, 256, 256, 1, split=True).startswith('gemm_kernel<64, 64')          # below the split threshold
+    assert ops.gemm_kernel_name(M2, 768, 192, 1, split=True, exact=True).startswith('gemm_kernel<128, 192')
+    assert ops.gemm_split_eligible(352 * 352, 128, 192, 20) and not ops.gemm_split_eligible(72 * 72, 128, 192, 3)
