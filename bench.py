@@ -177,7 +177,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='L352')
     ap.add_argument('--samples', type=int, default=100, help='samples per GPU')
-    ap.add_argument('--chunk', type=int, default=20)
+    ap.add_argument('--chunk', type=int, default=100, help='samples per pair-stack launch (workspace ~0.8 GB per sample at L = 352)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-op-profile', action='store_true')
     args = ap.parse_args()
