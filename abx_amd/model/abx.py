@@ -4,7 +4,7 @@ HIP kernels of libabx_hip.so (no PyTorch/CPU fallback: a missing library raises)
 
 Extensions (all optional, default = reference behaviour):
   batch['_shared_context'] = True   the B samples are copies of ONE complex -> trajectory-invariant embeddings are built once
-  ScoreNetwork.max_chunk            samples processed per pass through the pair stack (workspace size)
+  ScoreNetwork.max_chunk            samples per launch through the pair stack (workspace size); None = fit 45 % of the free HBM
 """
 import torch
 from torch import nn
@@ -24,6 +24,10 @@ def get_prev(batch, value, config):
     }
 
 
+# per-sample workspace of a pair-stack pass: w768 + w384 + bias/mask buffers + tri-mul plane operands ~ 6.6 KB per pair position
+_WORKSPACE_BYTES_PER_PAIR = 6600
+
+
 class ScoreNetwork(nn.Module):
     def __init__(self, model_conf, diffuser):
         super().__init__()
@@ -34,7 +38,8 @@ class ScoreNetwork(nn.Module):
         self.index_embed_size = c.index_embed_size
         self.impl = ScoreNetworkIteration(model_conf)
         self.diffuser = diffuser
-        self.max_chunk = 16
+        self._auto_chunks = {}
+        self.max_chunk = None            # None: as many samples per pair-stack launch as fit in 45 % of the free HBM
         self._engine = None
         self._engine_key = None
         self._static = None
@@ -51,6 +56,13 @@ class ScoreNetwork(nn.Module):
             self._engine_key = key
             self._static = None
         return self._engine
+
+    def _auto_chunk(self, B, L, device):
+        key = (B, L)
+        if key not in self._auto_chunks:         # decided once per problem size (the workspace itself eats into the free memory)
+            free, _ = torch.cuda.mem_get_info(device)
+            self._auto_chunks[key] = max(1, min(B, int(0.45 * free / (_WORKSPACE_BYTES_PER_PAIR * L * L))))
+        return self._auto_chunks[key]
 
     def invalidate_static(self):
         self._static = None
@@ -132,7 +144,7 @@ class ScoreNetwork(nn.Module):
         st['temb'] = torch.empty(B, c.index_embed_size, device=device)
         from abx_amd import ops
         ops.timestep_embedding(st['t64'], c.index_embed_size, st['temb'])
-        chunk = max(1, min(self.max_chunk, B))
+        chunk = max(1, min(self.max_chunk, B)) if self.max_chunk else self._auto_chunk(B, L, device)
         for b0 in range(0, B, chunk):
             eng.run_chunk(st, b0, min(B, b0 + chunk), final)
         folding = {

@@ -161,7 +161,7 @@ def test_medium_complex_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
     model.max_chunk = 2
     model.invalidate_static()
     ret = model(b)
-    model.max_chunk = 16
+    model.max_chunk = None
     ref = O.score_network(params, cpu, cfg, oracle_diffuser)
     f, fr = ret['heads']['folding'], ref['heads']['folding']
     agree = (ret['heads']['sequence_module']['seq_0'].cpu() == ref['heads']['sequence_module']['seq_0']).float().mean()
@@ -193,7 +193,7 @@ def test_split_bf16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_di
         bb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
         ops.GEMM_EXACT = exact
         try:
-            model.max_chunk = 16
+            model.max_chunk = None
             model.invalidate_static()
             r = model(bb)
             torch.cuda.synchronize()
@@ -231,7 +231,7 @@ def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_di
     gen = torch.Generator().manual_seed(5)
     noise = [dict(z_rot=torch.randn(B, L, 3, generator=gen), z_trans=torch.randn(B, L, 3, generator=gen),
                   jumps=torch.poisson(torch.full((B, L, 20), 0.02), generator=gen)) for _ in range(2)]
-    model.max_chunk = 16
+    model.max_chunk = None
     # ---- the warm-up call alone (inference.py:209-211), HIP vs oracle: the self-conditioning distogram is index work, and the
     # only pairs whose bin may differ are those whose predicted distance sits on a bin boundary
     from abx_amd.model.abx import get_prev
@@ -308,7 +308,7 @@ def test_full_size_properties(gpu_model, cfg):
     d = run(pb, 3, False)
     for k in a:
         assert torch.equal(a[k][perm], d[k]), f'sample permutation changed {k}'
-    model.max_chunk = 16
+    model.max_chunk = None
 
 
 def test_device_rng_sampling_is_shard_invariant(gpu_model, cfg):
