@@ -153,7 +153,8 @@ def _err(x, ref):
 def test_gemm_split_bf16_accuracy_vs_exact(ops):
     """The split-bf16 kernels (gemm3.hip) against float64, next to the exact fp32 MFMA kernel on the same problem: the
     split path must be as accurate as native fp32 (max error within 1.5x, mean error within 1.2x of the exact kernel)."""
-    for (M, N, K) in ((33000, 192, 192), (66000, 768, 192), (33000, 192, 768), (40000, 128, 192), (70000, 190, 100)):
+    for (M, N, K) in ((33000, 192, 192), (66000, 768, 192), (33000, 192, 768), (40000, 128, 192), (70000, 190, 100), (70001, 190, 192),
+                      (50003, 322, 128)):
         A = (torch.randn(M, K, generator=g(201)) * 3 + 0.7)
         W = torch.randn(N, K, generator=g(202)) / K ** 0.5
         b = torch.randn(N, generator=g(203))
