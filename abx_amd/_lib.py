@@ -37,6 +37,7 @@ class AbxGemm(C.Structure):
         ('C_split', C.c_void_p), ('sCp', LL), ('sCk', LL), ('c_split_L', I),
         ('glu', I),
         ('a_pair_transpose', I),
+        ('pair_L', I), ('pair_Lp', I), ('a_pair', I), ('c_pair', I),
         ('exact', I),
         ('tune', I),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
@@ -105,7 +106,7 @@ _PROTOS = {
     'abx_assemble_seq': (I, [c_f, LL, c_f, c_f, I, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_opm_features': (I, [c_f, c_f, LL, c_f, I, I, I, _S]),
-    'abx_pair_mask': (I, [c_f, c_f, I, I, _S]),
+    'abx_pair_mask': (I, [c_f, c_f, I, I, I, _S]),
     'abx_transpose_last2': (I, [c_f, c_f, I, I, _S]),
     'abx_pair_embed_features': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
     'abx_relpos_block': (I, [c_f, c_f, c_f, I, I, I, I, I, _S]),

@@ -53,11 +53,14 @@ __global__ void igso3_cdf_kernel(const float* __restrict__ pdf, int ns, int no, 
 // ------------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (device noise when none is injected)
 // ------------------------------------------------------------------------------------------------------------------
+// Counter layout: (sample id, residue, step, stream << 24 | draw).  The first three words identify WHOSE noise this is and are
+// never touched by next(); successive draws only advance the low 24 bits of the fourth word, so no two (sample, residue, step,
+// stream) tuples can ever share a block (a sample's noise does not depend on the batch it runs in or on its neighbours).
 struct Philox {
     uint32_t c[4], k[2];
-    __device__ Philox(unsigned long long seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    __device__ Philox(unsigned long long seed, uint32_t sid, uint32_t res, uint32_t step, uint32_t stream) {
         k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
-        c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+        c[0] = sid; c[1] = res; c[2] = step; c[3] = stream << 24;
     }
     __device__ void next(uint32_t* out) {
         uint32_t x[4] = {c[0], c[1], c[2], c[3]}, kk[2] = {k[0], k[1]};
@@ -70,7 +73,7 @@ struct Philox {
             kk[0] += 0x9E3779B9u; kk[1] += 0xBB67AE85u;
         }
         out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3];
-        if (++c[0] == 0) ++c[1];
+        c[3] = (c[3] & 0xff000000u) | ((c[3] + 1u) & 0x00ffffffu);
     }
 };
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)

@@ -204,13 +204,13 @@ __global__ __launch_bounds__(256) void opm_features_kernel(const float* __restri
     feat[p * 2 * C + C + c] = lv - rv;
 }
 
-__global__ void pair_mask_kernel(const float* __restrict__ mask, float* __restrict__ out, int B, int L) {
+__global__ void pair_mask_kernel(const float* __restrict__ mask, float* __restrict__ out, int B, int L, int Lp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * L * L) return;
-    const int j = (int)(idx % L);
-    const long long bi = idx / L;
+    if (idx >= (long long)B * L * Lp) return;
+    const int j = (int)(idx % Lp);
+    const long long bi = idx / Lp;
     const int b = (int)(bi / L);
-    out[idx] = mask[bi] * mask[(long long)b * L + j];
+    out[idx] = j < L ? mask[bi] * mask[(long long)b * L + j] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx,
@@ -379,10 +379,10 @@ extern "C" int abx_opm_features(const float* left, const float* right, long long
     return abx_check_launch("abx_opm_features");
 }
 
-extern "C" int abx_pair_mask(const float* mask, float* out, int B, int L, hipStream_t st) {
-    ABX_REQUIRE(mask && out && B > 0 && L > 0, "abx_pair_mask: bad args");
-    const long long total = (long long)B * L * L;
-    hipLaunchKernelGGL(pair_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mask, out, B, L);
+extern "C" int abx_pair_mask(const float* mask, float* out, int B, int L, int Lp, hipStream_t st) {
+    ABX_REQUIRE(mask && out && B > 0 && L > 0 && Lp >= L, "abx_pair_mask: bad args");
+    const long long total = (long long)B * L * Lp;
+    hipLaunchKernelGGL(pair_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mask, out, B, L, Lp);
     return abx_check_launch("abx_pair_mask");
 }
 

@@ -104,14 +104,20 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     long long a_step;                                          // bytes per k-tile
     if constexpr (AMODE == 0) {
         // offsets are relative to the tile's first row (to the batch base when the rows are pair-transposed)
-        const long long row0 = g.a_pair_transpose > 0 ? 0 : m0;
+        const bool remap = g.a_pair_transpose > 0 || g.a_pair != 0;
+        const long long row0 = remap ? 0 : m0;
         baseA = reinterpret_cast<const char*>(g.A + (long long)b * g.sAb + row0 * g.sAm);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int r = (wave * NLA + i) * 16 + (lane >> 2), p = lane & 3;
             const int kq = p ^ ((r >> 2) & 3);                 // physical 16-byte slot p of row r holds logical k-quad kq
             long long gr = min(m0 + r, g.M - 1);
-            if (g.a_pair_transpose > 0) gr = (gr % g.a_pair_transpose) * g.a_pair_transpose + gr / g.a_pair_transpose;
+            if (g.a_pair) {
+                // padded pair position (i, j) of the GEMM -> row of the unpadded pair tensor (pad columns re-read column L-1;
+                // their outputs are zeroed by the row scale / never stored)
+                const int pi = (int)(gr / g.pair_Lp), pj = min((int)(gr - (long long)pi * g.pair_Lp), g.pair_L - 1);
+                gr = g.a_pair_transpose > 0 ? (long long)pj * g.pair_L + pi : (long long)pi * g.pair_L + pj;
+            } else if (g.a_pair_transpose > 0) gr = (gr % g.a_pair_transpose) * g.a_pair_transpose + gr / g.a_pair_transpose;
             offsA[i] = (unsigned)(((gr - row0) * g.sAm + kq * 4) * 4);
         }
         a_step = BK * 4;
@@ -120,7 +126,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             const int kl = (wave * NLA + i) * 2 + (lane >> 5), mq = lane & 31;     // LDS [k][BM]: 2 k-rows per instruction
-            const int gm = min(m0 + mq * 4, g.M - 4) - m0;
+            const int gm = min(m0 + mq * 4, g.M - 4) - m0;                         // (M % 4 == 0: checked by the dispatch)
             offsA[i] = (unsigned)(((long long)kl * g.sAk + gm) * 4);
         }
         a_step = (long long)BK * g.sAk * 4;
@@ -363,7 +369,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         if (g.batch_inner > 0 && (g.sA3i % 8 != 0 || g.sB3i % 8 != 0)) return 1;
     } else if (g.sAk == 1) {
         if (!al16(g.A) || g.sAm % 4 != 0 || g.sAb % 4 != 0) return 1;
-        if (g.a_pair_transpose > 0 && (long long)g.a_pair_transpose * g.a_pair_transpose != g.M) return 1;
+        if (g.a_pair_transpose > 0 && !g.a_pair && (long long)g.a_pair_transpose * g.a_pair_transpose != g.M) return 1;
     } else {
         if (!al16(g.A) || g.sAk % 4 != 0 || g.sAb % 4 != 0 || g.M % 4 != 0 || g.M < 4 || g.a_pair_transpose > 0) return 1;
     }
@@ -371,7 +377,9 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     // columns (N = 768: q|k|v|gate, transition hidden); N = 192 / 448 take the wide tile
     // per-lane DMA offsets are 32-bit, relative to the tile's first row (k-contiguous A), to the batch base (pair-transposed
     // rows, plane operands) or to the tile's first column (row-contiguous A)
-    if (!g.A_split && g.sAk == 1 && (g.a_pair_transpose > 0 ? (long long)g.M * g.sAm : 128LL * g.sAm) >= (1LL << 30)) return 1;
+    if (!g.A_split && g.sAk == 1 && ((g.a_pair_transpose > 0 || g.a_pair) ? (long long)g.M * g.sAm : 128LL * g.sAm) >= (1LL << 30)) return 1;
+    if (g.pair_Lp > 0 && g.c_pair && g.c_transposed) return 1;
+    if (g.a_pair && (g.A_split || g.sAk != 1)) return 1;
     if (!g.A_split && g.sAk != 1 && 16LL * g.sAk + g.M >= (1LL << 30)) return 1;
     if (((long long)g.M + 127) / 128 * (((long long)g.N + 127) / 128) * g.batch >= (1LL << 31)) return 1;
     if (g.A_split && (long long)(g.K / 16) * g.sA3k >= (1LL << 31)) return 1;

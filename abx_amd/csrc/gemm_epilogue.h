@@ -130,7 +130,13 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
 #pragma unroll
                         for (int c = 0; c < 4; ++c) v[c] *= s;
                     }
-                    epi2_store(v, (long long)m * g.sCm + n, (long long)m * g.sGm + n, (long long)m * g.sRm + n, cnt, m, n);
+                    long long mo = m;                       // row of C / gate / resid
+                    if (g.c_pair) {                         // padded pair position (i, j) -> unpadded pair row; pad columns dropped
+                        const int pi = m / g.pair_Lp, pj = m - pi * g.pair_Lp;
+                        if (pj >= g.pair_L) continue;
+                        mo = (long long)pi * g.pair_L + pj;
+                    }
+                    epi2_store(v, mo * g.sCm + n, mo * g.sGm + n, mo * g.sRm + n, cnt, m, n);
                 }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -253,13 +253,20 @@ class FullDiffuser:
         q = torch.where(q < 1e-8, torch.zeros_like(q), q)
         x0c = torch.clamp(seq_0, 0, 19).long()
         rows = torch.gather(q, 1, x0c[..., None].expand(B, L, 20))
-        x_t = noise['seq_xt'].to(dev) if noise and 'seq_xt' in noise else torch.distributions.Categorical(rows).sample()
+        def cat_draw(probs, key, ukey):
+            # recorded draw (parity) | inverse-cdf of a supplied uniform (per-sample keyed noise) | torch's global generator
+            if noise and key in noise:
+                return noise[key].to(dev)
+            if noise and ukey in noise:
+                cdf = torch.cumsum(probs, dim=-1)
+                u = noise[ukey].to(dev).reshape(probs.shape[:-1])[..., None] * cdf[..., -1:]
+                return torch.clamp(torch.sum(cdf <= u, dim=-1), max=probs.shape[-1] - 1)
+            return torch.distributions.Categorical(probs).sample()
+        x_t = cat_draw(rows, 'seq_xt', 'u_xt')
         rate_rows = self.rate_const * (1.0 - torch.nn.functional.one_hot(x_t.long(), 20).float())      # (B,L,20), diagonal zeroed
-        dims = noise['seq_dim'].to(dev) if noise and 'seq_dim' in noise else \
-            torch.distributions.Categorical(rate_rows.sum(-1)).sample()
+        dims = cat_draw(rate_rows.sum(-1), 'seq_dim', 'u_dim')
         bidx = torch.arange(B, device=dev)
-        newv = noise['seq_new'].to(dev) if noise and 'seq_new' in noise else \
-            torch.distributions.Categorical(rate_rows[bidx, dims]).sample()
+        newv = cat_draw(rate_rows[bidx, dims], 'seq_new', 'u_new')
         seq_t = x_t.clone()
         seq_t[bidx, dims] = newv
         if diffuse_mask is not None:

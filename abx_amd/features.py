@@ -186,6 +186,28 @@ def make_diffuser_features(batch, generate_area, diffuser, diff_conf=None, opt_s
     return batch
 
 
+def per_sample_init_noise(sample_ids, L, seed, device=None):
+    """Init-time noise keyed by (seed, sample id): one CPU generator per sample, drawn with shape (1, L, ...) in the reference's
+    order (SURVEY.md §7 hard part 2: randn(B,L,3) axis, rand(B,L), randn(B,L,3), randint(B,L)), so a sample's starting point does
+    not depend on the batch or on the rank it runs in.  The extra uniforms feed forward_marginal's categorical draws (optimize mode).
+    Returns the `noise=` dict of FullDiffuser.sample_ref / forward_marginal."""
+    ids = [int(i) for i in (sample_ids.tolist() if torch.is_tensor(sample_ids) else sample_ids)]
+    cols = {k: [] for k in ('rot_axis', 'rot_u', 'trans_z', 'seq', 'u_xt', 'u_dim', 'u_new')}
+    for sid in ids:
+        g = torch.Generator().manual_seed((int(seed) * 0x9E3779B1 + sid * 0x85EBCA77 + 0x165667B1) & 0x7FFFFFFFFFFFFFFF)
+        cols['rot_axis'].append(torch.randn(1, L, 3, generator=g))
+        cols['rot_u'].append(torch.rand(1, L, generator=g))
+        cols['trans_z'].append(torch.randn(1, L, 3, generator=g))
+        cols['seq'].append(torch.randint(low=0, high=20, size=(1, L), generator=g))
+        cols['u_xt'].append(torch.rand(1, L, generator=g))
+        cols['u_dim'].append(torch.rand(1, generator=g))
+        cols['u_new'].append(torch.rand(1, generator=g))
+    if not ids:
+        return None
+    out = {k: torch.cat(v, dim=0) for k, v in cols.items()}
+    return {k: v.to(device) for k, v in out.items()} if device is not None else out
+
+
 def build_features(batch, diffuser, generate_area='H3', opt_step=None, noise=None, device=None):
     """The whole inference feature pipeline on a collated batch (config_data_feature.json order)."""
     if device is not None:

@@ -5,6 +5,13 @@ HIP kernels of libabx_hip.so (no PyTorch/CPU fallback: a missing library raises)
 Extensions (all optional, default = reference behaviour):
   batch['_shared_context'] = True   the B samples are copies of ONE complex -> trajectory-invariant embeddings are built once
   ScoreNetwork.max_chunk            samples per launch through the pair stack (workspace size); None = fit 45 % of the free HBM
+
+Lifetime of what a call returns: `representations` and `_prev_pos` are views of two internal ping-pong buffers (a (B,L,L,192)
+tensor is 9.5 GB at B = 100, L = 352).  A pass never writes the buffer that `batch['prev_pair']` currently points to, so the
+self-conditioning input of the next call is always intact; the representations returned by call n are overwritten during call
+n + 1.  Callers that keep them longer set `ScoreNetwork.clone_outputs = True` (fresh tensors, as the reference returns).
+The trajectory-invariant embeddings travel in `batch['_static']`: their lifetime is that of the batch dict they were built from
+(a new dict = a new complex = recomputed), never that of the module.
 """
 import torch
 from torch import nn
@@ -26,6 +33,7 @@ def get_prev(batch, value, config):
 
 # per-sample workspace of a pair-stack pass: w768 + w384 + bias/mask buffers + tri-mul plane operands ~ 6.6 KB per pair position
 _WORKSPACE_BYTES_PER_PAIR = 6600
+_MAX_CHUNK = 8192
 
 
 class ScoreNetwork(nn.Module):
@@ -40,11 +48,10 @@ class ScoreNetwork(nn.Module):
         self.diffuser = diffuser
         self._auto_chunks = {}
         self.max_chunk = None            # None: as many samples per pair-stack launch as fit in 45 % of the free HBM
+        self.clone_outputs = False
         self._engine = None
         self._engine_key = None
-        self._static = None
-        self._static_key = None
-        self._flip = 0
+        self._engine_serial = 0
         self._bufs = {}
 
     # ---- engine / packing ----------------------------------------------------------------------------------------
@@ -54,18 +61,27 @@ class ScoreNetwork(nn.Module):
             _lib.load()                                    # raises if the HIP library is missing
             self._engine = Engine(self._model_conf, Packed(self.state_dict(), device), device)
             self._engine_key = key
-            self._static = None
+            self._engine_serial += 1
+            self._auto_chunks = {}
         return self._engine
 
     def _auto_chunk(self, B, L, device):
+        """Samples per pair-stack launch.  Decided from the free HBM when the workspace for this problem size does not exist yet
+        (the workspace a previous decision allocated counts as available: it is what gets reused or replaced), and clamped to
+        the grid limits of the kernels (abx_transpose_last2 / abx_tri_attn_fwd: 4 * chunk, chunk <= 65535)."""
         key = (B, L)
-        if key not in self._auto_chunks:         # decided once per problem size (the workspace itself eats into the free memory)
-            free, _ = torch.cuda.mem_get_info(device)
-            self._auto_chunks[key] = max(1, min(B, int(0.45 * free / (_WORKSPACE_BYTES_PER_PAIR * L * L))))
-        return self._auto_chunks[key]
+        held = sum(b.numel() * b.element_size() for b in self._engine.ws.bufs.values()) if self._engine is not None else 0
+        need = _WORKSPACE_BYTES_PER_PAIR * L * L
+        hit = self._auto_chunks.get(key)
+        if hit is not None and hit * need <= held * 1.05:
+            return hit
+        free, _ = torch.cuda.mem_get_info(device)
+        chunk = max(1, min(B, _MAX_CHUNK, int(0.45 * (free + held) / need)))
+        self._auto_chunks[key] = chunk
+        return chunk
 
     def invalidate_static(self):
-        self._static = None
+        """Kept for callers of round-1 builds: the static embeddings now live in the batch dict (batch['_static'])."""
 
     def _buf(self, name, shape, dtype, device):
         b = self._bufs.get(name)
@@ -89,10 +105,13 @@ class ScoreNetwork(nn.Module):
                          prev_seq=torch.zeros([B, L, WS_], device=device),
                          prev_pair=torch.zeros([B, L, L, WZ], device=device))
         shared = bool(batch.get('_shared_context', False)) or B == 1
-        skey = (B, L, shared, batch['seq'].data_ptr(), batch['fixed_mask'].data_ptr(), batch['atom14_gt_positions'].data_ptr())
-        if self._static is None or self._static_key != skey:
-            self._static = eng.static_embeddings(batch, shared)
-            self._static_key = skey
+        # Residue/PairEmbedding depend on the fixed context only: built once per batch dict and carried in it
+        skey = (id(self), self._engine_serial, B, L, shared)
+        hit = batch.get('_static')
+        if hit is None or hit[0] != skey:
+            hit = (skey, eng.static_embeddings(batch, shared))
+            batch['_static'] = hit
+        self._static = hit[1]
         num_recycle = self._model_conf.num_recycle
         with torch.no_grad():
             batch.update(is_recycling=True)
@@ -111,10 +130,16 @@ class ScoreNetwork(nn.Module):
         c = self._model_conf.embeddings_and_seqformer
         WS_, WZ = c.seq_channel + c.index_embed_size, c.pair_channel + 2 * c.index_embed_size
         NC = self._model_conf.heads.diffusion_module.IPA.num_channel
-        # ping-pong representation buffers: the output never aliases prev_* (self-conditioning input)
-        self._flip ^= 1
-        tag = str(self._flip)
+        # ping-pong representation buffers: write the one that batch['prev_*'] does NOT point to (the self-conditioning input of
+        # this pass); foreign prev_* tensors (first call, reference-style drivers) leave both free
         f32, i64 = torch.float32, torch.int64
+        busy = {batch[k].data_ptr() for k in ('prev_seq', 'prev_pair', 'prev_pos') if torch.is_tensor(batch.get(k))}
+        tag = '0'
+        for cand in ('0', '1'):
+            mine = [self._bufs.get(n + cand) for n in ('rep_seq', 'rep_pair', 'prev_pos')]
+            if not any(b is not None and b.data_ptr() in busy for b in mine):
+                tag = cand
+                break
         t = batch['t']
         t_is_f32 = t.dtype != torch.float64
         st = dict(
@@ -158,4 +183,7 @@ class ScoreNetwork(nn.Module):
                '_prev_pos': st['prev_pos_out']}
         if final:
             ret['heads']['predicted_lddt'] = {'pLDDT': st['pLDDT']}
+            if self.clone_outputs:
+                ret['representations'] = {k: v.clone() for k, v in ret['representations'].items()}
+                ret['_prev_pos'] = ret['_prev_pos'].clone()
         return ret

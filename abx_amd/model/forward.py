@@ -281,23 +281,39 @@ class Engine:
         # Large problems run the contraction on the split-bf16 kernels: the projections write left/right directly as the
         # k-tiled bf16 plane operands of the contraction (C_split), and the incoming variant reads z pair-transposed
         # (a_pair_transpose) so that both einsums become the same row-major 'ik,jk->ij' product.
-        planes = ops.gemm_split_eligible(LL, 128, 192, Bc) and L % 4 == 0
+        # Any residue count: inside the triangle multiplication the pair positions are indexed with a row stride Lp = L rounded
+        # up to 4 (m' = i*Lp + j), so that plane rows, float4 stores and the channel-major product stay 16-byte aligned; the
+        # projections read / the output projection writes the unpadded pair tensor through the row maps a_pair / c_pair, and
+        # the padded row scale zeroes the pad columns of the contraction operands.
+        planes = ops.gemm_split_eligible(LL, 128, 192, Bc)
+        Lp = (L + 3) // 4 * 4
+        LLp = L * Lp
+        pad = (L, Lp) if Lp != L else None
         for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
             pre = P_BLK + name + '.'
             # sigmoid(left_gate | right_gate) channel-major like the projections they gate; sigmoid(final_gate) row-major
             GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
             Gf = w768.view(-1)[Bc * 256 * LL:Bc * 448 * LL].view(Bc, LL, 192)
-            pt = L if (planes and not outgoing) else 0
             _ln_lin(P, pre + 'final_gate', pre + 'norm', None, z3, Gf, act=2)
-            tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
-            tz = tt.view(Bc * 128, L, L)
             if planes:
                 # one GEMM: [left | right] projections * sigmoid(their gates) * pair mask -> plane operands of the contraction
-                KT = (L + 15) // 16
-                lrp = ws.get('tm_lr', (Bc, 256, KT, 3, L, 16), torch.int16, zero=(L % 16 != 0))
-                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, z3, lrp, rowscale=pmask, glu=True, a_pair_transpose=pt)
-                ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz.view(Bc * 128, L, L))
+                KT = (Lp + 15) // 16
+                lrp = ws.get('tm_lr', (Bc, 256, KT, 3, L, 16), torch.int16, zero=(Lp % 16 != 0))
+                if pad is None:
+                    pm = pmask
+                else:
+                    pm = ws.get('pmask_p', (Bc * LLp,))
+                    ops.pair_mask(mask_f, pm, Bc, L, Lp)
+                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, z3, lrp, rowscale=pm, glu=True,
+                        a_pair_transpose=0 if outgoing else L, pair=pad, a_pair=pad is not None)
+                tt = w384[:Bc * 128 * LLp].view(Bc, 128, LLp)      # channel-major product, padded pair rows (pads: never stored)
+                tz = tt.as_strided((Bc * 128, L, L), (LLp, Lp, 1))
+                ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz)
+                _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tt.transpose(1, 2), z3, gate=Gf, gate_sigmoid=False,
+                        resid=z3, pair=pad, c_pair=pad is not None)
             else:
+                tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
+                tz = tt.view(Bc * 128, L, L)
                 _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2)
                 left = w384[0:Bc * 128 * LL].view(Bc, 128, LL)
                 right = w384[Bc * 128 * LL:2 * Bc * 128 * LL].view(Bc, 128, LL)
@@ -311,8 +327,8 @@ class Engine:
                     ops.gemm(lz, rz.transpose(1, 2), tz)
                 else:             # 'bkic,bkjc->bijc'
                     ops.gemm(lz.transpose(1, 2), rz, tz)
-            tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
-            _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=Gf, gate_sigmoid=False, resid=z3)
+                tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
+                _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=Gf, gate_sigmoid=False, resid=z3)
         # ---------------- triangle attention (seqformer.py:506-550)
         for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
             pre = P_BLK + name + '.'

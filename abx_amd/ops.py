@@ -89,7 +89,7 @@ def split_weights(Wt):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -98,7 +98,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     A (b,K/16,3,M,16) and B (b,K/16,3,N,16) both as planes: the TriangleMultiplication contraction; Cout (b,N,L/16,3,L,16)
     int16 (M = L*L pair rows, m = i*L + k): the output is written as the plane operand [n][k/16][plane][i][16] of that
     contraction (transposed store).  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i.
-    glu=True: B holds (value, gate) column pairs (pack_glu_weights); Cout has N/2 channels = value * sigmoid(gate)."""
+    glu=True: B holds (value, gate) column pairs (pack_glu_weights); Cout has N/2 channels = value * sigmoid(gate).
+    pair=(L, Lp): the M rows are padded pair positions i*Lp + j (Lp % 4 == 0, any L); a_pair: A is the UNpadded (b, L*L, K) pair
+    tensor; c_pair: Cout / gate / resid are UNpadded (b, L*L, N) pair tensors (pad rows dropped).  rowscale is indexed by GEMM row."""
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
@@ -123,6 +125,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         nb, M, K = A.shape
         _f32(A)
         g.A, g.sAb, g.sAm, g.sAk = _p(A), A.stride(0) if nb > 1 else 0, A.stride(1), A.stride(2)
+        if a_pair:
+            assert pair is not None and M == pair[0] * pair[0], (A.shape, pair)
+            M = pair[0] * pair[1]
     if b_planes:
         assert B.dim() == 5 and B.shape[2] == 3 and B.shape[4] == 16 and B.stride(4) == 1 and B.shape[1] * 16 == K and B.shape[0] == nb
         N = B.shape[3]
@@ -139,14 +144,15 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     No = N // 2 if glu else N
     if c_planes:
         L = Cout.shape[4]
-        assert Cout.dim() == 6 and Cout.shape == (nb, No, (L + 15) // 16, 3, L, 16) and M == L * L, (Cout.shape, nb, M, N)
+        Lp = pair[1] if pair is not None else L
+        assert Cout.dim() == 6 and Cout.shape == (nb, No, (Lp + 15) // 16, 3, L, 16) and M == L * Lp, (Cout.shape, nb, M, N)
         assert Cout.stride(5) == 1 and Cout.stride(4) == 16
-        g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), L
+        g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), Lp
         g.c_transposed = 1
     else:
         if Cout.dim() == 2:
             Cout = Cout.unsqueeze(0)
-        assert Cout.shape == (nb, M, No), (Cout.shape, (nb, M, No))
+        assert Cout.shape == (nb, pair[0] * pair[0] if c_pair else M, No), (Cout.shape, (nb, M, No))
         _f32(Cout)
         g.C = _p(Cout)
         Cl = Cout
@@ -158,6 +164,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             g.c_transposed, g.sCm = 1, Cl.stride(2)
     g.M, g.N, g.K, g.batch = M, N, K, nb
     g.a_pair_transpose = int(a_pair_transpose)
+    if pair is not None:
+        g.pair_L, g.pair_Lp, g.a_pair, g.c_pair = int(pair[0]), int(pair[1]), int(bool(a_pair)), int(bool(c_pair))
+        assert M == pair[0] * pair[1], (M, pair)
     g.glu = int(bool(glu))
     if ln is not None:
         stats, csum = ln                     # stats None: the kernel derives (mean, rstd) from its own A stream
@@ -182,13 +191,13 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         if gate.dim() == 2:
             gate = gate.unsqueeze(0)
         cd, sd = (1, 2) if g.c_transposed else (2, 1)
-        assert gate.shape == (nb, M, N) and gate.stride(cd) == 1, 'gate must be laid out like Cout'
+        assert gate.shape == (nb, M if c_planes else Cout.shape[1], N) and gate.stride(cd) == 1, 'gate must be laid out like Cout'
         g.gate, g.sGb, g.sGm, g.gate_sigmoid = _p(_f32(gate)), (gate.stride(0) if nb > 1 else 0), gate.stride(sd), int(gate_sigmoid)
     if resid is not None:
         if resid.dim() == 2:
             resid = resid.unsqueeze(0)
         cd, sd = (1, 2) if g.c_transposed else (2, 1)
-        assert resid.shape == (nb, M, N) and resid.stride(cd) == 1, 'resid must be laid out like Cout'
+        assert resid.shape == (nb, M if c_planes else Cout.shape[1], N) and resid.stride(cd) == 1, 'resid must be laid out like Cout'
         g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(sd)
     check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
     return Cout
@@ -322,8 +331,9 @@ def opm_features(lr, feat, B, L, C_=64):
     return feat
 
 
-def pair_mask(mask_f, out, B, L):
-    check(_lib.load().abx_pair_mask(_p(mask_f), _p(out), B, L, _stream()), 'abx_pair_mask')
+def pair_mask(mask_f, out, B, L, Lp=None):
+    """out (B, L, Lp) = mask_i * mask_j, zero in the pad columns j >= L (Lp defaults to L)."""
+    check(_lib.load().abx_pair_mask(_p(mask_f), _p(out), B, L, L if Lp is None else Lp, _stream()), 'abx_pair_mask')
     return out
 
 

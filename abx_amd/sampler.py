@@ -43,8 +43,7 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
         opt_step = float(batch['t'][0])
         if opt_step < 1.0:
             steps = steps[steps <= opt_step + eps]
-    if hasattr(model, 'invalidate_static'):
-        model.invalidate_static()
+    batch.pop('_static', None)          # trajectory-invariant embeddings: rebuilt once per trajectory from THIS batch
     traj = []
     with torch.no_grad():
         if sc_conf.embed.embed_self_conditioning and self_condition and len(steps) > 0:
@@ -118,23 +117,33 @@ def gather_results(local, num_samples, rank, world_size, group=None):
 
 
 def design_samples(complex_feats, config, diffuser, model, num_samples, rank=0, world_size=1, mode='design', num_t=100,
-                   seed=0, group=None, features_fn=None):
+                   seed=0, group=None, features_fn=None, generate_area='H3', opt_step=None):
     """num_samples independent designs of ONE complex, sharded over ranks, gathered at the end.
     complex_feats: un-batched raw tensors of the complex on the device (abx_amd.synthetic.make_complex layout).
-    features_fn(batch, sample_ids) builds the per-sample diffusion features (noise initialisation)."""
+    features_fn(batch, sample_ids) builds the per-sample diffusion features; the default is the inference feature pipeline with
+    init noise keyed by (seed, sample id) (features.per_sample_init_noise), so that — together with the per-sample Philox keys of
+    the reverse step — a sample's whole trajectory is independent of the rank and of the batch it runs in.
+    Ranks without samples (world_size > num_samples) still take part in the gather, with zero-row blocks."""
+    from abx_amd import features
     ids = shard_sample_ids(num_samples, rank, world_size)
     n = len(ids)
     device = next(iter(v for v in complex_feats.values() if torch.is_tensor(v))).device
-    local = {}
+    L, Lab = complex_feats['seq'].shape[0], complex_feats['anchor_flag'].shape[0]
     if n > 0:
         batch = {k: v[None].expand(n, *v.shape).contiguous() for k, v in complex_feats.items()}
         sid = torch.tensor(ids, device=device, dtype=torch.int64)
-        batch = features_fn(batch, sid)
+        if features_fn is None:
+            batch = features.build_features(batch, diffuser, generate_area=generate_area, opt_step=opt_step,
+                                            noise=features.per_sample_init_noise(ids, L, seed, device))
+        else:
+            batch = features_fn(batch, sid)
         batch['_shared_context'] = True
         diffuser.seed = seed
         traj = sample_fn(batch, config, diffuser, model, mode=mode, num_t=num_t, sample_ids=sid)
         last = traj[-1]
         local = {'rigids': last['rigids_t'].double(), 'seq': last['seq'], 'atom14': last['atom14_results'], 'pLDDT': last['pLDDT']}
     else:
-        raise ValueError('more ranks than samples')
+        local = {'rigids': torch.zeros(0, L, 7, dtype=torch.float64, device=device),
+                 'seq': torch.zeros(0, Lab, dtype=torch.int64, device=device),
+                 'atom14': torch.zeros(0, Lab, 14, 3, device=device), 'pLDDT': torch.zeros(0, Lab, device=device)}
     return gather_results(local, num_samples, rank, world_size, group)

@@ -70,7 +70,7 @@ typedef struct AbxGemm {
                                                       one sample inside a wider channel tensor) */
     unsigned short* C_split; long long sCp, sCk; int c_split_L;   /* write the output as planes instead of C, laid out as the
                                                       k-tiled OPERAND of the following contraction: with m = i*L + k (L =
-                                                      c_split_L, transposed store only), element (m, n) of plane p goes to
+                                                      c_split_L, M % L == 0, transposed store only), element (m, n) of plane p goes to
                                                       C_split + b*sCb + n*sCm + (k/16)*sCk + p*sCp + i*16 + k%16 */
     int glu;                                       /* transposed store only: the N columns are (value, gate) pairs of 32-column blocks
                                                       [v0 | g0 | v1 | g1 | ...] of the same N/2 output channels (weights packed that
@@ -78,6 +78,15 @@ typedef struct AbxGemm {
                                                       Needs a kernel whose wave tile holds both blocks (split-bf16 128x128 tiles) */
     int a_pair_transpose;                          /* L > 0: M == L*L rows per batch are pair positions (i,k); row i*L + k of
                                                       the GEMM reads source row k*L + i (k-contiguous A, split-bf16 path only) */
+    int pair_L, pair_Lp;                           /* pair_Lp > 0: the M rows of the GEMM are PADDED pair positions m = i*pair_Lp + j
+                                                      (i < pair_L, j < pair_Lp, pair_Lp % 4 == 0, M == pair_L*pair_Lp): any residue
+                                                      count L keeps 16-byte aligned pair rows inside the triangle multiplication
+                                                      (split-bf16 path only).  With C_split, c_split_L == pair_Lp */
+    int a_pair;                                    /* A rows live in the UNpadded pair tensor: GEMM row (i,j) reads source row
+                                                      i*pair_L + min(j, pair_L-1), or min(j, pair_L-1)*pair_L + i when
+                                                      a_pair_transpose != 0 (k-contiguous fp32 A) */
+    int c_pair;                                    /* C / gate / resid rows live in the UNpadded pair tensor: GEMM row (i,j) is
+                                                      stored at row i*pair_L + j, rows with j >= pair_L are dropped (plain store) */
     int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split
                                                       into 3 bf16 pieces, 6 products, fp32 accumulate - csrc/gemm3.hip);
                                                       1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) */
@@ -158,8 +167,9 @@ int abx_opm_features(const float* left, const float* right, long long ld, float*
 /* out[n][j][i] = in[n][i][j] for nmat L x L matrices: the ending-node triangle attention reads its (4, L, L) pair bias
  * transposed ('b i j c -> b j i c', seqformer.py:536) so that both orientations read it key-contiguously */
 int abx_transpose_last2(const float* in, float* out, int nmat, int L, hipStream_t stream);
-/* pair mask[b,i,j] = mask[b,i]*mask[b,j] */
-int abx_pair_mask(const float* mask, float* out, int B, int L, hipStream_t stream);
+/* pair mask[b,i,j] = mask[b,i]*mask[b,j], rows of Lp >= L entries (columns j >= L are written as 0: the padded pair rows of
+ * AbxGemm.pair_Lp) */
+int abx_pair_mask(const float* mask, float* out, int B, int L, int Lp, hipStream_t stream);
 
 /* Trajectory-invariant encoders (encoder.py:123-269, seqformer.py:177-206): gather/concat stages; the MLPs run on abx_gemm. */
 int abx_pair_embed_features(const long long* aa, const int* chain_id, const int* residx, const float* atom14,

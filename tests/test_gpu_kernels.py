@@ -767,3 +767,55 @@ def test_reverse_step_device_rng_properties(ops, cfg):
     assert torch.isfinite(a[0]).all() and int(a[1].min()) >= 0 and int(a[1].max()) <= 19
     e = D.reverse(rig, seq, rs, tsx, lg, t, 0.01, dm, sample_ids=ids, step=8)
     assert not torch.equal(a[0], e[0])
+
+
+def test_reverse_step_device_rng_samples_share_no_noise(ops, cfg):
+    """Philox counter layout: the draw counter must not walk into the sample-id word.  With zero scores the Gaussian
+    draws can be read back from the outputs: z_trans from the R^3 update, z_rot from q_t^-1 (x) q_{t-1}.  Neighbouring sample ids
+    must not share any of them (the round-1 layout made z_trans[b, l, 1:3] == z_rot[b + 1, l, 0:2]), and a sample's noise must
+    not depend on the batch it sits in."""
+    from abx_amd.diffuser.full_diffuser import FullDiffuser, quat_multiply, quat_to_rotvec
+    D = FullDiffuser(cfg.diffuser)
+    D.set_tables(torch.zeros(1000, 1000), torch.zeros(1000, 1000), torch.zeros(1000, 1000), DEV)
+    B, L = 6, 40
+    ge = g(71)
+    q = torch.nn.functional.normalize(torch.randn(B, L, 4, generator=ge), dim=-1)
+    q = q * torch.sign(q[..., :1])
+    rig = torch.cat([q, torch.randn(B, L, 3, generator=ge) * 10], -1).double().to(DEV)
+    seq = torch.randint(0, 20, (B, L), generator=ge).to(DEV)
+    zero3 = torch.zeros(B, L, 3, device=DEV)
+    lg = torch.randn(B, L, 20, generator=ge).to(DEV)
+    dm = torch.ones(B, L, dtype=torch.int32, device=DEV)
+    tv = 0.5
+    t = torch.full((B,), tv, dtype=torch.float64, device=DEV)
+    ids = torch.arange(B, device=DEV) + 3
+    D.seed = 99
+    dt = float(np.float32(0.01))
+    out, _ = D.reverse(rig, seq, zero3, zero3.double(), lg, t, dt, dm, sample_ids=ids, step=5, center=False)
+    out = out.cpu()
+    rig_c = rig.cpu()
+    # R^3: x1 = x - ((-0.5 b x) dt + sqrt(b) dt z)
+    bt = D.min_b_f32 + tv * D.bdiff_f32
+    x = rig_c[..., 4:] * D.coord_scale_f32
+    x1 = out[..., 4:] * D.coord_scale_f32
+    z_t = (x - x1 + 0.5 * bt * x * dt) / (np.sqrt(bt) * dt)
+    # SO(3): q1 = q_t (x) quat(g sqrt(dt) z)
+    sig = np.log(tv * D.exp_max_sigma + (1 - tv) * D.exp_min_sigma)
+    g_so3 = np.sqrt(2 * (D.exp_max_sigma - D.exp_min_sigma) * sig / np.exp(sig))
+    qinv = torch.cat([rig_c[..., :1], -rig_c[..., 1:4]], -1)
+    z_r = quat_to_rotvec(quat_multiply(qinv, out[..., :4])) / (g_so3 * np.sqrt(np.float32(dt)))
+    assert z_t.abs().max() < 7 and z_r.abs().max() < 7 and z_t.std() > 0.8 and z_r.std() > 0.8      # they ARE unit Gaussians
+    allz = torch.cat([z_r, z_t], -1)                                     # (B, L, 6) draws of (sample, residue)
+    for b in range(B - 1):
+        for l in range(L):
+            d = (allz[b, l][:, None] - allz[b + 1, l][None, :]).abs()
+            assert d.min() > 1e-7, f'samples {b} and {b + 1} share a Gaussian draw at residue {l}'
+    # the same sample id in another batch composition sees the same noise
+    sub = [4, 1]
+    out2, seq2 = D.reverse(rig[sub], seq[sub], zero3[sub], zero3[sub].double(), lg[sub], t[sub], dt, dm[sub], sample_ids=ids[sub],
+                           step=5, center=False)
+    full, seqf = D.reverse(rig, seq, zero3, zero3.double(), lg, t, dt, dm, sample_ids=ids, step=5, center=False)
+    assert torch.equal(out2, full[sub]) and torch.equal(seq2, seqf[sub])
+    one, seq1 = D.reverse(rig[2:3], seq[2:3], zero3[2:3], zero3[2:3].double(), lg[2:3], t[2:3], dt, dm[2:3], sample_ids=ids[2:3],
+                          step=5, center=False)
+    assert torch.equal(one, full[2:3]) and torch.equal(seq1, seqf[2:3])
