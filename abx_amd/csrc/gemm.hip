@@ -453,7 +453,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     g.g_vec_ok = g.gate && al16(g.gate) && (g.sGb % 4 == 0) && (g.sGm % 4 == 0);
     g.r_vec_ok = g.resid && al16(g.resid) && (g.sRb % 4 == 0) && (g.sRm % 4 == 0);
     g.rs_vec_ok = g.rowscale && al16(g.rowscale) && (g.sRSb % 4 == 0);
-    if (!g.exact) {
+    if (g.exact != 1) {
         int rc = 0;
         if (!abx_gemm3_dispatch(g, st, &rc)) return rc;
     }

@@ -362,7 +362,8 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!g.B_split || g.K % 16 != 0 || g.N <= 64) return 1;
     const long long mt128 = ((long long)g.M + 127) / 128;
-    if (mt128 * (((long long)g.N + 127) / 128) * g.batch < ABX_SPLIT_MIN_TILES) return 1;
+    // exact == 2: the caller fixed the arithmetic class of this op (results must not depend on how many samples share a launch)
+    if (g.exact != 2 && mt128 * (((long long)g.N + 127) / 128) * g.batch < ABX_SPLIT_MIN_TILES) return 1;
     if (!al16(g.B_split) || g.sB3n % 8 != 0 || g.sB3p % 8 != 0 || g.sB3b % 8 != 0 || g.sB3k % 8 != 0) return 1;
     if (g.A_split) {
         if (!al16(g.A_split) || g.sA3m % 8 != 0 || g.sA3p % 8 != 0 || g.sA3b % 8 != 0 || g.sA3k % 8 != 0 || g.c_transposed) return 1;

@@ -6,8 +6,6 @@ seeded random weights (no checkpoint ships with the reference); complex: one of 
 
     python -m abx_amd.design --workload L256 --num_samples 4 --mode trajectory --num_t 10 --output_dir out/"""
 import argparse
-import json
-import os
 from collections import OrderedDict
 
 import torch
@@ -40,8 +38,7 @@ def main(argv=None):
     if a.ckpt:
         sd = torch.load(a.ckpt, map_location='cpu')['model_state_dict']
     else:
-        keys = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'sd_keys.json')))
-        sd = synthetic.random_state_dict(OrderedDict((k, tuple(s)) for k, s in keys), seed=a.seed)
+        sd = synthetic.random_state_dict(OrderedDict((k, tuple(v.shape)) for k, v in model.state_dict().items()), seed=a.seed)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
 

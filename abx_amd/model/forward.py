@@ -32,6 +32,7 @@ class Packed:
         self.wt, self.b = {}, {}
         self._ln_cache = {}
         self._split_cache = {}
+        self.gemm_mode = 0           # set per pass by Engine.run_chunk (ops.gemm_mode(L))
 
         def lin(name, key=None):
             key = key or name
@@ -126,12 +127,14 @@ class Workspace:
 
 
 def _lin(P, name, x, out, **kw):
+    kw.setdefault('exact', P.gemm_mode)
     return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), B3=P.split(name), **kw)
 
 
 def _ln_lin(P, name, ln_name, stats, x, out, **kw):
     """out = epi(LN(x) @ W^T + b) with the LayerNorm folded into the GEMM epilogue."""
     wt, csum, bias, w3 = P.ln_linear(name, ln_name)
+    kw.setdefault('exact', P.gemm_mode)
     return ops.gemm(x, wt, out, bias=bias, ln=(stats, csum), B3=w3, **kw)
 
 
@@ -155,6 +158,7 @@ class Engine:
         seq_t = batch['seq_t'][sl].long().contiguous()
         seq = batch['seq'][sl].long().contiguous()
         B, L = seq.shape
+        P.gemm_mode = ops.gemm_mode(L)
         Lab = batch['anchor_flag'].shape[1]
         mask = torch.logical_and(batch['mask'][sl], batch['fixed_mask'][sl].bool())
         mask_f = mask.float().contiguous()
@@ -226,6 +230,7 @@ class Engine:
         c = cfg.embeddings_and_seqformer
         Bc = b1 - b0
         L, Lab = st['L'], st['Lab']
+        P.gemm_mode = ops.gemm_mode(L)
         M1, M2, LL = Bc * L, Bc * L * L, L * L
         CS, CZ, E = c.seq_channel, c.pair_channel, c.index_embed_size
         WS_, WZ = CS + E, CZ + 2 * E
@@ -285,7 +290,7 @@ class Engine:
         # up to 4 (m' = i*Lp + j), so that plane rows, float4 stores and the channel-major product stay 16-byte aligned; the
         # projections read / the output projection writes the unpadded pair tensor through the row maps a_pair / c_pair, and
         # the padded row scale zeroes the pad columns of the contraction operands.
-        planes = ops.gemm_split_eligible(LL, 128, 192, Bc)
+        planes = P.gemm_mode == 2
         Lp = (L + 3) // 4 * 4
         LLp = L * Lp
         pad = (L, Lp) if Lp != L else None
@@ -308,7 +313,7 @@ class Engine:
                         a_pair_transpose=0 if outgoing else L, pair=pad, a_pair=pad is not None)
                 tt = w384[:Bc * 128 * LLp].view(Bc, 128, LLp)      # channel-major product, padded pair rows (pads: never stored)
                 tz = tt.as_strided((Bc * 128, L, L), (LLp, Lp, 1))
-                ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz)
+                ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz, exact=2)
                 _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tt.transpose(1, 2), z3, gate=Gf, gate_sigmoid=False,
                         resid=z3, pair=pad, c_pair=pad is not None)
             else:
@@ -324,9 +329,9 @@ class Engine:
                 lz = left.view(Bc * 128, L, L)
                 rz = right.view(Bc * 128, L, L)
                 if outgoing:      # 'bikc,bjkc->bijc'
-                    ops.gemm(lz, rz.transpose(1, 2), tz)
+                    ops.gemm(lz, rz.transpose(1, 2), tz, exact=1)
                 else:             # 'bkic,bkjc->bijc'
-                    ops.gemm(lz.transpose(1, 2), rz, tz)
+                    ops.gemm(lz.transpose(1, 2), rz, tz, exact=1)
                 tcm = tt.transpose(1, 2)                                   # (Bc, LL, 128) logical, channel-major storage
                 _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tcm, z3, gate=Gf, gate_sigmoid=False, resid=z3)
         # ---------------- triangle attention (seqformer.py:506-550)
@@ -372,7 +377,7 @@ class Engine:
         h1 = ws.get('i_h1', (M1, NC)); h2 = ws.get('i_h2', (M1, NC))
         upd = ws.get('i_upd', (M1, 6))
         for _ in range(ic.num_layer):
-            ops.gemm(s, P.wt[P_IPA + 'attention_module.proj'], proj, bias=P.b[P_IPA + 'attention_module.proj'])
+            ops.gemm(s, P.wt[P_IPA + 'attention_module.proj'], proj, bias=P.b[P_IPA + 'attention_module.proj'], exact=1)
             ops.ipa_pack(proj, cur_R, cur_t, qpack, kpack, vpack, Bc, L, P.ipa_ws)
             ops.ipa_attn(qpack, kpack, vpack, bias2d, zi, mask_f, cur_R, cur_t, P.ipa_pw, ifeat, Bc, L)
             _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)

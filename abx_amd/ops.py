@@ -35,10 +35,10 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     """Name of the kernel instantiation abx_gemm launches for a problem (mirror of the selection in csrc/gemm.hip and
     csrc/gemm3.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
     b = lambda x: 'true' if x else 'false'
-    exact = GEMM_EXACT if exact is None else exact
+    exact = 1 if GEMM_EXACT else int(exact or 0)
     blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
     wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128
-    if not exact and split and N > 64 and blocks128 >= 256 and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
+    if exact != 1 and split and N > 64 and (blocks128 >= 256 or exact == 2) and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
         amode = 2 if a_split else (0 if a_kcontig else 1)
         pad128, pad192 = ((N + 127) // 128) * 128, ((N + 191) // 192) * 192
         wide = pad192 <= pad128 if a_split else (wide192 and N % 128 != 0)
@@ -55,6 +55,16 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     else:
         cfg = (128, 128, 64, 64, 3)
     return f'gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 16, {b(a_kcontig)}, {b(b_ncontig)}, {b(transposed)}, {cfg[4]}>'
+
+
+SPLIT_MIN_L = 64
+
+
+def gemm_mode(L):
+    """Arithmetic class of the GEMMs of a network pass, fixed by the complex (residue count L) and NOT by how many samples share a
+    launch: 2 (split-bf16 kernels) from L = 64, 1 (exact fp32 MFMA) below.  Chunking a batch, sharding it over GPUs or running
+    one sample alone therefore gives bit-identical results."""
+    return 1 if (GEMM_EXACT or L < SPLIT_MIN_L) else 2
 
 
 def gemm_split_eligible(M, N, K, batch=1):
@@ -176,7 +186,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             assert stats.numel() == 2 * nb * M, (stats.shape, nb, M)
             g.ln_stats, g.sSb = _p(_f32(stats)), M
     g.a_relu = 1 if a_relu else 0
-    g.exact = int(GEMM_EXACT if exact is None else exact)
+    g.exact = 1 if GEMM_EXACT else int(exact or 0)        # 0 by problem size, 1 exact fp32 MFMA, 2 split-bf16 whenever the shape allows
     if B3 is not None:
         assert B3.dtype == torch.int16 and B3.is_contiguous() and B3.shape[1:] == (3, N, 16) and B3.shape[0] * 16 >= K
         g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
@@ -244,6 +254,14 @@ def transpose_last2(x, out):
     assert x.shape[-2] == L and x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
     check(_lib.load().abx_transpose_last2(_p(_f32(x)), _p(out), x.numel() // (L * L), L, _stream()), 'abx_transpose_last2')
     return out
+
+
+def tri_attn_kernel_name(L, exact=None):
+    """Name of the kernel abx_tri_attn_fwd launches (mirror of the selection in csrc/attention.hip), for per-kernel aggregation."""
+    if GEMM_EXACT if exact is None else exact:
+        return 'tri_attn_kernel'
+    slots = ((L + 15) // 16 + 11) // 12
+    return f'tri_attn3_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}>'
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None):

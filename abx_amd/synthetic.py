@@ -102,6 +102,7 @@ def replicate(complex_, n):
 WORKLOADS = {
     'L352': dict(L_heavy=120, L_light=108, L_antigen=124, cdr=(97, 109)),   # BASELINE nominal ~350 residues
     'L256': dict(L_heavy=120, L_light=108, L_antigen=28, cdr=(97, 109)),    # realistic cropped complex
-    '6ct7like': dict(L_heavy=113, L_light=107, L_antigen=10, cdr=(96, 99)),  # 3 diffused residues
+    '6ct7like': dict(L_heavy=113, L_light=107, L_antigen=10, cdr=(96, 99)),  # L = 230, 3 diffused residues (BASELINE configs 1-2)
+    '6qd7like': dict(L_heavy=120, L_light=109, L_antigen=32, cdr=(96, 109)),  # L = 261, 13 diffused residues (BASELINE config 5)
     'tiny': dict(L_heavy=10, L_light=6, L_antigen=4, cdr=(4, 8)),
 }

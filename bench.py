@@ -1,21 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the AbX reverse-diffusion sampling hot path on MI355X (BASELINE.json metric: diffusion-steps/sec).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--workload L352|6ct7like|6qd7like] [--samples S]
 
-A "step" = one iteration of the reference's reverse loop (inference.py:213-268) for a batch of B samples of ONE complex:
-ScoreNetwork call (2 recycles + final pass = 3 network passes) + get_prev + FullDiffuser.reverse.  All inputs are resident
-in HBM when the timed region starts.  value = (samples on all ranks) * K / max-over-ranks(time)  [sample-steps / s].
-Workload (config.workload): synthetic complex 'L352' (Lab 228 + antigen 124 = 352 residues, BASELINE's "~350-res complex"),
-100 samples per GPU (weak scaling: every rank designs its own 100 samples), seeded random weights (no trained checkpoint
-exists offline), ESM disabled, device Philox noise.  fp32 compute with float64 diffuser state, as the reference.
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment), or — when WORLD_SIZE is
+not set — this script starts them itself through torch.distributed.run on 127.0.0.1 and relays rank 0's JSON line.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (measured live with HIP events on the launch stream)
-and "cpu_baseline" (the oracle = CPU port of the same step, B = 1, timed on the host cores of this box).
+A "step" = one iteration of the reference's reverse loop (inference.py:213-268) for the samples of ONE complex that a rank
+holds: ScoreNetwork call (2 recycles + final pass = 3 network passes) + get_prev + FullDiffuser.reverse.  All inputs are
+resident in HBM when the timed region starts.  value = (samples on all ranks) * K / max-over-ranks(time)  [sample-steps / s].
+
+Scaling.  The metric is "100 samples of one ~350-residue complex at 1/2/4/8 GPUs": the S = 100 samples are sharded over the
+ranks in contiguous blocks (sampler.shard_sample_ids; 12-13 samples per GPU at N = 8) -> "scaling": "strong" (default).  There
+is no collective inside a step; ONE all-gather of the final results (sampler.gather_results, RCCL over xGMI) runs after the
+timed loop and is reported as `gather_ms`.  `--scaling weak` gives every rank its own S samples instead; at N > 1 the default
+run also times that variant for a few steps and reports it under "weak" on the same JSON line.
+
+Workloads (abx_amd.synthetic.WORKLOADS): 'L352' (Lab 228 + antigen 124, BASELINE's nominal "~350-res complex", the headline),
+'6ct7like' (L = 230, the cropped 6ct7 complex of BASELINE configs 1-2), '6qd7like' (L = 261, config 5: use --samples 32).
+Seeded random weights (no trained checkpoint exists offline), ESM disabled, device Philox noise, fp32 compute with float64
+diffuser state as the reference.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (measured live with HIP events on the launch stream) and
+"cpu_baseline": the oracle (CPU port of the same step) on sample 0 of the same complex, 1 warm-up + 3 timed steps on the
+physical cores of this box, with the HIP-vs-oracle parity of that very call ("parity").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from collections import OrderedDict, defaultdict
@@ -30,6 +45,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2516.6     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32-accurate product = 6 bf16 MFMA products (csrc/gemm3.hip)
+WEIGHT_SEED = 7
 
 
 def algorithmic_bytes_per_sample_step(L):
@@ -39,6 +55,13 @@ def algorithmic_bytes_per_sample_step(L):
 
 def algorithmic_flops_per_sample_step(L):
     return 3 * 2 * (1.064e6 * L * L + 1024.0 * L ** 3 + 12.4e6 * L + 1088.0 * L * L)
+
+
+def model_parameter_shapes(cfg):
+    """Names and shapes of the 190 ScoreNetwork parameters, from the module tree itself (the checkpoint contract)."""
+    from abx_amd.model.abx import ScoreNetwork
+    m = ScoreNetwork(cfg.model, None)
+    return OrderedDict((k, tuple(v.shape)) for k, v in m.state_dict().items())
 
 
 class OpTimer:
@@ -57,31 +80,28 @@ class OpTimer:
                     nb, M, K, N = A.shape[0] * A.shape[1], A.shape[4], A.shape[2] * 16, B.shape[4]
                 else:
                     nb, M, K, N = A.shape[0], A.shape[3], A.shape[1] * 16, B.shape[3]
-                kern = self.ops.gemm_kernel_name(M, N, K, nb, split=True, a_split=True)
+                kern = self.ops.gemm_kernel_name(M, N, K, nb, split=True, a_split=True, exact=kw.get('exact'))
                 return kern, 2.0 * nb * M * N * K, nb * (6.0 * (M + N) * K + 4.0 * M * N)
             nb = A.shape[0] if A.dim() == 3 else 1
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
             c_planes = C.dtype == torch.int16
             kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
-                                             split=kw.get('B3') is not None)
+                                             split=kw.get('B3') is not None, exact=kw.get('exact'))
             return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * K * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
-            exact = self.ops.GEMM_EXACT if kw.get('exact') is None else kw['exact']
-            slots = ((L + 15) // 16 + 11) // 12
-            kern = 'tri_attn_kernel' if exact else f'tri_attn3_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}>'
-            return kern, 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
+            return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
         if name == 'ipa_attn':
             Bc, L = args[-2], args[-1]
             return 'ipa_attn_kernel', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12)
         return name, 0.0, 0.0
 
     def __enter__(self):
+        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name')
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
-            if callable(fn) and not name.startswith('_') and name not in ('gemm_kernel_name', 'gemm_split_eligible') and \
-                    getattr(fn, '__module__', '') == self.ops.__name__:
+            if callable(fn) and not name.startswith('_') and name not in skip and getattr(fn, '__module__', '') == self.ops.__name__:
                 self.saved[name] = fn
 
                 def wrap(fn=fn, name=name):
@@ -113,61 +133,176 @@ class OpTimer:
         return sorted(((k, v[0], v[1], v[2], v[3]) for k, v in agg.items()), key=lambda x: -x[1])
 
 
-def cpu_baseline(args, D, batch, B, L, t_value):
-    """The oracle (CPU port of the same step definition) for ONE sample of the same complex, in a subprocess with a
-    bounded thread count and a hard timeout so that the default bench run stays within minutes."""
-    import subprocess
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle) + parity of the same call
+# ---------------------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """(physical cores, logical cpus, model name) of this host."""
+    logical = os.cpu_count() or 1
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name') and model == 'unknown':
+                model = line.split(':', 1)[1].strip()
+            elif line.startswith('physical id'):
+                phys = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':', 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    physical = min(len(cores), logical) if cores else logical
+    return max(1, physical), logical, model
+
+
+def cpu_baseline(model, D, batch, cfg, L, t_value, timed_steps=3):
+    """Sample 0 of the complex, one step (ScoreNetwork 3 passes + get_prev + reverse) with the CURRENT self-conditioning state:
+    run on the HIP path here and on the oracle in a subprocess (bounded threads, hard timeout); returns the timing of the
+    oracle (1 warm-up + `timed_steps` timed calls) and the difference between the two results."""
     import tempfile
-    threads = min(32, os.cpu_count() or 1)
+    physical, logical, cpu_model = host_cpu_info()
+    threads = physical
+    unit = 'sample-steps/s'
+    one = {}
+    for k, v in batch.items():
+        if k.startswith('_'):
+            continue
+        if torch.is_tensor(v):
+            one[k] = (v[:1] if v.dim() > 0 else v).clone()
+        elif isinstance(v, tuple):
+            one[k] = tuple(x[:1].clone() for x in v)
+    dev = one['seq'].device
+    t1 = torch.full((1,), t_value, dtype=torch.float64, device=dev)
+    from abx_amd import sampler
+    sampler.set_t_feats(one, D, t1, torch.ones(1, device=dev))
+    blob = {k: (v.cpu() if torch.is_tensor(v) else tuple(x.cpu() for x in v)) for k, v in one.items()}
+    with torch.no_grad():
+        out = model(one)
+        torch.cuda.synchronize()
+    hip = {'rigids': out['heads']['folding']['rigids'].cpu(), 'trans_score': out['heads']['folding']['trans_score'].cpu(),
+           'logits': out['heads']['sequence_module']['logits'].cpu(), 'seq_0': out['heads']['sequence_module']['seq_0'].cpu(),
+           'pLDDT': out['heads']['predicted_lddt']['pLDDT'].cpu(), 'prev_pos': out['_prev_pos'].cpu()}
+    blob['_tables'] = dict(pdf=D._pdf.cpu(), cdf=D._cdf.cpu(), score_norms=D.score_norms.cpu())
+    blob['_t'] = t_value
+    blob['_hip'] = hip
+    blob['_timed_steps'] = timed_steps
+    base = {'value': None, 'unit': unit, 'cores': threads, 'kind': 'port'}
     with tempfile.TemporaryDirectory() as d:
-        blob = {}
-        for k, v in batch.items():
-            if torch.is_tensor(v) and not k.startswith('prev_'):
-                blob[k] = (v[:1] if v.dim() > 0 and v.shape[0] == B else v).cpu()
-        blob['rigids_t'] = blob['rigids_t'].double()
-        blob['_tables'] = dict(pdf=D._pdf.cpu(), cdf=D._cdf.cpu(), score_norms=D.score_norms.cpu())
-        blob['_t'] = t_value
         torch.save(blob, os.path.join(d, 'in.pt'))
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(k, None)
         try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', d], env=env,
-                                 capture_output=True, text=True, timeout=420)
-            line = [x for x in out.stdout.splitlines() if x.startswith('CPU_BASELINE ')]
-            if out.returncode != 0 or not line:
-                return {'value': None, 'unit': 'sample-steps/s', 'cores': threads, 'kind': 'port',
-                        'sample': 'worker failed: ' + out.stderr[-300:]}
-            ctime = float(line[0].split()[1])
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', d], env=env,
+                                 capture_output=True, text=True, timeout=600)
+            line = [x for x in res.stdout.splitlines() if x.startswith('CPU_BASELINE ')]
+            if res.returncode != 0 or not line:
+                return dict(base, sample='worker failed: ' + res.stderr[-300:])
+            r = json.loads(line[0][len('CPU_BASELINE '):])
         except subprocess.TimeoutExpired:
-            return {'value': None, 'unit': 'sample-steps/s', 'cores': threads, 'kind': 'port', 'sample': 'timed out after 420 s'}
-    return {'value': 1.0 / ctime, 'unit': 'sample-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 diffusion step of 1 sample at L={L} (same complex, weights, step definition; trajectory-invariant '
-                      f'embeddings cached as in the HIP path; CPU batching does not help, BASELINE.md section 2), {ctime:.1f} s '
-                      f'on {threads} threads of {os.cpu_count()} logical CPUs'}
+            return dict(base, sample='timed out after 600 s')
+    ctime = float(np.mean(r['times']))
+    return dict(base, value=1.0 / ctime,
+                sample=f'1 diffusion step (ScoreNetwork 3 passes + get_prev + reverse) of sample 0 at L={L}, same complex, weights and '
+                       f'self-conditioning state as the HIP run; 1 warm-up + {len(r["times"])} timed steps ({", ".join("%.1f" % x for x in r["times"])} s; '
+                       f'warm-up {r["warmup"]:.1f} s) on {threads} threads = physical cores of {cpu_model} ({logical} logical CPUs); '
+                       'trajectory-invariant embeddings cached as in the HIP path; CPU batching does not help (BASELINE.md section 2)',
+                cpu_model=cpu_model, logical_cpus=logical, step_times_s=r['times'], parity=r['parity'])
 
 
 def cpu_baseline_worker(d):
-    from collections import OrderedDict as OD
     from abx_amd import synthetic
     from abx_amd.config import default_config
     from oracle import abx_oracle as O
     torch.set_num_threads(int(os.environ.get('OMP_NUM_THREADS', '8')))
     blob = torch.load(os.path.join(d, 'in.pt'))
     cfg = default_config()
-    keys = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'sd_keys.json')))
-    params = synthetic.random_state_dict(OD((k, tuple(s)) for k, s in keys), seed=7)
+    params = synthetic.random_state_dict(model_parameter_shapes(cfg), seed=WEIGHT_SEED)
     od = O.OracleDiffuser(cfg.diffuser, blob.pop('_tables'))
     tc = torch.full((1,), blob.pop('_t'), dtype=torch.float64)
-    cpu = blob
+    hip = blob.pop('_hip')
+    nt = int(blob.pop('_timed_steps'))
+    times, ro = [], None
     with torch.no_grad():
-        cpu = O.set_t_feats(cpu, od, tc, torch.ones(1))
-        static = O.static_embeddings(params, cpu, cfg)
-        c0 = time.perf_counter()
-        ro = O.score_network(params, cpu, cfg, od, static)
-        cpu.update(O.get_prev(cpu, ro, cfg))
-        dm = (1 - cpu['fixed_mask']) * cpu['atom14_gt_exists'][..., 0]
-        od.reverse(cpu['rigids_t'], cpu['seq_t'], ro['heads']['folding']['rot_score'], ro['heads']['folding']['trans_score'],
-                   ro['heads']['sequence_module']['logits'], tc, torch.tensor(0.01), dm)
-        print('CPU_BASELINE', time.perf_counter() - c0)
+        static = O.static_embeddings(params, blob, cfg)
+        for it in range(nt + 1):
+            cpu = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in blob.items()}
+            cpu = O.set_t_feats(cpu, od, tc, torch.ones(1))
+            c0 = time.perf_counter()
+            ro = O.score_network(params, cpu, cfg, od, static)
+            prev = O.get_prev(cpu, ro, cfg)
+            dm = (1 - cpu['fixed_mask']) * cpu['atom14_gt_exists'][..., 0]
+            od.reverse(cpu['rigids_t'], cpu['seq_t'], ro['heads']['folding']['rot_score'], ro['heads']['folding']['trans_score'],
+                       ro['heads']['sequence_module']['logits'], tc, torch.tensor(0.01), dm)
+            times.append(time.perf_counter() - c0)
+    f = ro['heads']['folding']
+    mx = lambda a, b: float((a.double() - b.double()).abs().max())
+    parity = {
+        'max_abs_rigids': mx(hip['rigids'], f['rigids']), 'max_abs_trans_score': mx(hip['trans_score'], f['trans_score']),
+        'max_abs_logits': mx(hip['logits'], ro['heads']['sequence_module']['logits']),
+        'max_abs_pLDDT': mx(hip['pLDDT'], ro['heads']['predicted_lddt']['pLDDT']),
+        'tokens_equal': bool(torch.equal(hip['seq_0'], ro['heads']['sequence_module']['seq_0'])),
+        'distogram_bins_differing': int((hip['prev_pos'] != prev['prev_pos']).sum()),
+        'what': 'HIP vs oracle, final pass of one call on sample 0 (L as benchmarked), absolute differences; rigids in Angstrom / unit quaternions',
+    }
+    print('CPU_BASELINE ' + json.dumps({'warmup': times[0], 'times': times[1:], 'parity': parity}))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun starts its own ranks
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(n, argv, port=None):
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """Start n ranks of this script and relay rank 0's JSON line (the only line this process prints on stdout)."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    res = subprocess.run(launcher_command(n, argv), env=env, capture_output=True, text=True)
+    lines = [x for x in res.stdout.splitlines() if x.startswith('{')]
+    sys.stderr.write(res.stderr[-4000:])
+    if res.returncode != 0 or not lines:
+        sys.stderr.write(f'\nbench.py: the {n}-rank launch failed (rc {res.returncode})\n')
+        sys.exit(res.returncode or 1)
+    print(lines[-1])
+
+
+def launcher_selftest(args):
+    """CPU check of the launch + rendezvous logic (gloo): every rank contributes its rank to an all_reduce and its shard of the
+    sample ids to an all_gather; rank 0 prints what it saw."""
+    import torch.distributed as dist
+    from abx_amd import sampler
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    x = torch.tensor([float(rank)])
+    dist.all_reduce(x)
+    ids = sampler.shard_sample_ids(args.samples, rank, world)
+    local = {'ids': torch.tensor(ids, dtype=torch.int64).reshape(-1, 1)}
+    got = sampler.gather_results(local, args.samples, rank, world)
+    if rank == 0:
+        print(json.dumps({'launcher_selftest': True, 'world': world, 'rank_sum': float(x), 'gathered_ids': got['ids'].reshape(-1).tolist(),
+                          'samples_per_rank': [len(sampler.shard_sample_ids(args.samples, r, world)) for r in range(world)]}))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -176,18 +311,28 @@ def main():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='L352')
-    ap.add_argument('--samples', type=int, default=100, help='samples per GPU')
-    ap.add_argument('--chunk', type=int, default=100, help='samples per pair-stack launch (workspace ~0.8 GB per sample at L = 352)')
+    ap.add_argument('--samples', type=int, default=100, help='samples of the complex: in total (strong scaling) or per GPU (weak)')
+    ap.add_argument('--scaling', choices=['strong', 'weak'], default='strong')
+    ap.add_argument('--chunk', type=int, default=0, help='samples per pair-stack launch (0 = as many as fit: the whole per-GPU batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-op-profile', action='store_true')
+    ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the additional weak-scaling measurement')
+    ap.add_argument('--launcher-selftest', action='store_true', help='CPU/gloo check of the multi-rank launch path, no GPU work')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])
+    if args.launcher_selftest:
+        return launcher_selftest(args)
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus or world == 1 and args.gpus == 1, f'--gpus {args.gpus} but WORLD_SIZE {world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -203,93 +348,129 @@ def main():
     assert rc == 0, lib.abx_last_error_string()
     cfg = default_config()
     cfg.diffuser.so3.cache_dir = f'/tmp/abx_bench_cache_{rank}/'
-    keys = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'sd_keys.json')))
-    params = synthetic.random_state_dict(OrderedDict((k, tuple(s)) for k, s in keys), seed=7)
+    params = synthetic.random_state_dict(model_parameter_shapes(cfg), seed=WEIGHT_SEED)
     D = FullDiffuser(cfg.diffuser).to(dev)                     # IGSO(3) tables by the HIP kernel
     model = ScoreNetwork(cfg.model, D)
     model.load_state_dict(params, strict=True)
     model = model.to(dev).eval()
-    model.max_chunk = args.chunk
+    model.max_chunk = args.chunk or None
 
     w = synthetic.WORKLOADS[args.workload]
-    B = args.samples
     cx = synthetic.make_complex(seed=1, **w)
     L = cx['seq'].shape[0]
-    raw = {k: v.to(dev) for k, v in synthetic.replicate(cx, B).items()}
-    torch.manual_seed(1234 + rank)
-    batch = features.build_features(raw, D)
-    batch['_shared_context'] = True
-    diffuse_mask = ((1 - batch['fixed_mask']) * batch['atom14_gt_exists'][..., 0]).to(torch.int32)
-    ones = torch.ones(B, device=dev)
-    sid = torch.arange(B, device=dev) + rank * B
     grid = np.linspace(0.01, 1.0, 100)[::-1]
     dt = float(np.float32(0.01))
     D.seed = 2024
 
-    def one_step(k):
-        t_ = torch.full((B,), float(grid[k % 99]), device=dev, dtype=torch.float64)
-        sampler.set_t_feats(batch, D, t_, ones)
-        out = model(batch)
-        f = out['heads']['folding']
-        batch.update(get_prev(batch, out, cfg.model))
-        rig, seq = D.reverse(rigid_t=batch['rigids_t'], seq_t=batch['seq_t'], rot_score=f['rot_score'], trans_score=f['trans_score'],
-                             logits_t=out['heads']['sequence_module']['logits'], diffuse_mask=diffuse_mask, t=t_, dt=dt,
-                             sample_ids=sid, step=k)
-        batch['rigids_t'], batch['seq_t'] = rig, seq
-        return out
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    with torch.no_grad():
-        # self-conditioning warm-up call of the sampler (untimed set-up, like the IGSO(3) table build)
-        sampler.set_t_feats(batch, D, float(grid[0]), ones)
-        out = model(batch)
-        batch.update(get_prev(batch, out, cfg.model))
-        for k in range(args.warmup):
-            one_step(k)
+    def measure(scaling, steps, warmup):
+        """Builds this rank's samples, runs warm-up + `steps` timed steps; returns (elapsed max over ranks, state)."""
+        total = args.samples if scaling == 'strong' else args.samples * world
+        ids = sampler.shard_sample_ids(total, rank, world)
+        B = len(ids)
+        st = {'ids': ids, 'B': B, 'total': total}
+        if B > 0:
+            raw = {k: v.to(dev) for k, v in synthetic.replicate(cx, B).items()}
+            batch = features.build_features(raw, D, noise=features.per_sample_init_noise(ids, L, seed=1234, device=dev))
+            batch['_shared_context'] = True
+            diffuse_mask = ((1 - batch['fixed_mask']) * batch['atom14_gt_exists'][..., 0]).to(torch.int32)
+            ones = torch.ones(B, device=dev)
+            sid = torch.tensor(ids, device=dev, dtype=torch.int64)
 
-        def barrier():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
+            def one_step(k):
+                t_ = torch.full((B,), float(grid[k % 99]), device=dev, dtype=torch.float64)
+                sampler.set_t_feats(batch, D, t_, ones)
+                out = model(batch)
+                f = out['heads']['folding']
+                batch.update(get_prev(batch, out, cfg.model))
+                rig, seq = D.reverse(rigid_t=batch['rigids_t'], seq_t=batch['seq_t'], rot_score=f['rot_score'],
+                                     trans_score=f['trans_score'], logits_t=out['heads']['sequence_module']['logits'],
+                                     diffuse_mask=diffuse_mask, t=t_, dt=dt, sample_ids=sid, step=k)
+                batch['rigids_t'], batch['seq_t'] = rig, seq
+                return out
+        else:
+            batch, one_step = None, (lambda k: None)
+        with torch.no_grad():
+            if B > 0:
+                # self-conditioning warm-up call of the sampler (untimed set-up, like the IGSO(3) table build)
+                sampler.set_t_feats(batch, D, float(grid[0]), ones)
+                out = model(batch)
+                batch.update(get_prev(batch, out, cfg.model))
+            for k in range(warmup):
+                out = one_step(k)
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                out = one_step(warmup + k)
+            barrier()
+            elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt_ = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            elapsed = float(tt_)
+        st.update(batch=batch, one_step=one_step, out=out, next_k=warmup + steps,
+                  finite=bool(torch.isfinite(batch['rigids_t']).all()) if B > 0 else True)
+        return elapsed, st
 
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            one_step(args.warmup + k)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        finite = bool(torch.isfinite(batch['rigids_t']).all())
+    elapsed, st = measure(args.scaling, args.steps, args.warmup)
+    total = st['total']
+    value = total * args.steps / elapsed
+    per_rank = [len(sampler.shard_sample_ids(total, r, world)) for r in range(world)]
+
+    # ---- the one collective of the path: final results of all samples to every rank (after the timed loop)
+    gather_ms, rccl_ranks = None, 1
     if world > 1:
-        tt_ = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-        elapsed = float(tt_)
-    value = world * B * args.steps / elapsed
+        Lab = cx['anchor_flag'].shape[0]
+        if st['B'] > 0:
+            o, b_ = st['out'], st['batch']
+            local = {'rigids': b_['rigids_t'].double(), 'seq': torch.clamp(b_['seq_t'][:, :Lab], 0, 19).long(),
+                     'atom14': o['heads']['folding']['final_atom14_positions'][:, :Lab].contiguous(),
+                     'pLDDT': o['heads']['predicted_lddt']['pLDDT'][:, :Lab].contiguous()}
+        else:
+            local = {'rigids': torch.zeros(0, L, 7, dtype=torch.float64, device=dev), 'seq': torch.zeros(0, Lab, dtype=torch.int64, device=dev),
+                     'atom14': torch.zeros(0, Lab, 14, 3, device=dev), 'pLDDT': torch.zeros(0, Lab, device=dev)}
+        sampler.gather_results(local, total, rank, world)        # first call: communicator set-up
+        barrier()
+        g0 = time.perf_counter()
+        got = sampler.gather_results(local, total, rank, world)
+        barrier()
+        gather_ms = 1000.0 * (time.perf_counter() - g0)
+        assert got['rigids'].shape[0] == total
+        cnt = torch.ones(1, device=dev)
+        dist.all_reduce(cnt)
+        rccl_ranks = int(cnt)
 
+    B0 = st['B']
     result = {
         'metric': 'diffusion-steps/sec (100 samples, ~350-res complex)', 'value': value, 'unit': 'sample-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'dtype_note': 'fp32 storage and accumulation everywhere; the large pair-stack GEMMs evaluate each fp32 product from '
                       '3-way bf16 operand splits (6 MFMA products, fp32 accumulate: as accurate as the native fp32 MFMA, '
                       'tests/test_gpu_kernels.py), everything else is native fp32 / fp64',
         'config': {'workload': f'{args.workload}: L={L} (Lab {w["L_heavy"] + w["L_light"]} + antigen {w["L_antigen"]}), '
-                               f'{B} samples/GPU of one complex, 1 step = ScoreNetwork (3 passes) + get_prev + reverse, '
-                               'seeded random weights, ESM off', 'L': L, 'samples_per_gpu': B, 'chunk': args.chunk},
-        'finite': finite,
+                               f'{total} samples of one complex over {world} GPU(s), 1 step = ScoreNetwork (3 passes) + get_prev '
+                               '+ reverse, seeded random weights, ESM off', 'L': L, 'samples_total': total,
+                   'samples_per_rank': per_rank, 'chunk': args.chunk or 'auto', 'parallelism': f'sample-shard x{world}, no collective in the step'},
+        'finite': st['finite'], 'rccl_ranks': rccl_ranks, 'gather_ms': gather_ms,
         'step_hbm_frac': value / world * algorithmic_bytes_per_sample_step(L) / 1e9 / HBM_PEAK_GBS,
         'step_mfma_f32_frac': value / world * algorithmic_flops_per_sample_step(L) / 1e12 / MFMA_F32_PEAK_TF,
     }
 
-    if rank == 0 and not args.no_op_profile:
+    if rank == 0 and not args.no_op_profile and B0 > 0:
         with torch.no_grad(), OpTimer(ops) as tm:
-            one_step(args.warmup + args.steps)
+            st['one_step'](st['next_k'])
         summ = tm.summary()
-        total = sum(s[1] for s in summ)
-        top = summ[0]
-        name, ms, calls, fl, by = top
+        tot_ms = sum(s[1] for s in summ)
+        name, ms, calls, fl, by = summ[0]
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
         if name.startswith('ipa_attn'):
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
-        elif name.startswith('gemm3_kernel') or name.startswith('tri_attn3_kernel'):
+        elif name.startswith('gemm3_kernel') or name.startswith('tri_attn3') or name.startswith('tri_attn4'):
             # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs six bf16 MFMA
             # products, so the ceiling is the dense bf16 peak / 6
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_SPLIT_PEAK_TF, 'unit': 'TFLOP/s',
@@ -298,18 +479,26 @@ def main():
         else:
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s'}
         traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc):             # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
             traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
         roof.update(frac=roof['achieved'] / roof['peak'], traffic=traffic, kernel=name, calls_per_step=calls,
-                    avg_launch_ms=ms / calls, share_of_step=ms / total)
+                    avg_launch_ms=ms / calls, share_of_step=ms / tot_ms)
         result['roofline'] = roof
-        result['op_profile_ms'] = [{'op': s[0], 'ms': round(s[1], 3), 'calls': s[2],
-                                    'avg_ms': round(s[1] / s[2], 4),
+        result['op_profile_ms'] = [{'op': s[0], 'ms': round(s[1], 3), 'calls': s[2], 'avg_ms': round(s[1] / s[2], 4),
                                     'tflops': (s[3] / (s[1] / 1e3) / 1e12 if s[3] else None)} for s in summ[:40]]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(args, D, batch, B, L, float(grid[1]))
+        result['cpu_baseline'] = cpu_baseline(model, D, st['batch'], cfg, L, float(grid[(st['next_k'] + 1) % 99]))
+
+    if world > 1 and args.scaling == 'strong' and not args.no_weak:
+        st = None
+        torch.cuda.empty_cache()
+        wsteps = max(1, min(args.steps, 3))
+        welapsed, wst = measure('weak', wsteps, 1)
+        result['weak'] = {'scaling': 'weak', 'samples_per_gpu': args.samples, 'steps': wsteps, 'warmup': 1,
+                          'value': wst['total'] * wsteps / welapsed, 'unit': 'sample-steps/s', 'ms_per_step': 1000.0 * welapsed / wsteps}
+
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -89,7 +89,10 @@ typedef struct AbxGemm {
                                                       stored at row i*pair_L + j, rows with j >= pair_L are dropped (plain store) */
     int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split
                                                       into 3 bf16 pieces, 6 products, fp32 accumulate - csrc/gemm3.hip);
-                                                      1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) */
+                                                      1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32);
+                                                      2: the split-bf16 kernels whatever the problem size (falls back to the exact
+                                                      kernel only on shape / alignment grounds): callers that need results
+                                                      independent of the batch size fix the arithmetic per op with 1 or 2 */
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
     int a_vec_ok, b_vec_ok, fast_ok;               /* filled by the library */
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */

@@ -400,3 +400,137 @@ def test_design_driver_trajectory_dump(tmp_path):
     txt = open(os.path.join(out, names[0])).read().splitlines()
     assert txt[0].startswith('ATOM      1  N  ') and txt[-1] == 'END   '
     assert sum(ln.startswith('TER') for ln in txt) == 2          # heavy + light chain (synthetic complex: no antigen records)
+
+
+def _cpu_copy(b, sl=slice(None)):
+    out = {}
+    for k, v in b.items():
+        if k.startswith('_'):
+            continue
+        if torch.is_tensor(v):
+            out[k] = (v[sl] if v.dim() > 0 else v).cpu()
+        elif isinstance(v, tuple):
+            out[k] = tuple(x[sl].cpu() for x in v)
+        else:
+            out[k] = v
+    return out
+
+
+class _GemmSpy:
+    """Counts the abx_gemm calls whose A operand is a bf16-plane tensor (the triangle-multiplication contraction on the
+    split-bf16 kernels) and those that use the padded pair-row maps."""
+
+    def __enter__(self):
+        from abx_amd import ops
+        self.ops, self.orig, self.plane, self.padded = ops, ops.gemm, 0, 0
+
+        def spy(A, B, C, **kw):
+            self.plane += int(A.dtype == torch.int16)
+            self.padded += int(kw.get('pair') is not None)
+            return self.orig(A, B, C, **kw)
+        ops.gemm = spy
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+
+
+@pytest.mark.parametrize('w', [dict(L_heavy=55, L_light=47, L_antigen=29, cdr=(30, 41)),      # L = 131 (odd)
+                               dict(L_heavy=50, L_light=44, L_antigen=24, cdr=(30, 39))])     # L = 118 (L % 4 == 2)
+def test_any_length_takes_the_plane_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser, w):
+    """residue counts that are not multiples of 4 (the real complexes are L = 230 and 261) run the triangle
+    multiplication on the same glu -> bf16 planes -> plane contraction route as L = 352, through the padded pair-row maps.
+    One full call (3 passes), 4 samples with different noise and a masked antigen tail, HIP vs oracle."""
+    from oracle import abx_oracle as O
+    from abx_amd import sampler, ops
+    model, D = gpu_model
+    B = 4
+    L = w['L_heavy'] + w['L_light'] + w['L_antigen']
+    assert L % 4 != 0 and ops.gemm_split_eligible(L * L, 128, 192, B)
+    b = _synthetic_batch(D, w, B=B, n_masked_tail=2)
+    t_ = torch.full((B,), 0.4040404040404041, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+    cpu = _cpu_copy(b)
+    model.max_chunk = None
+    with _GemmSpy() as spy:
+        ret = model(b)
+        torch.cuda.synchronize()
+    assert spy.plane == 6 and spy.padded == 12, (spy.plane, spy.padded)     # 2 tri-muls x 3 passes: contraction; glu + proj_out
+    ref = O.score_network(params, cpu, cfg, oracle_diffuser)
+    f, fr = ret['heads']['folding'], ref['heads']['folding']
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'].cpu(), ref['heads']['sequence_module']['seq_0'])
+    close(ret['representations']['pair'], ref['representations']['pair'], 3e-4, 1e-4, 'pair')
+    close(f['rigids'], fr['rigids'], 2e-4, 1e-4, 'rigids')
+    close(f['final_atom14_positions'], fr['final_atom14_positions'], 1e-3, 1e-4, 'atom14')
+    close(ret['heads']['sequence_module']['logits'], ref['heads']['sequence_module']['logits'], 3e-4, 1e-4, 'logits')
+    close(f['trans_score'], fr['trans_score'], 3e-4, 1e-4, 'trans_score')
+
+
+@pytest.mark.parametrize('name,B,chunk', [('6ct7like', 100, 40), ('6qd7like', 32, 32)])
+def test_real_complex_lengths_full_batch(gpu_model, params, cfg, oracle_diffuser, name, B, chunk):
+    """BASELINE configs 2 and 5 at their real (cropped) lengths, L = 230 x 100 samples and L = 261 x 32 samples of one complex:
+    the whole batch on the plane path; sample 0 of the batch against the oracle (values, not only properties); results
+    independent of the chunking of the batch."""
+    from oracle import abx_oracle as O
+    from abx_amd import sampler
+    model, D = gpu_model
+    b = _synthetic_batch(D, name, B=B)
+    b['_shared_context'] = True
+    L = b['seq'].shape[1]
+    assert L in (230, 261)
+    t_ = torch.full((B,), 0.7070707070707071, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+    cpu = _cpu_copy(b, slice(0, 1))
+
+    def run(ch):
+        bb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+        model.max_chunk = ch
+        with _GemmSpy() as spy:
+            r = model(bb)
+            torch.cuda.synchronize()
+        assert spy.plane == 6 * -(-B // ch)
+        return {'rigids': r['heads']['folding']['rigids'].clone(), 'logits': r['heads']['sequence_module']['logits'].clone(),
+                'seq_0': r['heads']['sequence_module']['seq_0'].clone(), 'atom14': r['heads']['folding']['final_atom14_positions'].clone(),
+                'trans_score': r['heads']['folding']['trans_score'].clone(), 'pLDDT': r['heads']['predicted_lddt']['pLDDT'].clone()}
+
+    a = run(B)
+    for k, v in a.items():
+        assert torch.isfinite(v.double()).all(), k
+    c = run(chunk)
+    for k in a:
+        assert torch.equal(a[k], c[k]), f'chunking changed {k}'
+    model.max_chunk = None
+    ref = O.score_network(params, cpu, cfg, oracle_diffuser)
+    fr = ref['heads']['folding']
+    assert torch.equal(a['seq_0'][:1].cpu(), ref['heads']['sequence_module']['seq_0'])
+    close(a['rigids'][:1], fr['rigids'], 2e-4, 1e-4, 'rigids')
+    close(a['atom14'][:1], fr['final_atom14_positions'], 1e-3, 1e-4, 'atom14')
+    close(a['logits'][:1], ref['heads']['sequence_module']['logits'], 3e-4, 1e-4, 'logits')
+    close(a['trans_score'][:1], fr['trans_score'], 3e-4, 1e-4, 'trans_score')
+    close(a['pLDDT'][:1], ref['heads']['predicted_lddt']['pLDDT'], 5e-3, 1e-4, 'pLDDT')
+
+
+def test_trajectory_mode_real_length(gpu_model, cfg):
+    """BASELINE config 5 shape (L = 261, trajectory mode, device Philox noise): every grid point is recorded, tokens stay in
+    range, fixed residues never move, and the run is reproducible for the same (seed, sample ids)."""
+    from abx_amd import sampler
+    model, D = gpu_model
+    B = 8
+    b = _synthetic_batch(D, '6qd7like', B=B)
+    b['_shared_context'] = True
+    sid = torch.arange(B, device=DEV) + 40
+    D.seed = 17
+    model.max_chunk = None
+    t1 = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=4, sample_ids=sid)
+    D.seed = 17
+    t2 = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=4, sample_ids=sid)
+    assert len(t1) == 4 and [r['time'] for r in t1] == pytest.approx([1.0, 0.67, 0.34, 0.01])
+    fixed = b['fixed_mask'].bool()
+    for r1, r2 in zip(t1, t2):
+        assert torch.isfinite(r1['rigids_t'].double()).all() and torch.isfinite(r1['atom14_results']).all()
+        assert int(r1['seq'].min()) >= 0 and int(r1['seq'].max()) <= 19
+        assert torch.equal(r1['seq'], r2['seq']) and torch.equal(r1['rigids_t'], r2['rigids_t'])
+    for r1 in t1[:-1]:          # reverse() keeps fixed residues (the last record takes the model's own frames)
+        assert torch.equal(r1['seq_t'][fixed], b['seq_t'][fixed])
+        assert (r1['rigids_t'][..., 4:][fixed].double() - b['rigids_t'][..., 4:][fixed].double()).abs().max() < 1e-4
+    assert int((~fixed).sum()) == 13 * B

@@ -177,3 +177,60 @@ def test_glu_weight_packing_and_kernel_name_mirror():
     assert ops.gemm_kernel_name(7040, 256, 256, 1, split=True).startswith('gemm_kernel<64, 64')          # below the split threshold
     assert ops.gemm_kernel_name(M2, 768, 192, 1, split=True, exact=True).startswith('gemm_kernel<128, 192')
     assert ops.gemm_split_eligible(352 * 352, 128, 192, 20) and not ops.gemm_split_eligible(72 * 72, 128, 192, 3)
+
+
+def test_bench_launches_its_own_ranks():
+    """a plain `python bench.py --gpus 2` (no torchrun, WORLD_SIZE unset) starts two ranks by itself.  The
+    launcher self-test runs the same launch + rendezvous path on CPU with gloo: an all_reduce sees both ranks and the padded
+    all_gather of sampler.gather_results returns the sample ids in order, for an uneven shard (7 samples on 2 ranks)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--samples', '7', '--launcher-selftest'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [x for x in out.stdout.splitlines() if x.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r['launcher_selftest'] and r['world'] == 2 and r['rank_sum'] == 1.0
+    assert r['gathered_ids'] == list(range(7)) and r['samples_per_rank'] == [4, 3]
+
+
+_WORKER_EMPTY = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from abx_amd.sampler import shard_sample_ids, gather_results
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+n = 1                                   # more ranks than samples: rank 1 holds nothing and still joins the collective
+ids = shard_sample_ids(n, rank, world)
+local = {'seq': torch.tensor([[i, i + 1] for i in ids], dtype=torch.int64).reshape(len(ids), 2),
+         'rigids': torch.tensor([[float(i) + 0.5] * 7 for i in ids], dtype=torch.float64).reshape(len(ids), 7)}
+out = gather_results(local, n, rank, world)
+assert out['seq'].tolist() == [[0, 1]] and out['rigids'].shape == (1, 7) and float(out['rigids'][0, 0]) == 0.5
+dist.barrier()
+dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def test_gather_results_with_an_empty_rank():
+    with tempfile.TemporaryDirectory() as d:
+        w = os.path.join(d, 'w.py')
+        open(w, 'w').write(_WORKER_EMPTY)
+        out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                              '--master-addr', '127.0.0.1', '--master-port', '29547', w, ROOT],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count('OK') == 2
+
+
+def test_per_sample_init_noise_is_batch_invariant():
+    import torch
+    from abx_amd import features
+    a = features.per_sample_init_noise([3, 4, 9], 12, seed=5)
+    b = features.per_sample_init_noise([9], 12, seed=5)
+    c = features.per_sample_init_noise([9], 12, seed=6)
+    for k in a:
+        assert torch.equal(a[k][2:3], b[k]), k
+    assert not torch.equal(b['trans_z'], c['trans_z'])
+    assert features.per_sample_init_noise([], 12, seed=5) is None
