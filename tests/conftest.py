@@ -67,3 +67,26 @@ def feat_batch_from_golden(g):
             b[k[5:]] = tt(v)
     b['rigidgroups_gt_frames'] = (tt(g['feat.rigidgroups_gt_frames.0']), tt(g['feat.rigidgroups_gt_frames.1']))
     return b
+
+
+def digest_batch(g, name, diffuser, build_features, device=None):
+    """Rebuild the featurised batch of an L256 / L352 digest fixture: the bench's synthetic complex (regenerated from its seed),
+    the feature pipeline run with the recorded init noise, then the reference's own diffusion features on top (so that the network
+    sees bit-identical inputs), and the t features of the in-loop call."""
+    from abx_amd import synthetic
+    cx = synthetic.make_complex(seed=int(g['seed']), **synthetic.WORKLOADS[name])
+    raw = synthetic.collate([cx])
+    if device is not None:
+        raw = {k: v.to(device) for k, v in raw.items()}
+    noise = {k[6:]: tt(v) for k, v in g.items() if k.startswith('noise.')}
+    if device is not None:
+        noise = {k: v.to(device) for k, v in noise.items()}
+    b = build_features(raw, diffuser, generate_area='H3', noise=noise)
+    mine = {k: b[k].detach().cpu().clone() for k in ('rigids_t', 'seq_t', 'fixed_mask', 'torsion_angles_sin_cos', 'rigids_0')}
+    for k in ('rigids_t', 'seq_t', 'fixed_mask', 'torsion_angles_sin_cos', 'rigids_0'):
+        v = tt(g['feat.' + k])
+        b[k] = v.to(device) if device is not None else v
+    for k in ('t', 'rot_score_scaling', 'trans_score_scaling'):
+        v = tt(g['in.' + k])
+        b[k] = v.to(device) if device is not None else v
+    return b, mine

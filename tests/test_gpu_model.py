@@ -534,3 +534,57 @@ def test_trajectory_mode_real_length(gpu_model, cfg):
         assert torch.equal(r1['seq_t'][fixed], b['seq_t'][fixed])
         assert (r1['rigids_t'][..., 4:][fixed].double() - b['rigids_t'][..., 4:][fixed].double()).abs().max() < 1e-4
     assert int((~fixed).sum()) == 13 * B
+
+
+def _check_call_gpu(ret, m, fixed, pair_key, S, tol_scale=1.0):
+    f = ret['heads']['folding']
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'].cpu(), tt(m['out.seq_0']))
+    close(f['rigids'], m['out.rigids'], 1e-4 * tol_scale, 1e-4, 'rigids')                   # north_star: 1e-4 on frames
+    close(f['final_atom14_positions'], m['out.atom14'], 5e-4 * tol_scale, 1e-5, 'atom14')
+    close(ret['heads']['sequence_module']['logits'], m['out.logits'], 2e-4 * tol_scale, 1e-5, 'logits')
+    close(ret['heads']['predicted_lddt']['pLDDT'], m['out.pLDDT'], 2e-3 * tol_scale, 1e-5, 'pLDDT')
+    close(f['trans_score'], m['out.trans_score'], 2e-4 * tol_scale, 1e-5, 'trans_score')
+    close(ret['representations']['seq'], m['out.seq'], 2e-4 * tol_scale, 1e-5, 'trunk seq')
+    pr = ret['representations']['pair']
+    close(pr[:, ::S, ::S], m[pair_key], 3e-4 * tol_scale, 2e-5, 'trunk pair (sub-grid)')
+    assert abs(float(pr.double().sum()) - float(m['out.pair.sum'])) <= 2e-5 * float(m['out.pair.abssum']), 'trunk pair sum'
+    rs, ref = f['rot_score'].cpu().numpy(), m['out.rot_score']
+    dif = (fixed.cpu().numpy() == 0).reshape(-1)
+    bad = (np.abs(rs - ref) > 2e-4 + 1e-4 * np.abs(ref)).reshape(-1, 3).any(axis=1)[dif].mean()
+    assert bad <= 0.1, f'rot_score bucket mismatches {bad}'
+
+
+def test_full_call_matches_reference_golden_L48(gpu_model, cfg):
+    """One in-loop call at L = 48 with a 3-residue padded antigen tail, from a zero self-conditioning state: HIP path vs the
+    reference's own outputs (tests/golden/make_golden_sizes.py)."""
+    model, D = gpu_model
+    m = load_npz('modules_L48.npz')
+    b = feat_batch_from_golden(m)
+    for k in ('seq_t', 'rigids_t', 't', 'rot_score_scaling', 'trans_score_scaling'):
+        b[k] = tt(m['in.' + k])
+    b = to_dev(b)
+    model.max_chunk = None
+    ret = model(b)
+    torch.cuda.synchronize()
+    assert torch.equal(b['seq_t'].cpu(), tt(m['final.seq_t_after']))
+    _check_call_gpu(ret, m, b['fixed_mask'], 'out.pair', int(m['sub']))
+    from abx_amd.model.abx import get_prev
+    assert (get_prev(b, ret, cfg.model)['prev_pos'].cpu().numpy() != m['out.prev_pos']).mean() < 1e-3
+
+
+@pytest.mark.parametrize('name', ['L256', 'L352'])
+def test_large_shape_digest_vs_reference(gpu_model, cfg, name):
+    """the HIP path against outputs of the REFERENCE ITSELF at the benchmark's sizes (the bench's synthetic
+    complexes, B = 1, one in-loop call = 3 passes on the split-bf16 kernels)."""
+    from abx_amd import features
+    from conftest import digest_batch
+    model, D = gpu_model
+    g = load_npz(f'{name}_digest.npz')
+    b, _ = digest_batch(g, name, D, features.build_features, device=DEV)
+    model.max_chunk = None
+    ret = model(b)
+    torch.cuda.synchronize()
+    assert torch.equal(b['seq_t'].cpu(), tt(g['final.seq_t_after']))
+    _check_call_gpu(ret, g, b['fixed_mask'], 'out.pair_sub', int(g['pair_sub']))
+    from abx_amd.model.abx import get_prev
+    assert (get_prev(b, ret, cfg.model)['prev_pos'].cpu().numpy() != g['out.prev_pos']).mean() < 1e-4

@@ -227,3 +227,123 @@ def test_optimize_mode_matches_reference(params, cfg, pinned_diffuser):
     assert np.array_equal(traj[-1]['seq'].numpy(), g['last.seq'])
     close(traj[-1]['atom14_results'], g['last.atom14'], 5e-3, 1e-4, 'optimize atom14')
     close(traj[-1]['rigids_t'], g['final.rigids_t'], 2e-3, 1e-4, 'optimize final rigids')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Beyond the tiny complex: L = 48 with a padded tail, and the bench's L = 256 / 352 complexes
+# ---------------------------------------------------------------------------------------------------------------------
+def test_features_match_reference_L48(oracle_diffuser):
+    from abx_amd import features, synthetic
+    g = load_npz('feat_L48.npz')
+    raw = {k[4:]: tt(v) for k, v in g.items() if k.startswith('raw.')}
+    w = dict(L_heavy=20, L_light=16, L_antigen=12, cdr=(10, 16))
+    again = synthetic.collate([synthetic.make_complex(seed=21, **w), synthetic.make_complex(seed=22, n_masked_tail=3, **w)])
+    for k in raw:
+        assert torch.equal(raw[k], again[k]), k
+    noise = {k[6:]: tt(v) for k, v in g.items() if k.startswith('noise.')}
+    out = features.build_features(dict(raw), oracle_diffuser, generate_area='H3', noise=noise)
+    for k in ('atom14_atom_exists', 'residx_atom37_to_atom14', 'atom37_atom_exists', 'atom37_gt_exists',
+              'rigidgroups_gt_exists', 'torsion_angles_mask', 'fixed_mask', 'struc_loss_mask', 'seq_t'):
+        assert np.array_equal(out[k].numpy(), g['feat.' + k]), k
+    close(out['atom37_gt_positions'], g['feat.atom37_gt_positions'], 0, name='atom37')
+    close(out['rigidgroups_gt_frames'][0], g['feat.rigidgroups_gt_frames.0'], 2e-6, name='frames R')
+    close(out['torsion_angles_sin_cos'], g['feat.torsion_angles_sin_cos'], 2e-6, name='torsions')
+    close(out['rigids_0'], g['feat.rigids_0'], 2e-6, name='rigids_0')
+    close(out['rigids_t'], g['feat.rigids_t'], 1e-5, rtol=1e-6, name='rigids_t')
+    assert int((1 - out['fixed_mask']).sum()) == 2 * 6           # [anchor+1, anchor_r-1): the last CDR residue stays fixed
+
+
+def _l48_state(m):
+    b = feat_batch_from_golden(m)
+    for k in ('seq_t', 'rigids_t', 't', 'rot_score_scaling', 'trans_score_scaling'):
+        b[k] = tt(m['in.' + k])
+    return b
+
+
+def test_modules_match_reference_L48(params, cfg, pinned_diffuser):
+    """Per-module parity at L = 48 with a 3-residue padded antigen tail (mask False): the final pass of one call.  Pair-shaped
+    outputs are compared on the stored [::3, ::3] sub-grid and through their full-tensor sums."""
+    m = load_npz('modules_L48.npz')
+    S = int(m['sub'])
+    p = params
+    b = _l48_state(m)
+    b.update(seq_t=tt(m['pass.seq_t']), prev_pos=tt(m['pass.prev_pos']).long(), prev_seq=tt(m['pass.prev_seq']),
+             prev_pair=tt(m['pass.prev_pair']))
+    mask = b['mask']
+    assert int((~mask).sum()) == 3
+
+    def pclose(x, key, atol, rtol, name):
+        close(x[:, ::S, ::S], m[key], atol, rtol, name)
+        assert abs(float(x.double().sum()) - float(m[key + '.sum'])) <= 2e-5 * float(m[key + '.abssum']) + 1e-3, name + ' sum'
+
+    with torch.no_grad():
+        close(O.residue_embedding(p, b), m['enc_residue.out'], 2e-5, 1e-5, 'residue embedding')
+        pclose(O.pair_embedding(p, b, dict(cfg.model.embeddings_and_seqformer.prev_pos)), 'enc_pair.out', 2e-5, 1e-5, 'pair embedding')
+        seq, pair = tt(m['block.seq_in']), tt(m['block.pair_in'])
+        d = O.seq_attention(p, seq, pair, mask)
+        close(d, m['seq_attn.out'], 2e-5, 1e-5, 'seq_attn')
+        seq = seq + tt(m['seq_attn.out'])
+        close(O.transition(p, O.P_BLK + 'seq_transition', seq), m['seq_transition.out'], 2e-5, 1e-5, 'seq_transition')
+        seq = seq + tt(m['seq_transition.out'])
+        for name, fn in (('opm', lambda z: O.outer_product_mean(p, seq, mask)),
+                         ('trimul_out', lambda z: O.triangle_multiplication(p, 'triangle_multiplication_outgoing', z, mask, True)),
+                         ('trimul_in', lambda z: O.triangle_multiplication(p, 'triangle_multiplication_incoming', z, mask, False)),
+                         ('triattn_start', lambda z: O.triangle_attention(p, 'triangle_attention_starting_node', z, mask, True)),
+                         ('triattn_end', lambda z: O.triangle_attention(p, 'triangle_attention_ending_node', z, mask, False)),
+                         ('pair_transition', lambda z: O.transition(p, O.P_BLK + 'pair_transition', z))):
+            upd = fn(pair)                   # the running pair tensor is the oracle's own (only sub-grids are stored)
+            pclose(upd, name + '.out', 1e-4, 2e-5, name)
+            pair = pair + upd
+        pclose(pair, 'out.pair', 3e-4, 2e-5, 'trunk pair')
+        ipa = O.ipa_attention(p, tt(m['ipa0.in_1d']), tt(m['ipa0.in_2d']), mask.float(), tt(m['ipa0.rots']),
+                              tt(m['ipa0.trans']), cfg.model.heads.diffusion_module.IPA)
+        close(ipa, m['ipa0.out'], 5e-5, 1e-5, 'ipa layer 0')
+
+
+def _check_call(ret, m, fixed, pair_key, S, tol_scale=1.0):
+    f = ret['heads']['folding']
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'].cpu(), tt(m['out.seq_0']))
+    g = lambda x: x.detach().cpu()
+    close(g(f['rigids']), m['out.rigids'], 2e-4 * tol_scale, 1e-5, 'rigids')
+    close(g(f['final_atom14_positions']), m['out.atom14'], 5e-4 * tol_scale, 1e-5, 'atom14')
+    close(g(ret['heads']['sequence_module']['logits']), m['out.logits'], 2e-4 * tol_scale, 1e-5, 'logits')
+    close(g(ret['heads']['predicted_lddt']['pLDDT']), m['out.pLDDT'], 2e-3 * tol_scale, 1e-5, 'pLDDT')
+    close(g(f['trans_score']), m['out.trans_score'], 2e-4 * tol_scale, 1e-5, 'trans_score')
+    close(g(ret['representations']['seq']), m['out.seq'], 2e-4 * tol_scale, 1e-5, 'trunk seq')
+    pr = g(ret['representations']['pair'])
+    close(pr[:, ::S, ::S], m[pair_key], 3e-4 * tol_scale, 2e-5, 'trunk pair (sub-grid)')
+    assert abs(float(pr.double().sum()) - float(m['out.pair.sum'])) <= 2e-5 * float(m['out.pair.abssum']), 'trunk pair sum'
+    rs, ref = g(f['rot_score']).numpy(), m['out.rot_score']
+    dif = (np.asarray(fixed) == 0).reshape(-1)
+    bad = (np.abs(rs - ref) > 2e-4 + 1e-4 * np.abs(ref)).reshape(-1, 3).any(axis=1)[dif].mean()
+    assert bad <= 0.1, f'rot_score bucket mismatches {bad}'
+
+
+def test_full_call_matches_reference_L48(params, cfg, pinned_diffuser):
+    """One in-loop call from a zero self-conditioning state at L = 48, padded tail: oracle vs the reference's outputs."""
+    m = load_npz('modules_L48.npz')
+    b = _l48_state(m)
+    ret = O.score_network(params, b, cfg, pinned_diffuser)
+    assert torch.equal(b['seq_t'], tt(m['final.seq_t_after']))
+    _check_call(ret, m, b['fixed_mask'], 'out.pair', int(m['sub']))
+    prev = O.get_prev(b, ret, cfg)
+    assert (prev['prev_pos'].numpy() != m['out.prev_pos']).mean() < 1e-3
+
+
+@pytest.mark.parametrize('name', ['L256', 'L352'])
+def test_large_shape_digest(params, cfg, pinned_diffuser, name):
+    """The bench's synthetic complexes at L = 256 / 352 (B = 1): host feature pipeline vs the reference's, then one in-loop call of
+    the oracle vs the reference's recorded outputs — the oracle is pinned at the benchmark's own size, not only at L = 20."""
+    from abx_amd import features
+    from conftest import digest_batch
+    g = load_npz(f'{name}_digest.npz')
+    b, mine = digest_batch(g, name, pinned_diffuser, features.build_features)
+    assert torch.equal(mine['seq_t'], tt(g['feat.seq_t'])) and torch.equal(mine['fixed_mask'], tt(g['feat.fixed_mask']))
+    close(mine['rigids_t'], g['feat.rigids_t'], 2e-5, 1e-6, 'rigids_t')
+    close(mine['torsion_angles_sin_cos'], g['feat.torsion_angles_sin_cos'], 2e-6, 0, 'torsions')
+    close(mine['rigids_0'], g['feat.rigids_0'], 2e-6, 1e-6, 'rigids_0')
+    ret = O.score_network(params, b, cfg, pinned_diffuser)
+    assert torch.equal(b['seq_t'], tt(g['final.seq_t_after']))
+    _check_call(ret, g, b['fixed_mask'], 'out.pair_sub', int(g['pair_sub']))
+    prev = O.get_prev(b, ret, cfg)
+    assert (prev['prev_pos'].numpy() != g['out.prev_pos']).mean() < 1e-4
