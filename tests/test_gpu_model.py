@@ -217,62 +217,107 @@ def test_split_bf16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_di
 
 
 def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
-    """Driver-level parity with the split-bf16 kernels active (L = 112, 3 samples: every pair-stack GEMM, the plane contraction
-    and the triangle attention run on the bf16 matrix cores): warm-up call + one reverse step + the final step under the
-    same injected noise, HIP sampler vs oracle sample_fn: tokens exact at every step, frames within 1e-4-class tolerances."""
+    """Driver-level parity with the split-bf16 kernels active (L = 112, 3 samples: every GEMM, the plane contraction and the
+    triangle attention run on the bf16 matrix cores), TEACHER-FORCED (SURVEY §7 hard part 1a): the warm-up call and every grid
+    point of a 3-point trajectory start from the ORACLE's state (rigids_t, seq_t, self-conditioning tensors), so each call and
+    each reverse step is compared on identical inputs at 1e-4-class tolerances, for both HIP arithmetic paths.  Then the
+    free-running HIP sampler against the free-running oracle under the same injected noise: tokens exact at every step."""
     from oracle import abx_oracle as O
     from abx_amd import sampler, ops
+    from abx_amd.model.abx import get_prev
     model, D = gpu_model
     w = dict(L_heavy=46, L_light=40, L_antigen=26, cdr=(28, 36))
     B, L = 3, 112
-    assert ops.gemm_split_eligible(L * L, 128, 192, B)
+    assert ops.gemm_mode(L) == 2
     b = _synthetic_batch(D, w, B=B)
-    cpu = {k: (v.cpu() if torch.is_tensor(v) else tuple(x.cpu() for x in v) if isinstance(v, tuple) else v) for k, v in b.items()}
+    cpu0 = _cpu_copy(b)
     gen = torch.Generator().manual_seed(5)
+    num_t = 3
     noise = [dict(z_rot=torch.randn(B, L, 3, generator=gen), z_trans=torch.randn(B, L, 3, generator=gen),
-                  jumps=torch.poisson(torch.full((B, L, 20), 0.02), generator=gen)) for _ in range(2)]
+                  jumps=torch.poisson(torch.full((B, L, 20), 0.02), generator=gen)) for _ in range(num_t - 1)]
     model.max_chunk = None
-    # ---- the warm-up call alone (inference.py:209-211), HIP vs oracle: the self-conditioning distogram is index work, and the
-    # only pairs whose bin may differ are those whose predicted distance sits on a bin boundary
-    from abx_amd.model.abx import get_prev
-    bw = sampler.set_t_feats({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}, D, 1.0, torch.ones(B, device=DEV))
-    model.invalidate_static()
-    ow = model(bw)
-    hip_bins = get_prev(bw, ow, cfg.model)['prev_pos'].cpu()
-    cw = O.set_t_feats({k: (v.clone() if torch.is_tensor(v) else v) for k, v in cpu.items()}, oracle_diffuser, 1.0, torch.ones(B))
-    rw = O.score_network(params, cw, cfg, oracle_diffuser)
-    ora_bins = O.get_prev(cw, rw, cfg)['prev_pos']
-    pb = O.pseudo_beta_v2(rw['heads']['folding']['final_atom_positions']).double()
-    dist = (pb[:, :, None] - pb[:, None]).norm(dim=-1)
     pp = cfg.model.embeddings_and_seqformer.prev_pos
     breaks = torch.linspace(pp.min_bin, pp.max_bin, steps=pp.num_bins - 1).double()
-    mism = hip_bins != ora_bins
-    assert float(mism.float().mean()) < 2e-4, f'{int(mism.sum())} distogram bins differ'
-    if mism.any():          # every differing pair is within 1e-3 A of a boundary, and off by exactly one bin
-        assert float((dist[mism][:, None] - breaks[None]).abs().min(dim=1).values.max()) < 1e-3
-        assert int((hip_bins[mism] - ora_bins[mism]).abs().max()) == 1
+    dm_cpu = (1 - cpu0['fixed_mask']) * cpu0['atom14_gt_exists'][..., 0]
+    dt = torch.tensor(1 / num_t)
+    steps = np.linspace(0.01, 1.0, num_t)[::-1]
+
+    def hip_call(state, exact):
+        """One HIP ScoreNetwork call on a device copy of the oracle's state."""
+        bb = to_dev({k: (v.clone() if torch.is_tensor(v) else v) for k, v in state.items()})
+        ops.GEMM_EXACT = exact
+        try:
+            r = model(bb)
+            torch.cuda.synchronize()
+        finally:
+            ops.GEMM_EXACT = False
+        return bb, r
+
+    def compare_call(tag, state_before, ro, state_after):
+        for exact in (False, True):
+            bb, rh = hip_call(state_before, exact)
+            name = f'{tag} {"exact" if exact else "split"}'
+            f, fr = rh['heads']['folding'], ro['heads']['folding']
+            assert torch.equal(rh['heads']['sequence_module']['seq_0'].cpu(), ro['heads']['sequence_module']['seq_0']), name + ' seq_0'
+            assert torch.equal(bb['seq_t'].cpu(), state_after['seq_t']), name + ' seq_t after the call'
+            close(f['rigids'], fr['rigids'], 1e-4, 1e-4, name + ' rigids')
+            close(f['final_atom14_positions'], fr['final_atom14_positions'], 5e-4, 1e-4, name + ' atom14')
+            close(rh['heads']['sequence_module']['logits'], ro['heads']['sequence_module']['logits'], 2e-4, 1e-4, name + ' logits')
+            close(f['trans_score'], fr['trans_score'], 2e-4, 1e-4, name + ' trans_score')
+            close(rh['heads']['predicted_lddt']['pLDDT'], ro['heads']['predicted_lddt']['pLDDT'], 3e-3, 1e-4, name + ' pLDDT')
+            rs, ref = f['rot_score'].cpu().numpy(), fr['rot_score'].numpy()
+            dif = (state_before['fixed_mask'].numpy() == 0).reshape(-1)
+            bad = (np.abs(rs - ref) > 2e-4 + 1e-4 * np.abs(ref)).reshape(-1, 3).any(axis=1)[dif].mean()
+            assert bad <= 0.05, f'{name}: rot_score bucket mismatches {bad}'
+            # self-conditioning distogram: index work; only pairs whose predicted distance sits on a bin boundary may differ
+            hip_bins = get_prev(bb, rh, cfg.model)['prev_pos'].cpu()
+            ora_bins = O.get_prev(state_after, ro, cfg)['prev_pos']
+            mism = hip_bins != ora_bins
+            assert float(mism.float().mean()) < 2e-4, f'{name}: {int(mism.sum())} distogram bins differ'
+            if mism.any():
+                pb = O.pseudo_beta_v2(fr['final_atom_positions']).double()
+                dist = (pb[:, :, None] - pb[:, None]).norm(dim=-1)
+                assert float((dist[mism][:, None] - breaks[None]).abs().min(dim=1).values.max()) < 1e-3
+                assert int((hip_bins[mism] - ora_bins[mism]).abs().max()) == 1
+        return rh
+
+    clone = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    # ---- warm-up call (inference.py:209-211): fp32 t, no self-conditioning state yet
+    st = O.set_t_feats(clone(cpu0), oracle_diffuser, steps[0], torch.ones(B))
+    before = clone(st)
+    ro = O.score_network(params, st, cfg, oracle_diffuser)
+    compare_call('warm-up', before, ro, st)
+    st.update(O.get_prev(st, ro, cfg))
+    # ---- grid points
+    for k, t in enumerate(steps):
+        if t > 0.01:
+            t_ = torch.tile(torch.tensor(t), (B,))
+            st = O.set_t_feats(st, oracle_diffuser, t_, torch.ones(B))
+        before = clone(st)
+        ro = O.score_network(params, st, cfg, oracle_diffuser)
+        compare_call(f'grid point {k}', before, ro, st)
+        if t > 0.01:
+            fo = ro['heads']['folding']
+            st.update(O.get_prev(st, ro, cfg))
+            rig_o, seq_o = oracle_diffuser.reverse(rigid_t=st['rigids_t'], seq_t=st['seq_t'], rot_score=fo['rot_score'],
+                                                   trans_score=fo['trans_score'], logits_t=ro['heads']['sequence_module']['logits'],
+                                                   diffuse_mask=dm_cpu, t=t_, dt=dt, noise=noise[k])
+            rig_h, seq_h = D.reverse(rigid_t=st['rigids_t'].to(DEV), seq_t=st['seq_t'].to(DEV), rot_score=fo['rot_score'].to(DEV),
+                                     trans_score=fo['trans_score'].to(DEV), logits_t=ro['heads']['sequence_module']['logits'].to(DEV),
+                                     diffuse_mask=dm_cpu.to(DEV), t=t_.to(DEV), dt=float(dt),
+                                     noise={kk: v.to(DEV) for kk, v in noise[k].items()})
+            assert torch.equal(seq_h.cpu(), seq_o.long()), f'reverse step {k}: tokens'
+            close(rig_h, rig_o, 2e-6, 1e-6, f'reverse step {k} rigids')
+            st['rigids_t'], st['seq_t'] = rig_o, seq_o
+    # ---- free-running samplers under the same noise: tokens exact at every step
     nf = lambda k: {kk: v.to(DEV) for kk, v in noise[k].items()}
-    traj = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=2, noise_fn=nf)
-    ops.GEMM_EXACT = True
-    try:
-        traj_x = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=2, noise_fn=nf)
-    finally:
-        ops.GEMM_EXACT = False
-    ref = O.sample_fn(params, cpu, cfg, oracle_diffuser, mode='trajectory', num_t=2, noise_fn=lambda k: noise[k])
-    assert len(traj) == len(ref) == 2
-    err = lambda x, y: float((x.detach().cpu().double() - y.double()).abs().max())
-    for k, (d, dx, r) in enumerate(zip(traj, traj_x, ref)):
+    traj = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=num_t, noise_fn=nf)
+    ref = O.sample_fn(params, cpu0, cfg, oracle_diffuser, mode='trajectory', num_t=num_t, noise_fn=lambda k: noise[k])
+    assert len(traj) == len(ref) == num_t
+    for k, (d, r) in enumerate(zip(traj, ref)):
         assert torch.equal(d['seq'].cpu(), r['seq']), f'step {k}: tokens differ'
         assert torch.equal(d['seq_t'].cpu().long(), r['seq_t'].long()), f'step {k}: seq_t differs'
-        assert torch.equal(d['seq'], dx['seq'])
-        # the two HIP arithmetic paths stay together along the trajectory (dt = 0.5 amplifies score differences ~10x)
-        assert err(d['rigids_t'], dx['rigids_t'].cpu()) < 2e-3, f'step {k}: split vs exact rigids_t'
-        assert err(d['atom14_results'], dx['atom14_results'].cpu()) < 2e-3, f'step {k}: split vs exact atom14'
-        # Against the CPU oracle the comparison after the FIRST call is limited by the self-conditioning distogram
-        # (abx.py:17-20): prev_pos is a hard binning of predicted distances, a 1e-5 A rounding difference flips the bin of the
-        # ~1e-5 fraction of the 37 632 pairs that sit on a boundary, and one flipped embedding row moves the next
-        # prediction by ~0.1 A.  Both HIP paths pick identical bins (asserted above through their 2e-3 agreement).
-        assert err(d['rigids_t'], r['rigids_t']) < 0.3 and err(d['atom14_results'], r['atom14_results']) < 0.5, f'step {k} vs oracle'
+        assert torch.isfinite(d['rigids_t']).all()
 
 
 def test_full_size_properties(gpu_model, cfg):
