@@ -215,36 +215,52 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 }
 
 // ---- triangle attention on the bf16 matrix cores (split-bf16, see gemm3.hip for the arithmetic) ------------------------------
-// Same (b, row s, head h) decomposition, online softmax and swapped S^T / O^T products as tri_attn_kernel, but both contractions
-// run on v_mfma_f32_16x16x32_bf16 with every fp32 operand written exactly as three bf16 pieces (6 products, fp32 accumulate:
-// fp32-accurate, 2.3x less matrix-core time than the exact v_mfma_f32_16x16x4_f32 kernel at head dim 48).
-//   K, V are split ONCE per block while they are staged, in chunks of 192 keys (so any L fits the LDS):
-//     K planes  [3][key][48 d]  bf16,  96-byte rows     -> A operand of S^T = K Q^T   (lane: key, 8 consecutive d)
-//     V^T planes [3][d][key']   bf16, 416-byte rows     -> A operand of O^T += V^T P  (lane: d, 8 keys in accumulator order)
-//   Q is split per query tile in registers, P per key tile in registers (the S^T accumulators of two 16-key sub-blocks are
-//   exactly the 8 keys a lane feeds to one PV MFMA; V^T is stored in that key order).
-//   The running (max, sum, O^T) of a wave's query tiles live in registers across the key chunks.
-constexpr int KCH = 192;                 // keys per chunk (3 tiles of 64)
-constexpr int KST = 96;                  // bytes per key row of a K plane: 32 * odd -> the 16-byte fragment reads (lane -> row, lane >> 4 -> 16-byte
-constexpr int VST = KCH * 2 + 32;        // column) of a ds_read_b128 lane group fall on 64 distinct banks; same for the V^T rows (416 = 32 * 13)
-constexpr int K_PLANE = KCH * KST, V_PLANE = TD * VST;
+// Same (b, row s, head h) decomposition, online softmax and swapped S^T product as tri_attn_kernel, with every fp32 operand written
+// exactly as three bf16 pieces (6 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32-accurate).
+//   K, V of the row are split ONCE, while they are staged, in chunks of 128 keys, DOUBLE BUFFERED: the global loads of chunk
+//   c + 1 are issued before the wave computes on chunk c and are split + written afterwards, ONE barrier per chunk.
+//     K planes [3][key][48 d] bf16 (96-byte rows)  -> A operand of S^T = K Q^T          (lane: key, 8 consecutive d; ds_read_b128)
+//     V planes [3][key][48 d] bf16 (same image)    -> B operand of O  += P V            (lane: d, 8 keys) through the transposing
+//                                                     LDS read ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 d] block
+//                                                     and lane n receives its column n; no transposed staging writes
+//   Q is split per query tile in registers; P per key tile in registers: the S^T accumulators of two 16-key sub-blocks (lane:
+//   query lq, keys 4g + r) are exactly the 8 k-values lane (m = lq, k-group g) feeds to the A operand of one PV MFMA.
+//   O[q][d] accumulators: column = d, rows q = 4g + r; the running (max, sum) live with the S^T columns (lane & 15 = query) and
+//   reach the O rows through 4 lane shuffles when a rescale is needed.
+//   The pair bias is read in rows of bias_sq floats (bias_sk == 1: rows padded to a multiple of 4 -> 16-byte loads for any L).
+//   Grid: 1-D, ordered so that the workgroups resident on one XCD walk the rows of ONE (b, h) pair: its (L, L) bias (495 KB at
+//   L = 352) stays in that XCD's L2 instead of being re-fetched from HBM by every row.
+constexpr int KC4 = 128;                 // keys per chunk
+constexpr int RST = 96;                  // bytes per key row of a plane: 32 * odd -> 16-byte fragment reads of 16 consecutive rows hit 64 banks
+constexpr int PLN = KC4 * RST;           // bytes per plane
+constexpr int BUF4 = 6 * PLN;            // K planes + V planes of one chunk
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
 
 template <int MAXQ>
-__global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn a) {
+__global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* Kp = reinterpret_cast<char*>(smem);
-    char* Vp = Kp + 3 * K_PLANE;
-    float* Ms = reinterpret_cast<float*>(Vp + 3 * V_PLANE);      // [KCH] additive key-mask codes of the chunk + 1 flag
+    char* lds = reinterpret_cast<char*>(smem);
+    float* Msb = reinterpret_cast<float*>(lds + 2 * BUF4);       // [2][KC4] key-mask clamps of the two chunks in flight
     const int L = a.L;
-    const int h = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    // ---- (b, h, s) of this workgroup: XCD x (blockIdx & 7) owns the (b, h) pairs x, x + 8, ... and walks their rows in order
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / a.S) * 8 + xcd, s = slot % a.S;
+    if (bh >= a.B * a.H) return;
+    const int b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, g = lane >> 4;
     const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
     const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
     const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
     const int nqt = (L + 15) / 16;
-    const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && (L % 4 == 0) &&
-                          ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
+    const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
+    const int bias_row = (int)a.bias_sq;                        // readable floats per bias row when bias_sk == 1
     const float qscale = a.scale * LOG2E;
 
     float m_run[MAXQ], l_run[MAXQ];
@@ -257,45 +273,61 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn
         for (int d = 0; d < 3; ++d) o[sl][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int c0 = 0; c0 < L; c0 += KCH) {
-        const int nkeys = min(KCH, L - c0);                    // valid keys of this chunk
-        const int nkt = (nkeys + 63) / 64;
-        __syncthreads();                                        // the previous chunk has been consumed
-        // ---- stage + split K, V of keys [c0, c0 + nkt * 64): 12 float4 per key; padded keys are zero
-        for (int idx = tid; idx < nkt * 64 * (TD / 4); idx += TRI_THREADS) {
+    // staging share of this thread: 2 (key, 4-channel) items of a chunk: 128 keys x 12 float4 = 1536 items over 768 threads
+    f32x4 kreg[2], vreg[2];
+    auto stage_load = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * TRI_THREADS;
             const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (kk < nkeys) {
+            kreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            vreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c0 + kk < L) {
                 const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
-                kv = *reinterpret_cast<const f32x4*>(a.k + off);
-                vv = *reinterpret_cast<const f32x4*>(a.v + off);
+                kreg[it] = *reinterpret_cast<const f32x4*>(a.k + off);
+                vreg[it] = *reinterpret_cast<const f32x4*>(a.v + off);
             }
+        }
+    };
+    auto stage_write = [&](int c0, int buf) {
+        char* Kp = lds + buf * BUF4;
+        char* Vp = Kp + 3 * PLN;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * TRI_THREADS;
+            const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
             unsigned a0, a1, a2, b0, b1, b2;
-            split2(kv[0], kv[1], a0, a1, a2);
-            split2(kv[2], kv[3], b0, b1, b2);
-            char* kd = Kp + kk * KST + c4 * 8;
+            split2(kreg[it][0], kreg[it][1], a0, a1, a2);
+            split2(kreg[it][2], kreg[it][3], b0, b1, b2);
+            char* kd = Kp + kk * RST + c4 * 8;
             *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
-            *reinterpret_cast<u32x2*>(kd + K_PLANE) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2*>(kd + 2 * K_PLANE) = u32x2{a2, b2};
-            // V^T: key position inside its 32-key group follows the S^T accumulator order (rows 4g + r of two 16-key sub-blocks)
-            const int o32 = kk & 31, og = (o32 & 15) >> 2, oe = (o32 & 3) + ((o32 >> 4) << 2);
-            const int pos = (kk & ~31) + og * 8 + oe;
-            split2(vv[0], vv[1], a0, a1, a2);
-            split2(vv[2], vv[3], b0, b1, b2);
-            unsigned short* vd = reinterpret_cast<unsigned short*>(Vp + (c4 * 4) * VST) + pos;
-            constexpr int VS2 = VST / 2, VP2 = V_PLANE / 2;
-            vd[0] = (unsigned short)(a0 & 0xffffu); vd[VS2] = (unsigned short)(a0 >> 16);
-            vd[2 * VS2] = (unsigned short)(b0 & 0xffffu); vd[3 * VS2] = (unsigned short)(b0 >> 16);
-            vd[VP2] = (unsigned short)(a1 & 0xffffu); vd[VP2 + VS2] = (unsigned short)(a1 >> 16);
-            vd[VP2 + 2 * VS2] = (unsigned short)(b1 & 0xffffu); vd[VP2 + 3 * VS2] = (unsigned short)(b1 >> 16);
-            vd[2 * VP2] = (unsigned short)(a2 & 0xffffu); vd[2 * VP2 + VS2] = (unsigned short)(a2 >> 16);
-            vd[2 * VP2 + 2 * VS2] = (unsigned short)(b2 & 0xffffu); vd[2 * VP2 + 3 * VS2] = (unsigned short)(b2 >> 16);
+            *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(kd + 2 * PLN) = u32x2{a2, b2};
+            split2(vreg[it][0], vreg[it][1], a0, a1, a2);
+            split2(vreg[it][2], vreg[it][3], b0, b1, b2);
+            char* vd = Vp + kk * RST + c4 * 8;
+            *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
+            *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
+            *reinterpret_cast<u32x2*>(vd + 2 * PLN) = u32x2{a2, b2};
         }
         // key-mask clamps, applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit
         // by finfo.min: every finite logit is >= finfo.min, so min() is that replacement), -inf beyond L
-        for (int kk = tid; kk < nkt * 64; kk += TRI_THREADS)
-            Ms[kk] = kk < nkeys ? ((!km || km[c0 + kk] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
-        __syncthreads();
+        if (tid < KC4) Msb[buf * KC4 + tid] = (c0 + tid < L) ? ((!km || km[c0 + tid] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+    };
+
+    stage_load(0);
+    stage_write(0, 0);
+    __syncthreads();
+
+    const int nchunk = (L + KC4 - 1) / KC4;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = ch * KC4, buf = ch & 1;
+        const int nkeys = min(KC4, L - c0);
+        const int nkt = (nkeys + 63) / 64;
+        if (ch + 1 < nchunk) stage_load(c0 + KC4);             // in flight under this chunk's MFMAs
+        const char* Kp = lds + buf * BUF4;
+        const char* Vp = Kp + 3 * PLN;
+        const float* Ms = Msb + buf * KC4;
 
 #pragma unroll
         for (int sl = 0; sl < MAXQ; ++sl) {
@@ -331,36 +363,33 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn
 
             for (int kt = 0; kt < nkt; ++kt) {
                 const int k0 = kt * 64;
-                // ---- bias of this tile (keys k0 + sub*16 + 4g + r), issued first
-                float bz[4][4];
-                if (bias_vec && c0 + k0 + 64 <= L) {
-#pragma unroll
-                    for (int sub = 0; sub < 4; ++sub) {
-                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + k0 + sub * 16 + g * 4);
-                        bz[sub][0] = t4[0]; bz[sub][1] = t4[1]; bz[sub][2] = t4[2]; bz[sub][3] = t4[3];
-                    }
-                } else {
-#pragma unroll
-                    for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = min(k0 + sub * 16 + g * 4 + r, nkeys - 1);
-                            bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
-                        }
-                }
-                // ---- S^T tiles: 4 sub-blocks of 16 keys x 2 d-steps x 6 products
+                // ---- bias of this tile (keys k0 + sub*16 + 4g + r), issued first: it becomes the initial value of the S^T accumulators
                 f32x4 sc[4];
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
-                    const char* kr = Kp + (k0 + sub * 16 + lq) * KST + g * 16;
+                    const int kq = k0 + sub * 16 + g * 4;                // first of this lane's 4 keys (chunk-relative)
+                    if (bias_vec && c0 + kq + 4 <= bias_row) {
+                        sc[sub] = *reinterpret_cast<const f32x4*>(brow + kq);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = min(kq + r, nkeys - 1);
+                            sc[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
+                        }
+                    }
+                }
+                // ---- S^T tiles: 4 sub-blocks of 16 keys x 2 d-steps x 6 products, accumulated on top of bias * log2(e)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const char* kr = Kp + (k0 + sub * 16 + lq) * RST + g * 16;
                     bf16x8 ka[2][3];
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
-                        ka[0][p] = *reinterpret_cast<const bf16x8*>(kr + p * K_PLANE);
+                        ka[0][p] = *reinterpret_cast<const bf16x8*>(kr + p * PLN);
                         // d 32..47: lane groups 0, 1 read d 32 + 8g; groups 2, 3 re-read a valid address and are multiplied by Q = 0
-                        ka[1][p] = *reinterpret_cast<const bf16x8*>(kr + p * K_PLANE + 64 - (g >> 1) * 32);
+                        ka[1][p] = *reinterpret_cast<const bf16x8*>(kr + p * PLN + 64 - (g >> 1) * 32);
                     }
-                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 c = sc[sub] * LOG2E;
 #pragma unroll
                     for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = fminf(fmaf(bz[sub][r], LOG2E, sc[sub][r]), mk[r]);
+                        const float v = fminf(sc[sub][r], mk[r]);
                         sc[sub][r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -398,12 +427,15 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn
                 lr = lr * alpha + rs;
                 mr = m_new;
                 if (!__all(alpha == 1.0f)) {
+                    // O rows are the queries 4g + r: their rescale factors live in the lanes whose column is that query
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
+                    for (int r = 0; r < 4; ++r) {
+                        const float ar = __shfl(alpha, 4 * g + r, 64);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) oo[d][r] *= alpha;
+                        for (int d = 0; d < 3; ++d) oo[d][r] *= ar;
+                    }
                 }
-                // ---- O^T += V^T P: one MFMA step contracts the 32 keys of two sub-blocks
+                // ---- O += P V: one MFMA step contracts the 32 keys of two sub-blocks; A = P (registers), B = V (transposing reads)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     unsigned p0[4], p1[4], p2[4];
@@ -411,50 +443,53 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn3_kernel(const AbxTriAttn
                     split2(sc[2 * m][2], sc[2 * m][3], p0[1], p1[1], p2[1]);
                     split2(sc[2 * m + 1][0], sc[2 * m + 1][1], p0[2], p1[2], p2[2]);
                     split2(sc[2 * m + 1][2], sc[2 * m + 1][3], p0[3], p1[3], p2[3]);
-                    bf16x8 pb[3];
-                    pb[0] = __builtin_bit_cast(bf16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
-                    pb[1] = __builtin_bit_cast(bf16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
-                    pb[2] = __builtin_bit_cast(bf16x8, u32x4{p2[0], p2[1], p2[2], p2[3]});
-                    const char* vr = Vp + lq * VST + (k0 + m * 32 + g * 8) * 2;
-                    bf16x8 va[3][3];
+                    bf16x8 pa[3];
+                    pa[0] = __builtin_bit_cast(bf16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+                    pa[1] = __builtin_bit_cast(bf16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
+                    pa[2] = __builtin_bit_cast(bf16x8, u32x4{p2[0], p2[1], p2[2], p2[3]});
+                    // lane i of a 16-lane group supplies row (4g + i/4) of the sub-block, 4 channels (i%4)*4.. of the 16-channel block
+                    const char* vr = Vp + (k0 + m * 32 + 4 * g + (lq >> 2)) * RST + (lq & 3) * 8;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
+                    for (int d = 0; d < 3; ++d) {
+                        bf16x8 vb[3];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) va[d][p] = *reinterpret_cast<const bf16x8*>(vr + d * 16 * VST + p * V_PLANE);
+                        for (int p = 0; p < 3; ++p) {
+                            const s16x4 lo = lds_tr16(vr + p * PLN + d * 32);
+                            const s16x4 hi = lds_tr16(vr + p * PLN + d * 32 + 16 * RST);
+                            vb[p] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                        }
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
-#pragma unroll
-                        for (int d = 0; d < 3; ++d)
-                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[d][TA[term]], pb[TB[term]], oo[d], 0, 0, 0);
+                        for (int term = 0; term < 6; ++term)
+                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[TA[term]], vb[TB[term]], oo[d], 0, 0, 0);
+                    }
                 }
             }
             m_run[sl] = mr;
             l_run[sl] = lr;
             o[sl][0] = oo[0]; o[sl][1] = oo[1]; o[sl][2] = oo[2];
         }
+        if (ch + 1 < nchunk) stage_write(c0 + KC4, buf ^ 1);   // the other buffer was last read before the previous barrier
+        __syncthreads();
     }
-    // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
+    // ---- normalise, gate, store.  O layout: column d = dblk*16 + lq, rows = queries 4g + r
 #pragma unroll
     for (int sl = 0; sl < MAXQ; ++sl) {
         const int qt = wave + sl * (TRI_THREADS / 64);
-        const int qrow = qt * 16 + lq;
-        if (qt >= nqt || qrow >= L) continue;
+        if (qt >= nqt) continue;
         const float inv = 1.0f / l_run[sl];
-        const long long go = base + (long long)qrow * a.sl;
-        float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int dd = d * 16 + g * 4;
-            f32x4 v = o[sl][d];
-            if (a.gate) {
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
+        for (int r = 0; r < 4; ++r) {
+            const float ir = __shfl(inv, 4 * g + r, 64);
+            const int qrow = qt * 16 + 4 * g + r;
+            if (qrow >= L) continue;
+            const long long go = base + (long long)qrow * a.sl;
+            float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * (1.0f / (1.0f + expf(-gv[r])));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= inv;
+            for (int d = 0; d < 3; ++d) {
+                float v = o[sl][d][r] * ir;
+                if (a.gate) v *= 1.0f / (1.0f + expf(-a.gate[go + d * 16 + lq]));
+                op[d * 16 + lq] = v;
             }
-            *reinterpret_cast<f32x4*>(op + dd) = v;
         }
     }
 }
@@ -525,22 +560,24 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
     if (!a.exact) {
-        // split-bf16 kernel: K / V staged in 192-key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
-        const size_t lds3 = (size_t)3 * K_PLANE + (size_t)3 * V_PLANE + (KCH + 4) * sizeof(float);
+        // split-bf16 kernel: K / V staged in double-buffered 128-key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
+        const size_t lds4 = (size_t)2 * BUF4 + 2 * KC4 * sizeof(float);
         const int slots = ((a.L + 15) / 16 + TRI_THREADS / 64 - 1) / (TRI_THREADS / 64);
         ABX_REQUIRE(slots <= 8, "abx_tri_attn_fwd: L too large (L <= 1536)");
-        static thread_local bool configured3 = false;
-        if (!configured3) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn3_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        static thread_local bool configured4 = false;
+        if (!configured4) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn4_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn4_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
             if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
-            configured3 = true;
+            configured4 = true;
         }
-        const dim3 grid(a.H, a.S, a.B), block(TRI_THREADS);
-        if (slots <= 2) hipLaunchKernelGGL(tri_attn3_kernel<2>, grid, block, lds3, st, a);
-        else if (slots <= 4) hipLaunchKernelGGL(tri_attn3_kernel<4>, grid, block, lds3, st, a);
-        else hipLaunchKernelGGL(tri_attn3_kernel<8>, grid, block, lds3, st, a);
+        const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
+        ABX_REQUIRE(nbh8 * a.S < (1LL << 31), "abx_tri_attn_fwd: grid too large");
+        const dim3 grid((unsigned)(nbh8 * a.S)), block(TRI_THREADS);
+        if (slots <= 2) hipLaunchKernelGGL(tri_attn4_kernel<2>, grid, block, lds4, st, a);
+        else if (slots <= 4) hipLaunchKernelGGL(tri_attn4_kernel<4>, grid, block, lds4, st, a);
+        else hipLaunchKernelGGL(tri_attn4_kernel<8>, grid, block, lds4, st, a);
         return abx_check_launch("abx_tri_attn_fwd");
     }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);

@@ -306,30 +306,37 @@ __global__ __launch_bounds__(256) void pair_embed_features_kernel(
     }
 }
 
-// out[n][j][i] = in[n][i][j] for nmat square L x L matrices (32x32 LDS tiles, both sides coalesced)
-__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int L) {
+// out[n][a][b] = in[n][b][a] (transpose) or in[n][a][b] (copy) for nmat L x L matrices, output rows padded to Lp >= L entries
+// (pad columns written as 0): 32x32 LDS tiles, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int L, int Lp,
+                                                              int transpose) {
     __shared__ float tile[32][33];
-    const long long base = (long long)blockIdx.z * L * L;
-    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const long long ibase = (long long)blockIdx.z * L * L, obase = (long long)blockIdx.z * L * Lp;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;         // output tile: rows a0.., columns b0..
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int i = i0 + ty + r * 8, j = j0 + tx;
-        if (i < L && j < L) tile[ty + r * 8][tx] = in[base + (long long)i * L + j];
+        // transpose: read in[b][a] with a fastest; copy: read in[a][b] with b fastest
+        const int y = ty + r * 8;
+        const int ia = transpose ? a0 + tx : a0 + y, ib = transpose ? b0 + y : b0 + tx;
+        float v = 0.f;
+        if (ia < L && ib < L) v = transpose ? in[ibase + (long long)ib * L + ia] : in[ibase + (long long)ia * L + ib];
+        if (transpose) tile[y][tx] = v;            // tile[b - b0][a - a0]
+        else tile[tx][y] = v;                      // tile[b - b0][a - a0]
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int j = j0 + ty + r * 8, i = i0 + tx;
-        if (i < L && j < L) out[base + (long long)j * L + i] = tile[tx][ty + r * 8];
+        const int a = a0 + ty + r * 8, b = b0 + tx;
+        if (a < L && b < Lp) out[obase + (long long)a * Lp + b] = tile[tx][ty + r * 8];
     }
 }
 
 }  // namespace
 
-extern "C" int abx_transpose_last2(const float* in, float* out, int nmat, int L, hipStream_t st) {
-    ABX_REQUIRE(in && out && in != out && nmat > 0 && nmat <= 65535 && L > 0, "abx_transpose_last2: bad args");
-    hipLaunchKernelGGL(transpose_last2_kernel, dim3((L + 31) / 32, (L + 31) / 32, nmat), dim3(256), 0, st, in, out, L);
+extern "C" int abx_transpose_last2(const float* in, float* out, int nmat, int L, int Lp, int transpose, hipStream_t st) {
+    ABX_REQUIRE(in && out && in != out && nmat > 0 && nmat <= 65535 && L > 0 && Lp >= L, "abx_transpose_last2: bad args");
+    hipLaunchKernelGGL(transpose_last2_kernel, dim3((Lp + 31) / 32, (L + 31) / 32, nmat), dim3(256), 0, st, in, out, L, Lp, transpose);
     return abx_check_launch("abx_transpose_last2");
 }
 

@@ -341,10 +341,14 @@ class Engine:
             bT = ws.get('biasT', (Bc, 4, LL))
             _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2))
             o = w384[:M2 * 192].view(M2, 192)
-            if not per_row:            # ending node: bias[b,h,q,k] = P[b,k,q,h] -> make it key-contiguous once (2 MB / sample)
-                bT2 = ws.get('biasT2', (Bc, 4, LL))
-                ops.transpose_last2(bT.view(Bc * 4, L, L), bT2.view(Bc * 4, L, L))
+            # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
+            # i.e. the transpose (2 MB per sample); starting node: a padded copy only when L % 4 != 0
+            if not per_row or Lp != L:
+                bT2 = ws.get('biasT2', (Bc, 4, L, Lp))
+                ops.transpose_last2(bT.view(Bc * 4, L, L), bT2.view(Bc * 4, L, Lp), transpose=not per_row)
                 bT = bT2
+            else:
+                bT = bT.view(Bc, 4, L, L)
             ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True)
             _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
         # ---------------- pair transition

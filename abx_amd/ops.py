@@ -249,10 +249,12 @@ def layernorm(x, gamma, beta, out=None, res=None, eps=1e-5):
     return out
 
 
-def transpose_last2(x, out):
-    L = x.shape[-1]
-    assert x.shape[-2] == L and x.is_contiguous() and out.is_contiguous() and out.shape == x.shape
-    check(_lib.load().abx_transpose_last2(_p(_f32(x)), _p(out), x.numel() // (L * L), L, _stream()), 'abx_transpose_last2')
+def transpose_last2(x, out, transpose=True):
+    """x (n, L, L) -> out (n, L, Lp): out[n, a, b] = x[n, b, a] (or x[n, a, b] when transpose=False), pad columns b >= L zeroed."""
+    L, Lp = x.shape[-1], out.shape[-1]
+    assert x.shape[-2] == L and x.is_contiguous() and out.is_contiguous() and out.shape[:-1] == x.shape[:-1] and Lp >= L
+    check(_lib.load().abx_transpose_last2(_p(_f32(x)), _p(out), x.numel() // (L * L), L, Lp, int(bool(transpose)), _stream()),
+          'abx_transpose_last2')
     return out
 
 
@@ -266,7 +268,8 @@ def tri_attn_kernel_name(L, exact=None):
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None):
     """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
-    already laid out [b,h,q,k] for this orientation (bias_is_qk=True); out (B*L*L, H*D)."""
+    already laid out [b,h,q,k] for this orientation (bias_is_qk=True; then (B,H,L,Lp) with rows padded to Lp % 4 == 0 floats gives
+    the kernel 16-byte bias loads for any L); out (B*L*L, H*D)."""
     lib = _lib.load()
     W = qkvg.shape[1]
     assert W == 4 * H * D and qkvg.is_contiguous() and out.is_contiguous() and biasT.is_contiguous()
@@ -277,8 +280,10 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.sb = L * L * W
     a.ss, a.sl = (L * W, W) if per_row else (W, L * W)
     a.bias = _p(biasT)
-    a.bias_sb, a.bias_sh = H * L * L, L * L
-    a.bias_sq, a.bias_sk = (L, 1) if (per_row or bias_is_qk) else (1, L)
+    Lp = biasT.shape[-1] if (biasT.dim() == 4 and bias_is_qk) else L       # (B,H,L,Lp): key-contiguous rows padded to Lp floats
+    assert biasT.numel() == B * H * L * Lp
+    a.bias_sb, a.bias_sh = H * L * Lp, L * Lp
+    a.bias_sq, a.bias_sk = (Lp, 1) if (per_row or bias_is_qk) else (1, L)
     if keymask is not None:
         a.keymask, a.km_sb = _p(_f32(keymask)), L
     C_ = H * D

@@ -167,9 +167,10 @@ int abx_assemble_pair(const float* pair_static, long long ps_b, const float* tem
  * left/right rows have stride ld floats */
 int abx_opm_features(const float* left, const float* right, long long ld, float* feat, int B, int L, int C,
                      hipStream_t stream);
-/* out[n][j][i] = in[n][i][j] for nmat L x L matrices: the ending-node triangle attention reads its (4, L, L) pair bias
- * transposed ('b i j c -> b j i c', seqformer.py:536) so that both orientations read it key-contiguously */
-int abx_transpose_last2(const float* in, float* out, int nmat, int L, hipStream_t stream);
+/* out[n][a][b] = in[n][b][a] (transpose != 0) or in[n][a][b] for nmat L x L matrices, output rows padded to Lp >= L floats (pad
+ * columns = 0).  The triangle attention reads its (4, L, L) pair bias key-contiguously in rows of Lp % 4 == 0 floats (16-byte
+ * loads for any residue count); the ending-node orientation reads it transposed ('b i j c -> b j i c', seqformer.py:536) */
+int abx_transpose_last2(const float* in, float* out, int nmat, int L, int Lp, int transpose, hipStream_t stream);
 /* pair mask[b,i,j] = mask[b,i]*mask[b,j], rows of Lp >= L entries (columns j >= L are written as 0: the padded pair rows of
  * AbxGemm.pair_Lp) */
 int abx_pair_mask(const float* mask, float* out, int B, int L, int Lp, hipStream_t stream);

@@ -415,10 +415,10 @@ def test_gemm_small_n_and_relu_input(ops):
 
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('exact', [False, True])
-@pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False), (200, True), (212, False)])
+@pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False), (200, True), (212, False), (261, True), (300, False)])
 def test_tri_attn(ops, L, per_row, exact):
-    """exact=False: split-bf16 kernel (K/V chunks of 192 keys: L = 200 / 212 cross a chunk boundary and carry the online
-    softmax state over it); exact=True: fp32 MFMA kernel."""
+    """exact=False: split-bf16 kernel (K/V in double-buffered chunks of 128 keys: L = 200 / 212 cross one chunk boundary, 261 / 300
+    two, and carry the online softmax state over them); exact=True: fp32 MFMA kernel."""
     from oracle import abx_oracle as O
     B, H, D = (2 if L < 128 else 1), 4, 48
     C = H * D
@@ -438,20 +438,25 @@ def test_tri_attn(ops, L, per_row, exact):
         o = o.transpose(1, 2)
     check(out.view(B, L, L, C), o, 5e-6, f'tri_attn L={L} per_row={per_row}')
     # same through the key-contiguous bias copy the model uses for the ending node
-    b2 = biasT.to(DEV) if per_row else ops.transpose_last2(biasT.to(DEV).view(B * H, L, L), torch.empty(B * H, L, L, device=DEV)).view(B, H, L, L)
+    Lp = (L + 3) // 4 * 4           # key-contiguous bias rows padded to a multiple of 4 floats, as model/forward.py passes them
+    b2 = ops.transpose_last2(biasT.to(DEV).view(B * H, L, L), torch.full((B * H, L, Lp), float('nan'), device=DEV),
+                             transpose=not per_row).view(B, H, L, Lp)
+    assert torch.equal(b2[..., :L].cpu(), biasT if per_row else biasT.transpose(-1, -2)) and bool((b2[..., L:] == 0).all())
     out2 = torch.full((B * L * L, C), float('nan'), device=DEV)
     ops.tri_attn(x.view(B * L * L, 4 * C).to(DEV), b2, mask.float().to(DEV), out2, B, L, per_row, bias_is_qk=True, exact=exact)
     check(out2.view(B, L, L, C), o, 5e-6, f'tri_attn (qk bias) L={L} per_row={per_row}')
 
 
 @pytest.mark.parametrize('exact', [False, True])
-def test_tri_attn_all_keys_masked_row_and_spike(ops, exact):
-    """Fully masked keys give the uniform softmax of finfo.min logits; a spiked key forces the online-softmax rescale."""
+@pytest.mark.parametrize('L,spike', [(80, 70), (200, 190)])
+def test_tri_attn_all_keys_masked_row_and_spike(ops, exact, L, spike):
+    """Fully masked keys give the uniform softmax of finfo.min logits; a spiked key forces the online-softmax rescale (in the 2nd
+    key tile of the first chunk / in the second chunk: the rescale factors cross from the S^T columns to the O rows)."""
     from oracle import abx_oracle as O
-    B, L, H, D = 1, 80, 4, 48
+    B, H, D = 1, 4, 48
     C = H * D
     x = torch.randn(B, L, L, 4 * C, generator=g(33))
-    x[0, 3, 70, C:2 * C] *= 30.0                                # key 70 of row 3 dominates -> max jumps in the 2nd key tile
+    x[0, 3, spike, C:2 * C] *= 30.0                             # this key of row 3 dominates -> the running max jumps late
     P = torch.zeros(B, L, L, H)
     for mask in (torch.zeros(B, L, dtype=torch.bool), torch.ones(B, L, dtype=torch.bool)):
         out = torch.empty(B * L * L, C, device=DEV)
