@@ -13,6 +13,7 @@
 //
 // abx_seq_attn_fwd — sequence attention with 32-head pair bias (seqformer.py:314-356, split_first=False :278-281);
 // 0.8 % of the step, one thread per query with K/V of the (b, h) pair in LDS.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -220,33 +221,69 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 //   K, V of the row are split ONCE, while they are staged, in chunks of 128 keys, DOUBLE BUFFERED: the global loads of chunk
 //   c + 1 are issued before the wave computes on chunk c and are split + written afterwards, ONE barrier per chunk.
 //     K planes [3][key][48 d] bf16 (96-byte rows)  -> A operand of S^T = K Q^T          (lane: key, 8 consecutive d; ds_read_b128)
-//     V planes [3][key][48 d] bf16 (same image)    -> B operand of O  += P V            (lane: d, 8 keys) through the transposing
+//     V planes [3][key][48 d] bf16 (same image)    -> A operand of O^T += V^T P         (lane: d, 8 keys) through the transposing
 //                                                     LDS read ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 d] block
 //                                                     and lane n receives its column n; no transposed staging writes
 //   Q is split per query tile in registers; P per key tile in registers: the S^T accumulators of two 16-key sub-blocks (lane:
 //   query lq, keys 4g + r) are exactly the 8 k-values lane (m = lq, k-group g) feeds to the A operand of one PV MFMA.
-//   O[q][d] accumulators: column = d, rows q = 4g + r; the running (max, sum) live with the S^T columns (lane & 15 = query) and
-//   reach the O rows through 4 lane shuffles when a rescale is needed.
+//   O^T[d][q] accumulators: column = query like the S^T tiles, so the running (max, sum) and the rescale are lane-local; the
+//   four-lane reductions of a query column use v_permlane16/32_swap (VALU), never the LDS queue.
 //   The pair bias is read in rows of bias_sq floats (bias_sk == 1: rows padded to a multiple of 4 -> 16-byte loads for any L).
 //   Grid: 1-D, ordered so that the workgroups resident on one XCD walk the rows of ONE (b, h) pair: its (L, L) bias (495 KB at
 //   L = 352) stays in that XCD's L2 instead of being re-fetched from HBM by every row.
-constexpr int KC4 = 128;                 // keys per chunk
 constexpr int RST = 96;                  // bytes per key row of a plane: 32 * odd -> 16-byte fragment reads of 16 consecutive rows hit 64 banks
-constexpr int PLN = KC4 * RST;           // bytes per plane
-constexpr int BUF4 = 6 * PLN;            // K planes + V planes of one chunk
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// single-instruction max / min (the compiler otherwise canonicalises MFMA results with an extra v_max before fmaxf / fminf)
+__device__ __forceinline__ float vmax(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ float vmin(float x, float y) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+__device__ __forceinline__ float vmax3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+// Reductions over the four lanes {l, l^16, l^32, l^48} (one query column of the swapped S^T tiles) on the VALU path:
+// v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves in a few cycles, where __shfl_xor goes through the LDS
+// queue (ds_bpermute) behind the K / V fragment reads of all 12 waves - four serial LDS round trips per key tile were the
+// largest single cost of this kernel.
+__device__ __forceinline__ float quad_max(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = vmax(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <int MAXQ>
+// KC4: keys per chunk; DB: double-buffered chunks (next chunk's loads ride under this chunk's compute, one barrier per chunk) or
+// a single buffer (load -> split -> write between two barriers at every chunk start, but fewer, larger chunks)
+template <int MAXQ, int KC4, bool DB>
 __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn a) {
+    constexpr int PLN = KC4 * RST;           // bytes per plane
+    constexpr int BUF4 = 6 * PLN;            // K planes + V planes of one chunk
+    constexpr int NIT = (KC4 * (TD / 4) + TRI_THREADS - 1) / TRI_THREADS;     // staging items per thread and chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
-    float* Msb = reinterpret_cast<float*>(lds + 2 * BUF4);       // [2][KC4] key-mask clamps of the two chunks in flight
+    float* Msb = reinterpret_cast<float*>(lds + (DB ? 2 : 1) * BUF4);       // [2][KC4] key-mask clamps of the chunks in flight
     const int L = a.L;
     // ---- (b, h, s) of this workgroup: XCD x (blockIdx & 7) owns the (b, h) pairs x, x + 8, ... and walks their rows in order
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -262,6 +299,12 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
     const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
     const int bias_row = (int)a.bias_sq;                        // readable floats per bias row when bias_sk == 1
     const float qscale = a.scale * LOG2E;
+    // wave-uniform: does this sample mask any key?  (12 waves x 64 lanes cover L <= 768 in one pass of the ballot loop)
+    bool any_masked = false;
+    if (km) {
+        for (int j = lane; j < L; j += 64) any_masked |= km[j] == 0.f;
+        any_masked = __any(any_masked);
+    }
 
     float m_run[MAXQ], l_run[MAXQ];
     f32x4 o[MAXQ][3];
@@ -273,66 +316,75 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
         for (int d = 0; d < 3; ++d) o[sl][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    // staging share of this thread: 2 (key, 4-channel) items of a chunk: 128 keys x 12 float4 = 1536 items over 768 threads
-    f32x4 kreg[2], vreg[2];
-    auto stage_load = [&](int c0) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * TRI_THREADS;
-            const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
-            kreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            vreg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (c0 + kk < L) {
-                const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
-                kreg[it] = *reinterpret_cast<const f32x4*>(a.k + off);
-                vreg[it] = *reinterpret_cast<const f32x4*>(a.v + off);
-            }
+    // staging share of this thread: 2 (key, 4-channel) items of a chunk: 128 keys x 12 float4 = 1536 items over 768 threads.
+    // Item `it` of the NEXT chunk is loaded before and written after the wave's query-tile slot `it` of the current chunk (the
+    // other buffer was last read before the previous barrier), so only one item is live in registers at a time.
+    f32x4 kreg, vreg;
+    auto stage_load = [&](int c0, int it) {
+        const int idx = tid + it * TRI_THREADS;
+        const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
+        kreg = (f32x4){0.f, 0.f, 0.f, 0.f};
+        vreg = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kk < KC4 && c0 + kk < L) {
+            const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
+            kreg = *reinterpret_cast<const f32x4*>(a.k + off);
+            vreg = *reinterpret_cast<const f32x4*>(a.v + off);
         }
     };
-    auto stage_write = [&](int c0, int buf) {
+    auto stage_write = [&](int c0, int buf, int it) {
         char* Kp = lds + buf * BUF4;
         char* Vp = Kp + 3 * PLN;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * TRI_THREADS;
-            const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
-            unsigned a0, a1, a2, b0, b1, b2;
-            split2(kreg[it][0], kreg[it][1], a0, a1, a2);
-            split2(kreg[it][2], kreg[it][3], b0, b1, b2);
-            char* kd = Kp + kk * RST + c4 * 8;
-            *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
-            *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2*>(kd + 2 * PLN) = u32x2{a2, b2};
-            split2(vreg[it][0], vreg[it][1], a0, a1, a2);
-            split2(vreg[it][2], vreg[it][3], b0, b1, b2);
-            char* vd = Vp + kk * RST + c4 * 8;
-            *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
-            *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
-            *reinterpret_cast<u32x2*>(vd + 2 * PLN) = u32x2{a2, b2};
-        }
-        // key-mask clamps, applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit
-        // by finfo.min: every finite logit is >= finfo.min, so min() is that replacement), -inf beyond L
-        if (tid < KC4) Msb[buf * KC4 + tid] = (c0 + tid < L) ? ((!km || km[c0 + tid] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+        const int idx = tid + it * TRI_THREADS;
+        const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
+        if (it == 0 && tid < KC4) Msb[buf * KC4 + tid] = (c0 + tid < L) ? ((!km || km[c0 + tid] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+        if (kk >= KC4) return;
+        unsigned a0, a1, a2, b0, b1, b2;
+        split2(kreg[0], kreg[1], a0, a1, a2);
+        split2(kreg[2], kreg[3], b0, b1, b2);
+        char* kd = Kp + kk * RST + c4 * 8;
+        *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(kd + 2 * PLN) = u32x2{a2, b2};
+        split2(vreg[0], vreg[1], a0, a1, a2);
+        split2(vreg[2], vreg[3], b0, b1, b2);
+        char* vd = Vp + kk * RST + c4 * 8;
+        *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
+        *reinterpret_cast<u32x2*>(vd + 2 * PLN) = u32x2{a2, b2};
     };
+    // (key-mask clamps are applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit by
+    // finfo.min: every finite logit is >= finfo.min, so min() is that replacement), -inf beyond L)
 
-    stage_load(0);
-    stage_write(0, 0);
-    __syncthreads();
+    if (DB) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { stage_load(0, it); stage_write(0, 0, it); }
+        __syncthreads();
+    }
 
     const int nchunk = (L + KC4 - 1) / KC4;
     for (int ch = 0; ch < nchunk; ++ch) {
-        const int c0 = ch * KC4, buf = ch & 1;
+        const int c0 = ch * KC4, buf = DB ? (ch & 1) : 0;
         const int nkeys = min(KC4, L - c0);
         const int nkt = (nkeys + 63) / 64;
-        if (ch + 1 < nchunk) stage_load(c0 + KC4);             // in flight under this chunk's MFMAs
+        const bool more = DB && ch + 1 < nchunk;
+        if (!DB) {
+            __syncthreads();                                    // the previous chunk has been consumed
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) { stage_load(c0, it); stage_write(c0, 0, it); }
+            __syncthreads();
+        }
         const char* Kp = lds + buf * BUF4;
         const char* Vp = Kp + 3 * PLN;
         const float* Ms = Msb + buf * KC4;
+        const bool masked_chunk = any_masked;                   // (per sample: a masked key anywhere -> clamp every tile)
 
 #pragma unroll
         for (int sl = 0; sl < MAXQ; ++sl) {
             const int qt = wave + sl * (TRI_THREADS / 64);
-            if (qt >= nqt) break;
+            // staging item sl of the next chunk rides along with slot sl (slots >= 2 carry none; a wave without a query tile in
+            // this slot still does its share)
+            if (sl < NIT && more) stage_load(c0 + KC4, sl);
+            if (qt < nqt) {
             // ---- Q fragments (B operand of the swapped product), pre-scaled, split: lane holds Q[q][dbase + 8g .. +7]
             const int qrow = qt * 16 + lq;
             const bool qok = qrow < L;
@@ -363,22 +415,23 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
 
             for (int kt = 0; kt < nkt; ++kt) {
                 const int k0 = kt * 64;
-                // ---- bias of this tile (keys k0 + sub*16 + 4g + r), issued first: it becomes the initial value of the S^T accumulators
-                f32x4 sc[4];
+                // ---- bias of this tile (keys k0 + sub*16 + 4g + r): issued first, consumed after the QK^T MFMAs
+                f32x4 bz[4];
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
                     const int kq = k0 + sub * 16 + g * 4;                // first of this lane's 4 keys (chunk-relative)
                     if (bias_vec && c0 + kq + 4 <= bias_row) {
-                        sc[sub] = *reinterpret_cast<const f32x4*>(brow + kq);
+                        bz[sub] = *reinterpret_cast<const f32x4*>(brow + kq);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = min(kq + r, nkeys - 1);
-                            sc[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
+                            bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
                         }
                     }
                 }
-                // ---- S^T tiles: 4 sub-blocks of 16 keys x 2 d-steps x 6 products, accumulated on top of bias * log2(e)
+                f32x4 sc[4];
+                // ---- S^T tiles: 4 sub-blocks of 16 keys x 2 d-steps x 6 products
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
                     const char* kr = Kp + (k0 + sub * 16 + lq) * RST + g * 16;
@@ -389,7 +442,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                         // d 32..47: lane groups 0, 1 read d 32 + 8g; groups 2, 3 re-read a valid address and are multiplied by Q = 0
                         ka[1][p] = *reinterpret_cast<const bf16x8*>(kr + p * PLN + 64 - (g >> 1) * 32);
                     }
-                    f32x4 c = sc[sub] * LOG2E;
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -398,52 +451,59 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                     sc[sub] = c;
                 }
                 // ---- bias, mask, online softmax (base 2) of this lane's query column
-                float mx = -INFINITY;
+                float mx;
+                // logits (base 2) = S^T + bias * log2(e); the key clamps only where the tile has masked / padded keys
+                const bool clamp = masked_chunk || k0 + 64 > nkeys;
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fminf(sc[sub][r], mk[r]);
-                        sc[sub][r] = v;
-                        mx = fmaxf(mx, v);
+                    for (int r = 0; r < 4; ++r) sc[sub][r] = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                }
+                if (clamp) {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[sub][r] = vmin(sc[sub][r], mk[r]);
                     }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float m_new = fmaxf(mr, mx);
+                {   // tree maximum of the lane's 16 logits, then over the 4 lanes of the query column
+                    const float m0 = vmax3(sc[0][0], sc[0][1], sc[0][2]), m1 = vmax3(sc[0][3], sc[1][0], sc[1][1]);
+                    const float m2 = vmax3(sc[1][2], sc[1][3], sc[2][0]), m3 = vmax3(sc[2][1], sc[2][2], sc[2][3]);
+                    const float m4 = vmax3(sc[3][0], sc[3][1], sc[3][2]);
+                    mx = vmax(vmax3(m0, m1, m2), vmax3(m3, m4, sc[3][3]));
+                }
+                mx = quad_max(mx);
+                const float m_new = vmax(mr, mx);
                 const float alpha = __builtin_amdgcn_exp2f(mr - m_new);
-                float rs = 0.f;
+                float rs4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float p = __builtin_amdgcn_exp2f(sc[sub][r] - m_new);
                         sc[sub][r] = p;
-                        rs += p;
+                        rs4[r] += p;
                     }
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
+                const float rs = quad_sum((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
                 lr = lr * alpha + rs;
                 mr = m_new;
-                if (!__all(alpha == 1.0f)) {
-                    // O rows are the queries 4g + r: their rescale factors live in the lanes whose column is that query
+                if (!__all(alpha == 1.0f)) {                        // O^T columns are the queries: lane-local rescale
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float ar = __shfl(alpha, 4 * g + r, 64);
+                    for (int d = 0; d < 3; ++d)
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) oo[d][r] *= ar;
-                    }
+                        for (int r = 0; r < 4; ++r) oo[d][r] *= alpha;
                 }
-                // ---- O += P V: one MFMA step contracts the 32 keys of two sub-blocks; A = P (registers), B = V (transposing reads)
+                // ---- O^T += V^T P: one MFMA step contracts the 32 keys of two sub-blocks; A = V^T (transposing reads of the row-major
+                // V planes: lane d receives 8 keys of its column), B = P (registers)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
+                    bf16x8 pa[3];
                     unsigned p0[4], p1[4], p2[4];
                     split2(sc[2 * m][0], sc[2 * m][1], p0[0], p1[0], p2[0]);
                     split2(sc[2 * m][2], sc[2 * m][3], p0[1], p1[1], p2[1]);
                     split2(sc[2 * m + 1][0], sc[2 * m + 1][1], p0[2], p1[2], p2[2]);
                     split2(sc[2 * m + 1][2], sc[2 * m + 1][3], p0[3], p1[3], p2[3]);
-                    bf16x8 pa[3];
                     pa[0] = __builtin_bit_cast(bf16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
                     pa[1] = __builtin_bit_cast(bf16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
                     pa[2] = __builtin_bit_cast(bf16x8, u32x4{p2[0], p2[1], p2[2], p2[3]});
@@ -460,36 +520,40 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                         }
 #pragma unroll
                         for (int term = 0; term < 6; ++term)
-                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[TA[term]], vb[TB[term]], oo[d], 0, 0, 0);
+                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[TA[term]], pa[TB[term]], oo[d], 0, 0, 0);
                     }
                 }
             }
             m_run[sl] = mr;
             l_run[sl] = lr;
             o[sl][0] = oo[0]; o[sl][1] = oo[1]; o[sl][2] = oo[2];
+            }
+            if (sl < NIT && more) stage_write(c0 + KC4, buf ^ 1, sl);
         }
-        if (ch + 1 < nchunk) stage_write(c0 + KC4, buf ^ 1);   // the other buffer was last read before the previous barrier
-        __syncthreads();
+        if (DB) __syncthreads();
     }
-    // ---- normalise, gate, store.  O layout: column d = dblk*16 + lq, rows = queries 4g + r
+    // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
 #pragma unroll
     for (int sl = 0; sl < MAXQ; ++sl) {
         const int qt = wave + sl * (TRI_THREADS / 64);
-        if (qt >= nqt) continue;
+        const int qrow = qt * 16 + lq;
+        if (qt >= nqt || qrow >= L) continue;
         const float inv = 1.0f / l_run[sl];
+        const long long go = base + (long long)qrow * a.sl;
+        float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ir = __shfl(inv, 4 * g + r, 64);
-            const int qrow = qt * 16 + 4 * g + r;
-            if (qrow >= L) continue;
-            const long long go = base + (long long)qrow * a.sl;
-            float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
+        for (int d = 0; d < 3; ++d) {
+            const int dd = d * 16 + g * 4;
+            f32x4 v = o[sl][d];
+            if (a.gate) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float v = o[sl][d][r] * ir;
-                if (a.gate) v *= 1.0f / (1.0f + expf(-a.gate[go + d * 16 + lq]));
-                op[d * 16 + lq] = v;
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * (1.0f / (1.0f + expf(-gv[r])));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= inv;
             }
+            *reinterpret_cast<f32x4*>(op + dd) = v;
         }
     }
 }
@@ -560,25 +624,23 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
     if (!a.exact) {
-        // split-bf16 kernel: K / V staged in double-buffered 128-key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
-        const size_t lds4 = (size_t)2 * BUF4 + 2 * KC4 * sizeof(float);
+        // split-bf16 kernel: K / V staged in (double-buffered) key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
         const int slots = ((a.L + 15) / 16 + TRI_THREADS / 64 - 1) / (TRI_THREADS / 64);
         ABX_REQUIRE(slots <= 8, "abx_tri_attn_fwd: L too large (L <= 1536)");
-        static thread_local bool configured4 = false;
-        if (!configured4) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn4_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tri_attn4_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-            if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
-            configured4 = true;
-        }
         const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
         ABX_REQUIRE(nbh8 * a.S < (1LL << 31), "abx_tri_attn_fwd: grid too large");
         const dim3 grid((unsigned)(nbh8 * a.S)), block(TRI_THREADS);
-        if (slots <= 2) hipLaunchKernelGGL(tri_attn4_kernel<2>, grid, block, lds4, st, a);
-        else if (slots <= 4) hipLaunchKernelGGL(tri_attn4_kernel<4>, grid, block, lds4, st, a);
-        else hipLaunchKernelGGL(tri_attn4_kernel<8>, grid, block, lds4, st, a);
-        return abx_check_launch("abx_tri_attn_fwd");
+        auto launch = [&](auto kern, size_t lds4) -> int {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+            if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
+            hipLaunchKernelGGL(kern, grid, block, lds4, st, a);
+            return abx_check_launch("abx_tri_attn_fwd");
+        };
+        auto lds_of = [](int kc, bool db) { return (size_t)(db ? 2 : 1) * (6 * kc * RST + kc * sizeof(float)); };
+        // (single-buffered 192- / 256-key chunks and an 8-wave variant with hoisted Q fragments measured the same as this one)
+        if (slots <= 2) return launch(&tri_attn4_kernel<2, 128, true>, lds_of(128, true));
+        if (slots <= 4) return launch(&tri_attn4_kernel<4, 128, true>, lds_of(128, true));
+        return launch(&tri_attn4_kernel<8, 128, true>, lds_of(128, true));
     }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout of the exact kernel (L <= 389)");

@@ -263,7 +263,7 @@ def tri_attn_kernel_name(L, exact=None):
     if GEMM_EXACT if exact is None else exact:
         return 'tri_attn_kernel'
     slots = ((L + 15) // 16 + 11) // 12
-    return f'tri_attn3_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}>'
+    return f'tri_attn4_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}, 128, true>'
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None):
