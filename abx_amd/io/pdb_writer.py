@@ -99,7 +99,9 @@ def _one_record_files(meta, rec, output_dir, multi):
             antigen = {'antigen_str_seq': meta['antigen_origin_str_seq'][i],
                        'antigen_coords': meta['antigen_origin_atom14_gt_positions'][i],
                        'antigen_coord_mask': meta['antigen_origin_atom14_gt_exists'][i],
-                       'antigen_chain_ids': meta['antigen_origin_chain_ids'][i], 'antigen_chains': list(parts[-1])}
+                       'antigen_chain_ids': meta['antigen_origin_chain_ids'][i],
+                       # design.py:152 splits the antigen chain ids on '|' ('6qd7_X_Z_F|E'); inference.py:149 takes the characters
+                       'antigen_chains': parts[-1].split('|') if '|' in parts[-1] else list(parts[-1])}
         path = f'{output_dir}/{name}@{time:.4f}.pdb' if time else f'{output_dir}/{name}.pdb'
         save_pdb(index_to_str_seq(seq[:nh]), parts[1], index_to_str_seq(seq[nh:nh + nl]), parts[2],
                  rec['atom14_results'][i, :nh + nl], path, rec['pLDDT'][i], antigen)

@@ -633,3 +633,27 @@ def test_large_shape_digest_vs_reference(gpu_model, cfg, name):
     _check_call_gpu(ret, g, b['fixed_mask'], 'out.pair_sub', int(g['pair_sub']))
     from abx_amd.model.abx import get_prev
     assert (get_prev(b, ret, cfg.model)['prev_pos'].cpu().numpy() != g['out.prev_pos']).mean() < 1e-4
+
+
+def test_design_driver_on_the_shipped_pdb(tmp_path):
+    """BASELINE configs 1 / 2 / 5 on real coordinates: `design --pdb_file` reads the reference's 6ct7 example
+    (chains H, L + antigen S), samples 3 designs of CDR-H3 and writes PDB files that contain the antibody (designed H3, fixed
+    framework at its input coordinates up to the rigid-frame rebuild) and the antigen chain."""
+    from abx_amd import design
+    from abx_amd.io.pdb_reader import read_pdb, chain_feature
+    from conftest import GOLDEN
+    src = os.path.join(GOLDEN, 'pdb', '6ct7_H_L_S.pdb')
+    out = str(tmp_path / 'd6ct7')
+    files = design.main(['--pdb_file', src, '--num_samples', '3', '--mode', 'design', '--num_t', '3', '--output_dir', out])
+    assert sorted(os.path.basename(f) for f in files) == [f'6ct7-{i:03d}_H_L_S.pdb' for i in range(3)]
+    ref = read_pdb(src)
+    ref_h = chain_feature(ref['H'])['str_seq'][:113]
+    for f in files:
+        ch = read_pdb(f)
+        assert list(ch) == ['H', 'L', 'S']
+        h, l, s = (chain_feature(ch[c]) for c in 'HLS')
+        assert len(h['str_seq']) == 113 and len(l['str_seq']) == 108 and s['str_seq'] == 'MDVFMKGLSK'
+        # only the diffused window (3 residues of CDR-H3 = TSAH) may change
+        diff = [i for i in range(113) if h['str_seq'][i] != ref_h[i]]
+        assert all(98 <= i <= 100 for i in diff), diff
+        assert np.isfinite(h['coords']).all() and float(np.abs(h['coords']).max()) < 500
