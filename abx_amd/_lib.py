@@ -87,6 +87,16 @@ class AbxReverseArgs(C.Structure):
     ]
 
 
+class AbxGuidanceArgs(C.Structure):
+    _fields_ = [
+        ('atom14', c_f), ('atom_mask', c_f), ('aatype', c_f), ('chain_id', c_f),
+        ('radius', c_f), ('frame_trans', c_f),
+        ('overlap_tolerance', F), ('between_chain_factor', F), ('bond_tolerance_factor', F), ('w_clash', F), ('w_bond', F),
+        ('energy', c_f), ('grad_atom', c_f), ('grad_trans', c_f), ('grad_rot', c_f),
+        ('B', I), ('L', I),
+    ]
+
+
 _S = c_f   # hipStream_t
 
 _PROTOS = {
@@ -120,6 +130,8 @@ _PROTOS = {
     'abx_plddt': (I, [c_f, c_f, I, I, _S]),
     'abx_igso3_tables': (I, [c_f, c_f, I, I, I, c_f, c_f, c_f, _S]),
     'abx_reverse_step': (I, [C.POINTER(AbxReverseArgs), _S]),
+    'abx_clash_grad_workspace_bytes': (LL, [I, I]),
+    'abx_clash_grad': (I, [C.POINTER(AbxGuidanceArgs), c_f, _S]),
 }
 
 EXPORTED = tuple(_PROTOS)

@@ -6,6 +6,13 @@ Extensions (all optional, default = reference behaviour):
   batch['_shared_context'] = True   the B samples are copies of ONE complex -> trajectory-invariant embeddings are built once
   ScoreNetwork.max_chunk            samples per launch through the pair stack (workspace size); None = fit 45 % of the free HBM
 
+ESM2 hook (seqformer.py:185-191, encoder.py:72-121).  With `esm.enabled` the per-layer ESM2 representations of
+the CURRENT antibody sequence are an INPUT of every network pass: a (B, Lab, embed_channel, num_layers + 1) tensor taken from
+`ScoreNetwork.esm_provider(batch)` (a callable running ESM2 on the host PyTorch stack, called once per pass because the recycles
+change `seq_t`) or, if no provider is set, from `batch['esm_embed']` (a fixed tensor).  The layer-softmax mix and the
+LayerNorm -> Linear -> ReLU -> Linear projection run here; the ESM2 weights (`impl.seqformer.encode_esm_emb.*` keys of a
+reference checkpoint) are skipped by `load_state_dict`.
+
 Lifetime of what a call returns: `representations` and `_prev_pos` are views of two internal ping-pong buffers (a (B,L,L,192)
 tensor is 9.5 GB at B = 100, L = 352).  A pass never writes the buffer that `batch['prev_pair']` currently points to, so the
 self-conditioning input of the next call is always intact; the representations returned by call n are overwritten during call
@@ -49,10 +56,16 @@ class ScoreNetwork(nn.Module):
         self._auto_chunks = {}
         self.max_chunk = None            # None: as many samples per pair-stack launch as fit in 45 % of the free HBM
         self.clone_outputs = False
+        self.esm_provider = None         # callable(batch) -> (B, Lab, embed_channel, num_layers + 1) when esm.enabled
         self._engine = None
         self._engine_key = None
         self._engine_serial = 0
         self._bufs = {}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """The ESM2 module of a reference checkpoint belongs to the external embedding provider, not to this module."""
+        sd = {k: v for k, v in state_dict.items() if not k.startswith('impl.seqformer.encode_esm_emb.')}
+        return super().load_state_dict(sd, strict=strict, **kw)
 
     # ---- engine / packing ----------------------------------------------------------------------------------------
     def _get_engine(self, device):
@@ -124,6 +137,18 @@ class ScoreNetwork(nn.Module):
             ret = self._pass(eng, batch, final=bool(compute_loss))
         return ret
 
+    def _esm_embed(self, batch):
+        c = self._model_conf.embeddings_and_seqformer
+        if not c.esm.enabled:
+            return None
+        e = self.esm_provider(batch) if self.esm_provider is not None else batch.get('esm_embed')
+        if e is None:
+            raise RuntimeError('esm.enabled: set ScoreNetwork.esm_provider (callable(batch) -> (B, Lab, C, layers) tensor) or '
+                               "batch['esm_embed']; the ESM2 model itself runs outside this module")
+        B, Lab = batch['seq'].shape[0], batch['anchor_flag'].shape[1]
+        assert tuple(e.shape) == (B, Lab, c.esm.embed_channel, c.esm.num_layers + 1), tuple(e.shape)
+        return e.to(device=batch['seq'].device)
+
     def _pass(self, eng, batch, final):
         device = batch['seq'].device
         B, L = batch['seq'].shape[:2]
@@ -148,6 +173,7 @@ class ScoreNetwork(nn.Module):
             fixed_i32=batch['fixed_mask'].to(torch.int32).contiguous(), rigids_t=batch['rigids_t'],
             torsion_gt=batch['torsion_angles_sin_cos'].to(f32), a37to14=batch['residx_atom37_to_atom14'].to(i64),
             prev_seq=batch.get('prev_seq'), prev_pair=batch.get('prev_pair'), prev_pos=batch.get('prev_pos'),
+            esm_embed=self._esm_embed(batch),
             t64=t.to(torch.float64).contiguous(), t_is_f32=t_is_f32,
             rep_seq_out=self._buf('rep_seq' + tag, (B, L, WS_), f32, device),
             rep_pair_out=self._buf('rep_pair' + tag, (B, L, L, WZ), f32, device),

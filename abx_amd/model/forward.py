@@ -250,6 +250,16 @@ class Engine:
                          *P.ln(P_SEQF + 'prev_seq_norm'), seq_act, Bc, L, CS, E)
         ops.assemble_pair(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos,
                           P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E)
+        if st.get('esm_embed') is not None:
+            # seqformer.py:185-191: softmax layer mix of the ESM2 representations (host-side tensor plumbing of the embedding
+            # hook), then LayerNorm -> Linear -> ReLU -> Linear, added to the antibody rows' aa-type embedding
+            e = st['esm_embed'][b0:b1]
+            wl = torch.softmax(P.sd[P_SEQF + 'esm_embed_weights'], dim=-1)
+            mixed = torch.einsum('blcn,n->blc', e.to(wl.dtype), wl).reshape(Bc * Lab, -1).contiguous()
+            h1 = ws.get('esm_h', (Bc * Lab, CS))
+            _ln_lin(P, P_SEQF + 'proj_esm_embed.1', P_SEQF + 'proj_esm_embed.0', None, mixed, h1, act=1)
+            tgt = seq_act[:, :Lab, :CS]                        # (Bc, Lab, 512) window of the (Bc, L, 544) rows
+            _lin(P, P_SEQF + 'proj_esm_embed.3', h1.view(Bc, Lab, CS), tgt, resid=tgt)
         s2 = seq_act.view(M1, WS_)
         z2 = pair_act.view(M2, WZ)
         z3 = pair_act.view(Bc, LL, WZ)

@@ -129,13 +129,17 @@ class Seqformer(_Holder):
 class EmbeddingAndSeqformer(_Holder):
     def __init__(self, c):
         super().__init__()
-        if c.esm.enabled:
-            raise NotImplementedError('ESM2 embedding is out of scope of the MI355X hot path (SURVEY.md §8f item 3)')
         self.proj_aa_type = nn.Embedding(23, c.seq_channel, padding_idx=20)
         self.encode_residue_emb = ResidueEmbedding(c.seq_channel)
         self.encode_pair_emb = PairEmbedding(c.pair_channel, c.prev_pos.num_bins)
         self.aa_proj = _mlp(nn.LayerNorm(c.seq_channel), _lin(c.seq_channel, c.seq_channel), nn.ReLU(),
                             _lin(c.seq_channel, c.seq_channel))
+        if c.esm.enabled:
+            # seqformer.py:143-154.  The ESM2-3B module itself (`encode_esm_emb.model.*`) is NOT instantiated: its per-layer
+            # representations arrive through the embedding hook (ScoreNetwork.esm_provider / batch['esm_embed'])
+            self.esm_embed_weights = nn.Parameter(torch.zeros(c.esm.num_layers + 1))
+            self.proj_esm_embed = _mlp(nn.LayerNorm(c.esm.embed_channel), _lin(c.esm.embed_channel, c.seq_channel), nn.ReLU(),
+                                       _lin(c.seq_channel, c.seq_channel))
         self.proj_rel_pos = nn.Embedding(c.max_relative_feature * 2 + 2, c.pair_channel)
         self.prev_seq_norm = nn.LayerNorm(c.seq_channel + c.index_embed_size)
         self.prev_pair_norm = nn.LayerNorm(c.pair_channel + 2 * c.index_embed_size)

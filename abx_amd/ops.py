@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from abx_amd import _lib
-from abx_amd._lib import AbxGemm, AbxTriAttn, AbxScoreArgs, AbxReverseArgs, check
+from abx_amd._lib import AbxGemm, AbxTriAttn, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, check
 
 
 def _stream():
@@ -434,3 +434,48 @@ def reverse_step(**kw):
     for k, v in kw.items():
         setattr(a, k, _p(v) if torch.is_tensor(v) else v)
     check(_lib.load().abx_reverse_step(C.byref(a), _stream()), 'abx_reverse_step')
+
+
+_VDW = {'C': 1.7, 'N': 1.55, 'O': 1.52, 'S': 1.8}       # abx/common/residue_constants.py:381-386
+_RADIUS = {}
+
+
+def vdw_radius_table(device):
+    """(21, 14) van-der-Waals radius of every atom14 slot by element (0 for empty slots)."""
+    key = str(device)
+    if key not in _RADIUS:
+        from abx_amd import residue_constants as rc
+        t = torch.zeros(21, 14)
+        for i, r in enumerate(rc.restypes):
+            for j, name in enumerate(rc.restype_name_to_atom14_names[rc.restype_1to3[r]]):
+                if name:
+                    t[i, j] = _VDW[name[0]]
+        _RADIUS[key] = t.to(device).contiguous()
+    return _RADIUS[key]
+
+
+def clash_grad(atom14, atom_mask, aatype, chain_id, frame_trans, overlap_tolerance=1.5, between_chain_factor=0.2,
+               bond_tolerance_factor=12.0, w_clash=1.0, w_bond=1.0):
+    """Violation energies and gradients (abx_clash_grad).  atom14 (B,L,14,3) f32, atom_mask (B,L,14), aatype (B,L) int64,
+    chain_id (B,L) int32, frame_trans (B,L,3).  -> energy (B,2) [clash, bond], grad_atom (B,L,14,3), grad_trans, grad_rot (B,L,3)."""
+    lib = _lib.load()
+    B, L = aatype.shape
+    dev = atom14.device
+    a = AbxGuidanceArgs()
+    x = _f32(atom14).contiguous()
+    m = atom_mask.to(torch.uint8).contiguous()
+    aa = aatype.to(torch.int64).contiguous()
+    ch = chain_id.to(torch.int32).contiguous()
+    ft = _f32(frame_trans).contiguous()
+    energy = torch.empty(B, 2, device=dev)
+    g_atom = torch.empty(B, L, 14, 3, device=dev)
+    g_t = torch.empty(B, L, 3, device=dev)
+    g_r = torch.empty(B, L, 3, device=dev)
+    ws = torch.empty(max(int(lib.abx_clash_grad_workspace_bytes(B, L)) // 4, 1), device=dev)
+    a.atom14, a.atom_mask, a.aatype, a.chain_id, a.radius, a.frame_trans = _p(x), _p(m), _p(aa), _p(ch), _p(vdw_radius_table(dev)), _p(ft)
+    a.overlap_tolerance, a.between_chain_factor, a.bond_tolerance_factor = float(overlap_tolerance), float(between_chain_factor), float(bond_tolerance_factor)
+    a.w_clash, a.w_bond = float(w_clash), float(w_bond)
+    a.energy, a.grad_atom, a.grad_trans, a.grad_rot = _p(energy), _p(g_atom), _p(g_t), _p(g_r)
+    a.B, a.L = B, L
+    check(lib.abx_clash_grad(C.byref(a), _p(ws), _stream()), 'abx_clash_grad')
+    return energy, g_atom, g_t, g_r

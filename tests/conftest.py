@@ -90,3 +90,21 @@ def digest_batch(g, name, diffuser, build_features, device=None):
         v = tt(g['in.' + k])
         b[k] = v.to(device) if device is not None else v
     return b, mine
+
+
+def esm_tensor(g, B, Lab):
+    """The seeded stand-in for the ESM2 per-layer representations used by tests/golden/make_golden_esm.py."""
+    gen = torch.Generator().manual_seed(int(g['esm_seed']))
+    return float(g['esm_scale']) * torch.randn(B, Lab, 2560, 37, generator=gen)
+
+
+@pytest.fixture(scope='session')
+def esm_setup():
+    """Config with esm.enabled and the 197-tensor parameter set (190 + layer-mix weights + projection MLP)."""
+    from abx_amd import synthetic
+    from abx_amd.config import default_config
+    cfg = default_config()
+    cfg.model.embeddings_and_seqformer.esm.enabled = True
+    keys = json.load(open(os.path.join(GOLDEN, 'sd_keys_esm.json')))
+    shapes = OrderedDict((k, tuple(s)) for k, s in keys)
+    return cfg, synthetic.random_state_dict(shapes, seed=7)

@@ -824,3 +824,46 @@ def test_reverse_step_device_rng_samples_share_no_noise(ops, cfg):
     one, seq1 = D.reverse(rig[2:3], seq[2:3], zero3[2:3], zero3[2:3].double(), lg[2:3], t[2:3], dt, dm[2:3], sample_ids=ids[2:3],
                           step=5, center=False)
     assert torch.equal(one, full[2:3]) and torch.equal(seq1, seqf[2:3])
+
+
+def test_clash_grad_vs_oracle_autograd(ops):
+    """Row G: abx_clash_grad energies and ANALYTIC gradients against the fp64 torch restatement and its autograd gradient (which
+    is the finite-difference limit), on a compact random two-chain + antigen complex where thousands of atom pairs overlap; the
+    frame pull-back (sum of atom gradients, torque about the frame origin) against the same gradients."""
+    from oracle import abx_oracle as O
+    from abx_amd import residue_constants as rc
+    B, L = 2, 70
+    ge = g(90)
+    aatype = torch.randint(0, 20, (B, L), generator=ge)
+    aatype[0, 11] = 4; aatype[0, 40] = 4            # a cysteine pair (SG-SG excluded)
+    aatype[:, 20] = 14                              # a proline after a peptide bond
+    chain = torch.cat([torch.zeros(30), torch.ones(25), 2 * torch.ones(15)]).int()[None].repeat(B, 1)
+    ca = torch.cumsum(1.6 * torch.randn(B, L, 3, generator=ge), dim=1)            # compact walk: many clashes
+    x = ca[:, :, None] + 1.2 * torch.randn(B, L, 14, 3, generator=ge)
+    mask = torch.as_tensor(rc.restype_atom14_mask)[aatype].clone()
+    mask[1, 5] = False                               # a residue without atoms
+    mask[0, 33, 4:] = False
+    # put C(i) / N(i+1) of consecutive residues near bond length for half of the pairs so that both branches of the flat bottom occur
+    x[:, 1:, 0] = x[:, :-1, 2] + torch.tensor([1.33, 0., 0.]) + 0.25 * torch.randn(B, L - 1, 3, generator=ge) * (torch.rand(B, L - 1, 1, generator=ge) > 0.5)
+    kw = dict(overlap_tolerance=1.5, between_chain_factor=0.2, bond_tolerance_factor=12.0, w_clash=0.7, w_bond=1.3)
+    t0 = x[:, :, 1].clone()
+    e, ga, gt, gr = ops.clash_grad(x.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)
+    xd = x.double().requires_grad_(True)
+    ec, eb = O.violation_energy(xd, mask, aatype, chain, **kw)
+    (ec.sum() + eb.sum()).backward()
+    assert float(ec.min()) > 10 and float(eb.min()) > 0.1, (ec, eb)              # the terms are active
+    check(e[:, 0].cpu(), ec.detach(), 2e-5, 'clash energy')
+    check(e[:, 1].cpu(), eb.detach(), 2e-5, 'bond energy')
+    gref = xd.grad * mask[..., None]
+    check(ga.cpu() * mask[..., None], gref, 5e-5, 'atom gradients')
+    check(gt.cpu(), gref.sum(2), 5e-5, 'frame translation gradient')
+    tq = torch.cross(xd.detach() - t0.double()[:, :, None], gref, dim=-1).sum(2)
+    check(gr.cpu(), tq, 5e-5, 'frame rotation gradient (torque)')
+    # central finite difference of the KERNEL's own energy along a random direction
+    dirn = torch.randn(B, L, 14, 3, generator=ge) * mask[..., None]
+    h = 1e-2
+    ep = ops.clash_grad((x + h * dirn).to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)[0].sum(1).cpu().double()
+    em = ops.clash_grad((x - h * dirn).to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)[0].sum(1).cpu().double()
+    fd = (ep - em) / (2 * h)
+    an = (ga.cpu().double() * dirn.double()).sum((1, 2, 3))
+    assert ((fd - an).abs() <= 2e-2 * an.abs() + 2e-2).all(), (fd, an)

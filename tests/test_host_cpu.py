@@ -27,7 +27,7 @@ def lib():
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(?:int|const char\*)\s+(abx_\w+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(?:int|long long|const char\*)\s+(abx_\w+)\s*\(', src)))
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -54,7 +54,7 @@ def test_argument_checks_return_codes_without_gpu(lib):
 def test_ctypes_structs_match_c_layout():
     from abx_amd import _lib
     structs = {'AbxGemm': _lib.AbxGemm, 'AbxTriAttn': _lib.AbxTriAttn, 'AbxScoreArgs': _lib.AbxScoreArgs,
-               'AbxReverseArgs': _lib.AbxReverseArgs}
+               'AbxReverseArgs': _lib.AbxReverseArgs, 'AbxGuidanceArgs': _lib.AbxGuidanceArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(){']
     for name, st in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')

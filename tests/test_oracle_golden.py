@@ -347,3 +347,31 @@ def test_large_shape_digest(params, cfg, pinned_diffuser, name):
     _check_call(ret, g, b['fixed_mask'], 'out.pair_sub', int(g['pair_sub']))
     prev = O.get_prev(b, ret, cfg)
     assert (prev['prev_pos'].numpy() != g['out.prev_pos']).mean() < 1e-4
+
+
+def test_esm_hook_matches_reference(esm_setup, pinned_diffuser):
+    """ESM2 embedding hook (8f-3): the reference run with esm.enabled and its ESM module replaced by a seeded stand-in tensor;
+    the oracle mixes the 37 layers with softmax(esm_embed_weights) and projects as seqformer.py:185-191."""
+    from conftest import esm_tensor
+    cfg, params = esm_setup
+    g = load_npz('esm_tiny.npz')
+    b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    for k in ('seq_t', 'rigids_t', 't', 'rot_score_scaling', 'trans_score_scaling'):
+        b[k] = tt(g['in.' + k])
+    b['esm_embed'] = esm_tensor(g, b['seq'].shape[0], b['anchor_flag'].shape[1])
+    ret = O.score_network(params, b, cfg, pinned_diffuser)
+    f = ret['heads']['folding']
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'], tt(g['out.seq_0'])) and torch.equal(b['seq_t'], tt(g['final.seq_t_after']))
+    close(ret['representations']['seq'], g['out.seq'], 2e-4, 1e-5, 'trunk seq')
+    close(ret['representations']['pair'], g['out.pair'], 2e-4, 1e-5, 'trunk pair')
+    close(f['rigids'], g['out.rigids'], 2e-4, 1e-5, 'rigids')
+    close(ret['heads']['sequence_module']['logits'], g['out.logits'], 2e-4, 1e-5, 'logits')
+    close(f['final_atom14_positions'], g['out.atom14'], 5e-4, 1e-5, 'atom14')
+    # and the hook matters: without the ESM term the trunk output is different
+    cfg0 = type(cfg)(__import__('copy').deepcopy(dict(cfg)))
+    cfg0.model.embeddings_and_seqformer.esm.enabled = False
+    b2 = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+    for k in ('seq_t', 'rigids_t', 't', 'rot_score_scaling', 'trans_score_scaling'):
+        b2[k] = tt(g['in.' + k])
+    r0 = O.score_network(params, b2, cfg0, pinned_diffuser)
+    assert float((r0['representations']['seq'] - tt(g['out.seq'])).abs().max()) > 1e-2

@@ -89,3 +89,30 @@ def test_writer_output_round_trips_through_the_reader(tmp_path):
     assert np.abs(fx['coords'][m] - b['atom14_gt_positions'][0, :nh].numpy()[m]).max() < 6e-4
     ag = chain_feature(ch['F'])['str_seq'] + chain_feature(ch['E'])['str_seq']
     assert ag == b['antigen_origin_str_seq'][0]
+
+
+def test_ab_metrics_rmsd_and_aar():
+    """calc_ab_metrics (ab_utils.py:124-167): a rigidly moved copy of the 6qd7 antibody has zero RMSD everywhere and AAR 1; a
+    perturbed CDR-H3 with two mutations shows up in heavy_cdr3 only."""
+    from abx_amd.data import antibody as A
+    from abx_amd import metrics
+    b = A.load_complex(PDB['6qd7'], seed=0)
+    Lab = b['anchor_flag'].shape[1]
+    ca = b['atom14_gt_positions'][0, :Lab, 1].numpy().astype(np.float64)
+    cdr = b['cdr_def'][0, :Lab].numpy()
+    seq = b['str_heavy_seq'][0] + b['str_light_seq'][0]
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    moved = ca @ R.T + np.array([5.0, -3.0, 11.0])
+    m = metrics.calc_ab_metrics(ca, moved, cdr, seq, seq)
+    assert list(m)[:4] == ['heavy_cdr1_AAR', 'heavy_cdr1_RMSD', 'heavy_cdr2_AAR', 'heavy_cdr2_RMSD']
+    assert all(abs(v) < 1e-9 for k, v in m.items() if k.endswith('RMSD')) and all(v == 1.0 for k, v in m.items() if k.endswith('AAR'))
+    h3 = np.nonzero(cdr == 5)[0]
+    pert = moved.copy()
+    pert[h3[5]] += np.array([3.0, 0.0, 0.0])
+    mut = list(seq)
+    mut[h3[5]] = 'W' if seq[h3[5]] != 'W' else 'A'
+    mut[h3[0]] = 'W' if seq[h3[0]] != 'W' else 'A'
+    m2 = metrics.calc_ab_metrics(ca, pert, cdr, seq, ''.join(mut))
+    assert m2['heavy_cdr3_AAR'] == pytest.approx(1 - 2 / len(h3)) and m2['heavy_cdr3_Loop_AAR'] == pytest.approx(1 - 1 / (len(h3) - 6))
+    assert 0.5 < m2['heavy_cdr3_RMSD'] < 1.0 and m2['light_cdr3_RMSD'] < 0.1 and m2['heavy_cdr1_AAR'] == 1.0
