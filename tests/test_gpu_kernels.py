@@ -851,7 +851,7 @@ def test_clash_grad_vs_oracle_autograd(ops):
     xd = x.double().requires_grad_(True)
     ec, eb = O.violation_energy(xd, mask, aatype, chain, **kw)
     (ec.sum() + eb.sum()).backward()
-    assert float(ec.min()) > 10 and float(eb.min()) > 0.1, (ec, eb)              # the terms are active
+    assert float(ec.detach().min()) > 10 and float(eb.detach().min()) > 0.1, (ec, eb)              # the terms are active
     check(e[:, 0].cpu(), ec.detach(), 2e-5, 'clash energy')
     check(e[:, 1].cpu(), eb.detach(), 2e-5, 'bond energy')
     gref = xd.grad * mask[..., None]
@@ -859,11 +859,16 @@ def test_clash_grad_vs_oracle_autograd(ops):
     check(gt.cpu(), gref.sum(2), 5e-5, 'frame translation gradient')
     tq = torch.cross(xd.detach() - t0.double()[:, :, None], gref, dim=-1).sum(2)
     check(gr.cpu(), tq, 5e-5, 'frame rotation gradient (torque)')
-    # central finite difference of the KERNEL's own energy along a random direction
+    # central finite difference of the KERNEL's own fp32 energy along a random direction, on a looser geometry (a few hundred
+    # overlapping pairs: with the compact complex above the fp32 rounding of an energy of ~1e5 would swamp the difference)
+    ca2 = torch.cumsum(3.0 * torch.randn(B, L, 3, generator=ge), dim=1)
+    x2 = ca2[:, :, None] + 1.0 * torch.randn(B, L, 14, 3, generator=ge)
+    x2[:, 1:, 0] = x2[:, :-1, 2] + torch.tensor([1.6, 0., 0.])                    # every peptide bond stretched beyond the flat bottom
     dirn = torch.randn(B, L, 14, 3, generator=ge) * mask[..., None]
-    h = 1e-2
-    ep = ops.clash_grad((x + h * dirn).to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)[0].sum(1).cpu().double()
-    em = ops.clash_grad((x - h * dirn).to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)[0].sum(1).cpu().double()
-    fd = (ep - em) / (2 * h)
-    an = (ga.cpu().double() * dirn.double()).sum((1, 2, 3))
-    assert ((fd - an).abs() <= 2e-2 * an.abs() + 2e-2).all(), (fd, an)
+    run = lambda xx: ops.clash_grad(xx.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)
+    e2, ga2 = run(x2)[:2]
+    assert 1.0 < float(e2.sum(1).min()) and float(e2.sum(1).max()) < 5e3, e2
+    h = 5e-3                    # the energy is piecewise linear in the distances: a smaller step crosses fewer hinges
+    fd = (run(x2 + h * dirn)[0].sum(1).cpu().double() - run(x2 - h * dirn)[0].sum(1).cpu().double()) / (2 * h)
+    an = (ga2.cpu().double() * dirn.double()).sum((1, 2, 3))
+    assert ((fd - an).abs() <= 4e-2 * an.abs() + 0.3).all(), (fd, an)
