@@ -80,6 +80,7 @@ class AbxReverseArgs(C.Structure):
         ('diffuse_mask', c_f), ('t', c_f), ('dt', F),
         ('z_rot', c_f), ('z_trans', c_f), ('jumps', c_f),
         ('seed', C.c_ulonglong), ('sample_ids', c_f), ('step', I),
+        ('step_dev', c_f),
         ('exp_max_sigma', F), ('exp_min_sigma', F), ('min_b', F), ('bdiff', F), ('coord_scale', F), ('rate_const', F),
         ('noise_scale', F), ('center', I),
         ('rigid_out', c_f), ('seq_out', c_f), ('rates_out', c_f),

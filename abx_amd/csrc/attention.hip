@@ -630,9 +630,14 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
         ABX_REQUIRE(nbh8 * a.S < (1LL << 31), "abx_tri_attn_fwd: grid too large");
         const dim3 grid((unsigned)(nbh8 * a.S)), block(TRI_THREADS);
+        static thread_local bool configured4[3] = {false, false, false};      // once per instantiation (not inside a graph capture)
         auto launch = [&](auto kern, size_t lds4) -> int {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-            if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
+            bool& done = configured4[slots <= 2 ? 0 : (slots <= 4 ? 1 : 2)];
+            if (!done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
+                done = true;
+            }
             hipLaunchKernelGGL(kern, grid, block, lds4, st, a);
             return abx_check_launch("abx_tri_attn_fwd");
         };

@@ -114,6 +114,7 @@ __device__ __forceinline__ void quat_to_rotvec_ff(const float* qi, float* v) {
 __global__ __launch_bounds__(256) void reverse_step_kernel(const AbxReverseArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sh[];     // [L][3] un-centred x_{t-1} + [3*4] partials
     const int b = blockIdx.x, tid = threadIdx.x, L = a.L;
+    const int step = a.step_dev ? *a.step_dev : a.step;
     double* x1s = sh;
     double* part = sh + (size_t)L * 3;                              // [4 waves][3]
     const double t = a.t[b];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const AbxReverseArgs 
             for (int k = 0; k < 3; ++k) { zr[k] = a.z_rot[i * 3 + k]; zt[k] = a.z_trans[i * 3 + k]; }
         } else {
             const long long sid = a.sample_ids ? a.sample_ids[b] : b;
-            Philox ph(a.seed, (uint32_t)sid, (uint32_t)l, (uint32_t)a.step, 0u);
+            Philox ph(a.seed, (uint32_t)sid, (uint32_t)l, (uint32_t)step, 0u);
             uint32_t r4[4], r4b[4];
             ph.next(r4); ph.next(r4b);
             const float r0 = sqrtf(-2.f * logf(u01(r4[0]))), th0 = 6.28318530717958647692f * u01(r4[1]);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const AbxReverseArgs 
             p[s] = r;
         }
         float overall = 0.f;
-        Philox ph2(a.seed ^ 0x5851F42D4C957F2Dull, (uint32_t)(a.sample_ids ? a.sample_ids[b] : b), (uint32_t)l, (uint32_t)a.step, 1u);
+        Philox ph2(a.seed ^ 0x5851F42D4C957F2Dull, (uint32_t)(a.sample_ids ? a.sample_ids[b] : b), (uint32_t)l, (uint32_t)step, 1u);
 #pragma unroll 1
         for (int s2 = 0; s2 < 20; ++s2) {
             // inner[s2] = sum_s ratio[s] * q_t0[s][s2] = q_diff * sum_s ratio[s] + (q_same - q_diff) * ratio[s2]

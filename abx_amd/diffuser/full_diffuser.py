@@ -169,7 +169,7 @@ class FullDiffuser:
 
     # ---- reverse step -------------------------------------------------------------------------------------------------------
     def reverse(self, rigid_t, seq_t, rot_score, trans_score, logits_t, t, dt, diffuse_mask=None, center=True,
-                noise_scale=1.0, noise=None, sample_ids=None, step=None):
+                noise_scale=1.0, noise=None, sample_ids=None, step=None, step_dev=None):
         dev = rigid_t.device
         self.to(dev)
         B, L = rigid_t.shape[:2]
@@ -199,6 +199,9 @@ class FullDiffuser:
                 kw.update(jumps=noise['jumps'].float().contiguous())
         if sample_ids is not None:
             kw.update(sample_ids=sample_ids.to(torch.int64).contiguous())
+        if step_dev is not None:
+            assert step_dev.dtype == torch.int32 and step_dev.is_cuda
+            kw.update(step_dev=step_dev)
         ops.reverse_step(**kw)
         return out_r, out_s
 

@@ -23,13 +23,15 @@ def set_t_feats(feats, diffuser, t, ones):
 
 
 def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_t=0.01, center=True, self_condition=True,
-              noise_scale=1.0, eps=1e-8, noise_fn=None, sample_ids=None, on_step=None, on_record=None, guidance=None):
+              noise_scale=1.0, eps=1e-8, noise_fn=None, sample_ids=None, on_step=None, on_record=None, guidance=None, use_graph=False):
     """Returns the trajectory: list of dicts {seq (B,Lab) i64, atom14_results (B,Lab,14,3), pLDDT (B,Lab), time,
     rigids_t, seq_t}; only the last element unless mode == 'trajectory'.  All tensors stay on the device.
     on_record(rec): called for every element that enters the trajectory, e.g. `abx_amd.io.TrajectoryWriter.submit` to dump the
     per-step PDB files asynchronously (device->host copy on a side stream, formatting and disk I/O on a worker thread).
     guidance: None (the reference's un-guided sampler, bit-identical code path) or an abx_amd.guidance.ViolationGuidance whose
-    clash / bond gradients on the predicted structure are subtracted from the scores before the reverse step."""
+    clash / bond gradients on the predicted structure are subtracted from the scores before the reverse step.
+    use_graph: record the step into two hipGraphs (abx_amd.graph.GraphedSteps) after one eager step and replay them; needs the
+    device noise generator (noise_fn None) and gives the same results as the eager loop."""
     model_conf = config.model
     sc_conf = model_conf.heads.diffusion_module
     batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_init.items()}
@@ -53,8 +55,16 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
             out = model(batch)
             batch.update(get_prev(batch, out, model_conf))
         dm_f = diffuse_mask.to(torch.float32)
+        graphed = None
+        if use_graph:
+            assert noise_fn is None, 'graph replay uses the device Philox generator (no injected noise)'
+            from abx_amd.graph import GraphedSteps
+            graphed = GraphedSteps(batch, config, diffuser, model, diffuse_mask, dt, sample_ids, center, noise_scale, guidance)
         for k, t in enumerate(steps):
-            if t > min_t:
+            if t > min_t and graphed is not None:
+                out = graphed.run(k, t)
+                rigids_t, seq_t = batch['rigids_t'], batch['seq_t']
+            elif t > min_t:
                 t_ = torch.full((B,), float(t), device=device, dtype=torch.float64)
                 batch = set_t_feats(batch, diffuser, t_, ones)
                 out = model(batch)

@@ -233,7 +233,7 @@ int abx_igso3_tables(const float* sigma, const float* omega, int num_sigma, int 
                      float* score_norms, hipStream_t stream);
 /* One reverse step of all three processes in float64 with injected or device-generated noise, mask merge after all three.
  * rigid_in f32 or f64 (B,L,7); rot_score f32; trans_score f64 (or f32 when ts_is_f32); logits f32 (B,L,20); t (B,) double.
- * Noise: z_rot,z_trans f32 (B,L,3), jumps f32 (B,L,20) when given; otherwise Philox4x32-10 keyed by (seed, sample id, step).
+ * Noise: z_rot,z_trans f32 (B,L,3), jumps f32 (B,L,20) when given; otherwise Philox4x32-10 keyed by (seed, sample id, residue, step).
  * Outputs rigid_out f64 (B,L,7), seq_out int64 (B,L).  Also writes the Poisson rates*dt when rates_out != NULL. */
 typedef struct AbxReverseArgs {
     const void* rigid_in; int rigid_is_f64;
@@ -242,6 +242,8 @@ typedef struct AbxReverseArgs {
     const int* diffuse_mask; const double* t; float dt;
     const float* z_rot; const float* z_trans; const float* jumps;
     unsigned long long seed; const long long* sample_ids; int step;
+    const int* step_dev;                     /* optional DEVICE int: overrides `step` (a hipGraph-captured reverse step reads the
+                                                current step index at replay time instead of a value frozen at capture) */
     float exp_max_sigma, exp_min_sigma, min_b, bdiff, coord_scale, rate_const;
     float noise_scale; int center;
     double* rigid_out; long long* seq_out; float* rates_out;
