@@ -336,6 +336,8 @@ def main():
     ap.add_argument('--no-op-profile', action='store_true')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the additional weak-scaling measurement')
     ap.add_argument('--launcher-selftest', action='store_true', help='CPU/gloo check of the multi-rank launch path, no GPU work')
+    ap.add_argument('--debug-one-gpu', action='store_true', help='debugging on a 1-GPU box: every rank uses cuda:0 and the gloo backend '
+                                                                 '(exercises the whole multi-rank code path; the numbers mean nothing)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -345,7 +347,7 @@ def main():
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    local_rank = 0 if args.debug_one_gpu else int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
@@ -354,7 +356,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.debug_one_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from abx_amd import synthetic, features, sampler, ops, _lib
     from abx_amd.config import default_config
