@@ -38,6 +38,9 @@ class AbxGemm(C.Structure):
         ('glu', I),
         ('a_pair_transpose', I),
         ('pair_L', I), ('pair_Lp', I), ('a_pair', I), ('c_pair', I),
+        ('A2', c_f), ('sA2b', LL), ('sA2m', LL), ('K2', I),
+        ('B2_split', C.c_void_p), ('sB23p', LL), ('sB23n', LL), ('sB23k', LL),
+        ('ln2_csum', c_f), ('bias2', c_f),
         ('exact', I),
         ('tune', I),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),

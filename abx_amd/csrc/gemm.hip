@@ -462,6 +462,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(g.a_pair_transpose <= 0 && g.pair_Lp == 0, "abx_gemm: pair-row remapping is served by the split-bf16 kernels only");
     ABX_REQUIRE(g.batch <= 65535, "abx_gemm: batch > 65535 (exact fp32 kernels)");
     ABX_REQUIRE(!g.glu, "abx_gemm: glu is served by the split-bf16 kernels only (large problems, K % 16 == 0)");
+    ABX_REQUIRE(!g.A2, "abx_gemm: the dual GEMM is served by the split-bf16 kernels only");
     const long long mt128 = ((long long)g.M + 127) / 128;
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);

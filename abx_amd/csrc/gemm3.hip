@@ -73,8 +73,11 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
     }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS>
-__device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
+// Main loop of one output tile: acc += A' B for the operands of `g`; for the inline LayerNorm also the per-row partial sums
+// (ls, lq over this lane's k half, shifted by lshift).  Ends with all DMA drained and a block barrier (the LDS is free again).
+template <int BM, int BN, int WM, int WN, int AMODE>
+__device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, int mt, int nt, int b, f32x16 (&acc)[WM / 32][WN / 32],
+                                               float (&ls)[WM / 32], float (&lq)[WM / 32]) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;                  // bytes per A stage
@@ -158,7 +161,6 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
             if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + offsB[i], dst + i * 1024);
     };
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -168,7 +170,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
 
     const bool relu = g.a_relu != 0;
     const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
-    float ls[TM], lq[TM], lshift[TM];
+    float lshift[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) ls[i] = lq[i] = lshift[i] = 0.f;
 
@@ -267,17 +269,23 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     }
     // drain the (redundant) tail DMA before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
-    // ---- LayerNorm row statistics of this M-panel -> LDS, then the shared epilogue
-    float* st_lds = smem;                                   // [BM][2]
+// LayerNorm row statistics of this M-panel -> st_lds [BM][2] (mean - shift, rstd); returns whether the GEMM is LN-folded
+template <int BM, int BN, int WM, int WN, bool EDGE>
+__device__ __forceinline__ bool gemm3_row_stats(const AbxGemm& g, float* st_lds, int mt, int b, const float (&ls)[WM / 32],
+                                                const float (&lq)[WM / 32]) {
+    constexpr int TM = WM / 32, WAVES_N = BN / WN;
+    const int m0 = mt * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N, h = lane >> 5;
+    const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
     const float* gstats = g.ln_stats ? g.ln_stats + 2 * (long long)b * g.sSb : nullptr;
-    const bool stats = gstats != nullptr || ln_inline;
     if (gstats) {
         for (int idx = threadIdx.x; idx < 2 * BM; idx += 256) {
             const int m = m0 + (idx >> 1);
             st_lds[idx] = (!EDGE || m < g.M) ? gstats[2 * (long long)m + (idx & 1)] : 0.f;
         }
-        __syncthreads();
     } else if (ln_inline) {
         const float invK = 1.0f / (float)g.K;
 #pragma unroll
@@ -290,9 +298,44 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
                 st_lds[2 * row + 1] = 1.0f / sqrtf(fmaxf(sq * invK - dm * dm, 0.f) + g.ln_eps);
             }
         }
-        __syncthreads();
     }
-    gemm_epilogue<BM, BN, WM, WN, EDGE, TS>(g, st_lds, smem + 2 * BM, acc, m0, n0, b, stats);
+    return gstats != nullptr || ln_inline;
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS>
+__device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    f32x16 acc[TM][TN];
+    float ls[TM], lq[TM];
+    gemm3_mainloop<BM, BN, WM, WN, AMODE>(g, smem, mt, nt, b, acc, ls, lq);
+    float* st_lds = smem;                                   // [BM][2]
+    const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
+    __syncthreads();
+    gemm_epilogue<BM, BN, WM, WN, EDGE, TS>(g, st_lds, smem + 2 * BM, acc, mt * BM, nt * BN, b, stats);
+}
+
+// Dual GEMM (the TriangleMultiplication tail, seqformer.py:496-503): out = epi(A' B) * sigmoid(LN(A2) B2 + bias2) (+ resid).
+// Two main loops over the same output tile into two accumulator sets: the channel-major product (AMODE 1) against proj_out, then
+// the rows of z (k-contiguous, inline LayerNorm) against the final-gate weights; the gate never travels through HBM and z is
+// read once for both the gate and the residual.
+template <int BM, int BN, int WM, int WN, bool EDGE>
+__device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    f32x16 acc[TM][TN], acc2[TM][TN];
+    float ls[TM], lq[TM], ls2[TM], lq2[TM];
+    AbxGemm g2 = g;                                          // operand view of the gate GEMM
+    g2.A = g.A2; g2.sAb = g.sA2b; g2.sAm = g.sA2m; g2.sAk = 1; g2.K = g.K2;
+    g2.A_split = nullptr; g2.a_relu = 0; g2.a_pair_transpose = 0; g2.a_pair = g.pair_Lp > 0 ? 1 : 0;
+    g2.B_split = g.B2_split; g2.sB3p = g.sB23p; g2.sB3n = g.sB23n; g2.sB3k = g.sB23k; g2.sB3b = 0;
+    g2.ln_csum = g.ln2_csum; g2.ln_stats = nullptr; g2.batch_inner = 0;
+    if (g.sAk == 1) gemm3_mainloop<BM, BN, WM, WN, 0>(g, smem, mt, nt, b, acc, ls, lq);
+    else gemm3_mainloop<BM, BN, WM, WN, 1>(g, smem, mt, nt, b, acc, ls, lq);
+    gemm3_mainloop<BM, BN, WM, WN, 0>(g2, smem, mt, nt, b, acc2, ls2, lq2);
+    float* st_lds = smem;                                   // [BM][2] + [BM][2]
+    const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
+    gemm3_row_stats<BM, BN, WM, WN, EDGE>(g2, st_lds + 2 * BM, mt, b, ls2, lq2);
+    __syncthreads();
+    gemm_epilogue<BM, BN, WM, WN, EDGE, false>(g, st_lds, smem + 4 * BM, acc, mt * BM, nt * BN, b, stats, &acc2, st_lds + 2 * BM);
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
@@ -323,6 +366,26 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS>(g, smem, mt, nt, b);
     else gemm3_block<BM, BN, WM, WN, AMODE, true, TS>(g, smem, mt, nt, b);
+}
+
+template <int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) {
+    constexpr int A_STAGE = BM * 64, B_STAGE = 3 * BN * 32;
+    constexpr int OPER = (2 * A_STAGE + 2 * B_STAGE) / 4;
+    constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;
+    constexpr int EPI = 4 * BM + 4 * 32 * (TGW * 32 + 4);
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const long long nwg = gridDim.x, bid = blockIdx.x;
+    const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const long long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int per_batch = ntn * ntm;
+    const int b = (int)(wgid / per_batch);
+    const int rem = (int)(wgid - (long long)b * per_batch);
+    const int mt = rem / ntn, nt = rem % ntn;
+    const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
+    if (interior) gemm3_dual_block<BM, BN, WM, WN, false>(g, smem, mt, nt, b);
+    else gemm3_dual_block<BM, BN, WM, WN, true>(g, smem, mt, nt, b);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW>
@@ -385,6 +448,21 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if (((long long)g.M + 127) / 128 * (((long long)g.N + 127) / 128) * g.batch >= (1LL << 31)) return 1;
     if (g.A_split && (long long)(g.K / 16) * g.sA3k >= (1LL << 31)) return 1;
     if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
+    if (g.A2) {
+        // dual GEMM: 128 x 96 tiles (two accumulator sets of 48 registers)
+        if (g.A_split || g.c_transposed || g.glu || !g.B2_split || g.K2 % 16 != 0 || !al16(g.A2) || g.sA2m % 4 != 0 || g.sA2b % 4 != 0 ||
+            !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 || !g.ln2_csum ||
+            (g.pair_Lp > 0 ? (long long)g.pair_L * g.pair_L * g.sA2m : 128LL * g.sA2m) >= (1LL << 30) ||
+            (long long)(g.K2 / 16) * g.sB23k >= (1LL << 31)) {
+            abx_set_error("abx_gemm: dual (A2 / B2_split) operands do not qualify for the split-bf16 dual kernel");
+            *rc = ABX_ERR_ARG;
+            return 0;
+        }
+        const long long mt = ((long long)g.M + 127) / 128, ntn = ((long long)g.N + 95) / 96;
+        hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
+        *rc = abx_check_launch("abx_gemm(dual)");
+        return 0;
+    }
     const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;
     const int force = (g.tune >> 1) & 7;                       // 1: 128x128, 2: 128x192 (benchmarking)
     // (the plane x plane contraction at L = 352 pads to 384 either way: the wide tile measured 10 % faster)

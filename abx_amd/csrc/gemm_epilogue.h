@@ -8,7 +8,8 @@
 
 template <int BM, int BN, int WM, int WN, bool EDGE, bool TS>
 __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __restrict__ st_lds, float* __restrict__ scratch,
-                                              f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats) {
+                                              f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats,
+                                              f32x16 (*acc2)[WM / 32][WN / 32] = nullptr, const float* __restrict__ st2_lds = nullptr) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -18,13 +19,15 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
     const float* gt = g.gate ? g.gate + (long long)b * g.sGb : nullptr;
     const float* rd = g.resid ? g.resid + (long long)b * g.sRb : nullptr;
     const bool c_vec = g.c_vec_ok != 0, g_vec = g.g_vec_ok != 0, r_vec = g.r_vec_ok != 0, gsig = g.gate_sigmoid != 0;
-    float bias[TN], csum[TN];
+    float bias[TN], csum[TN], bias2[TN], csum2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + (lane & 31);
         const bool nok = !EDGE || n < g.N;
         bias[j] = (g.bias && nok) ? g.bias[n] : 0.f;
         csum[j] = (stats && nok) ? g.ln_csum[n] : 0.f;
+        bias2[j] = (acc2 && g.bias2 && nok) ? g.bias2[n] : 0.f;
+        csum2[j] = (acc2 && nok) ? g.ln2_csum[n] : 0.f;
     }
     // per-element part that needs no global operand: folded LayerNorm, bias, alpha, activation
     auto epi1 = [&](float v, int ml, int j) -> float {
@@ -107,8 +110,14 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                         const int mloc = 8 * rq + 4 * (lane >> 5) + c;
                         const int ml = wm * WM + i * 32 + mloc;
 #pragma unroll
-                        for (int j = 0; j < TG; ++j)
-                            wsc[mloc * LW + j * 32 + (lane & 31)] = epi1(acc[i][jg + j][rq * 4 + c], ml, jg + j);
+                        for (int j = 0; j < TG; ++j) {
+                            float v = epi1(acc[i][jg + j][rq * 4 + c], ml, jg + j);
+                            if (acc2) {      // dual GEMM: times sigmoid(LN-folded gate accumulator + bias2)
+                                const float gv = st2_lds[2 * ml + 1] * ((*acc2)[i][jg + j][rq * 4 + c] - st2_lds[2 * ml] * csum2[jg + j]) + bias2[jg + j];
+                                v *= 1.0f / (1.0f + expf(-gv));
+                            }
+                            wsc[mloc * LW + j * 32 + (lane & 31)] = v;
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -309,8 +309,12 @@ class Engine:
             # sigmoid(left_gate | right_gate) channel-major like the projections they gate; sigmoid(final_gate) row-major
             GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
             Gf = w768.view(-1)[Bc * 256 * LL:Bc * 448 * LL].view(Bc, LL, 192)
-            _ln_lin(P, pre + 'final_gate', pre + 'norm', None, z3, Gf, act=2)
             if planes:
+                # The dual output GEMM reads z (gate operand + residual) for ALL 192 input channels while other tiles of the same
+                # rows write their output columns, so it must not run in place: the outgoing variant writes into the free
+                # 768-wide workspace, the incoming one reads that and writes the pair tensor again.
+                zb = w768.view(-1)[:Bc * LL * 192].view(Bc, LL, 192)
+                zin, zout = (z3, zb) if outgoing else (zb, z3)
                 # one GEMM: [left | right] projections * sigmoid(their gates) * pair mask -> plane operands of the contraction
                 KT = (Lp + 15) // 16
                 lrp = ws.get('tm_lr', (Bc, 256, KT, 3, L, 16), torch.int16, zero=(Lp % 16 != 0))
@@ -319,14 +323,18 @@ class Engine:
                 else:
                     pm = ws.get('pmask_p', (Bc * LLp,))
                     ops.pair_mask(mask_f, pm, Bc, L, Lp)
-                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, z3, lrp, rowscale=pm, glu=True,
+                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, zin, lrp, rowscale=pm, glu=True,
                         a_pair_transpose=0 if outgoing else L, pair=pad, a_pair=pad is not None)
                 tt = w384[:Bc * 128 * LLp].view(Bc, 128, LLp)      # channel-major product, padded pair rows (pads: never stored)
                 tz = tt.as_strided((Bc * 128, L, L), (LLp, Lp, 1))
                 ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz, exact=2)
-                _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tt.transpose(1, 2), z3, gate=Gf, gate_sigmoid=False,
-                        resid=z3, pair=pad, c_pair=pad is not None)
+                # output projection and final gate in ONE dual GEMM: proj_out(final_norm(product)) * sigmoid(final_gate(norm(z))) + z;
+                # the gate never exists in HBM and z is read once for the gate and the residual
+                gw, gcs, gb, gw3 = P.ln_linear(pre + 'final_gate', pre + 'norm')
+                _ln_lin(P, pre + 'proj_out', pre + 'final_norm', None, tt.transpose(1, 2), zout, resid=zin, pair=pad, c_pair=pad is not None,
+                        dual=(zin, gw3, gcs, gb))
             else:
+                _ln_lin(P, pre + 'final_gate', pre + 'norm', None, z3, Gf, act=2)
                 tt = w384[2 * Bc * 128 * LL:3 * Bc * 128 * LL].view(Bc, 128, LL)
                 tz = tt.view(Bc * 128, L, L)
                 _ln_lin(P, pre + 'lr_gates', pre + 'norm', None, z3, GT.transpose(1, 2), act=2)

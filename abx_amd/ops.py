@@ -99,7 +99,7 @@ def split_weights(Wt):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -110,7 +110,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     contraction (transposed store).  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i.
     glu=True: B holds (value, gate) column pairs (pack_glu_weights); Cout has N/2 channels = value * sigmoid(gate).
     pair=(L, Lp): the M rows are padded pair positions i*Lp + j (Lp % 4 == 0, any L); a_pair: A is the UNpadded (b, L*L, K) pair
-    tensor; c_pair: Cout / gate / resid are UNpadded (b, L*L, N) pair tensors (pad rows dropped).  rowscale is indexed by GEMM row."""
+    tensor; c_pair: Cout / gate / resid are UNpadded (b, L*L, N) pair tensors (pad rows dropped).  rowscale is indexed by GEMM row.
+    dual=(A2, B3_2, csum2, bias2): Cout = epi(A' B) * sigmoid(LN(A2) @ W2 + bias2) (+ resid): A2 (b, rows, K2) k-contiguous fp32 (the
+    UNpadded pair tensor when pair is given), B3_2 = split_weights of the gamma-scaled gate weights (K2, N), csum2 their column sums."""
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
@@ -191,6 +193,19 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         assert B3.dtype == torch.int16 and B3.is_contiguous() and B3.shape[1:] == (3, N, 16) and B3.shape[0] * 16 >= K
         g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
     g.tune = GEMM_TUNE if tune is None else tune
+    if dual is not None:
+        A2, B32, csum2, bias2 = dual
+        if A2.dim() == 2:
+            A2 = A2.unsqueeze(0)
+        _f32(A2)
+        assert A2.stride(2) == 1 and A2.shape[0] == nb and A2.shape[1] == (pair[0] * pair[0] if pair is not None else M)
+        K2 = A2.shape[2]
+        assert B32.dtype == torch.int16 and B32.is_contiguous() and B32.shape[1:] == (3, N, 16) and B32.shape[0] * 16 == K2 and csum2.numel() == N
+        g.A2, g.sA2b, g.sA2m, g.K2 = _p(A2), (A2.stride(0) if nb > 1 else 0), A2.stride(1), K2
+        g.B2_split, g.sB23k, g.sB23p, g.sB23n = _p(B32), B32.stride(0), B32.stride(1), B32.stride(2)
+        g.ln2_csum, g.bias2 = _p(_f32(csum2)), _p(bias2)
+        if g.ln_eps == 0:
+            g.ln_eps = 1e-5
     g.bias = _p(bias)
     g.alpha = float(alpha)
     g.act = int(act)

@@ -87,6 +87,12 @@ typedef struct AbxGemm {
                                                       a_pair_transpose != 0 (k-contiguous fp32 A) */
     int c_pair;                                    /* C / gate / resid rows live in the UNpadded pair tensor: GEMM row (i,j) is
                                                       stored at row i*pair_L + j, rows with j >= pair_L are dropped (plain store) */
+    /* Dual GEMM (split-bf16 path, plain store): out = epi(A' B) * sigmoid(LN(A2) B2 + bias2) (+ resid) - the tail of the
+     * TriangleMultiplication (seqformer.py:496-503: proj_out(final_norm(x)) * sigmoid(final_gate(norm(z)))) in one kernel.
+     * A2: k-contiguous fp32 rows (K2 % 16 == 0), statistics inline; with pair_Lp > 0 its rows live in the UNpadded pair tensor. */
+    const float* A2; long long sA2b, sA2m; int K2;
+    const unsigned short* B2_split; long long sB23p, sB23n, sB23k;   /* gate weights as k-tiled planes (abx_split_weights) */
+    const float* ln2_csum; const float* bias2;     /* [N] column sums of the gamma-scaled gate weights, folded bias */
     int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split
                                                       into 3 bf16 pieces, 6 products, fp32 accumulate - csrc/gemm3.hip);
                                                       1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32);

@@ -872,3 +872,31 @@ def test_clash_grad_vs_oracle_autograd(ops):
     fd = (run(x2 + h * dirn)[0].sum(1).cpu().double() - run(x2 - h * dirn)[0].sum(1).cpu().double()) / (2 * h)
     an = (ga2.cpu().double() * dirn.double()).sum((1, 2, 3))
     assert ((fd - an).abs() <= 4e-2 * an.abs() + 0.3).all(), (fd, an)
+
+
+@pytest.mark.parametrize('L', [64, 70])
+def test_gemm_dual_proj_out_times_gate(ops, L):
+    """The tail of the TriangleMultiplication as one dual GEMM: LN(product, channel-major) @ Wo * sigmoid(LN(z) @ Wg + bg) + z,
+    with padded pair rows when L % 4 != 0 (A2 / C / resid in the unpadded pair tensor), against fp64."""
+    Bc = 3
+    LL, Lp = L * L, (L + 3) // 4 * 4
+    ge = g(120)
+    z = torch.randn(Bc, LL, 192, generator=ge) * 2 + 0.5
+    tt_full = torch.randn(Bc, 128, L, Lp, generator=ge)                  # channel-major product with padded rows
+    Wo, bo = torch.randn(128, 192, generator=ge) / 11, torch.randn(192, generator=ge) * 0.1
+    Wg, bg = torch.randn(192, 192, generator=ge) / 14, torch.randn(192, generator=ge) * 0.1
+    g1, b1 = 1 + 0.1 * torch.randn(128, generator=ge), 0.1 * torch.randn(128, generator=ge)
+    g2, b2 = 1 + 0.1 * torch.randn(192, generator=ge), 0.1 * torch.randn(192, generator=ge)
+    wo, cso, bio = fold_ln(Wo.t().contiguous(), bo, g1, b1)
+    wg, csg, big = fold_ln(Wg.t().contiguous(), bg, g2, b2)
+    zd = z.clone().to(DEV)
+    out = torch.full_like(zd, float('nan'))         # out of place: other column tiles still read the rows of z for their gate
+    tt = tt_full.reshape(Bc, 128, L * Lp).to(DEV)
+    pad = (L, Lp) if Lp != L else None
+    ops.gemm(tt.transpose(1, 2), wo, out, bias=bio, ln=(None, cso), B3=ops.split_weights(wo), resid=zd,
+             pair=pad, c_pair=pad is not None, dual=(zd, ops.split_weights(wg), csg, big), exact=2)
+    zd = out
+    x = tt_full[..., :L].permute(0, 2, 3, 1).reshape(Bc, LL, 128).double()
+    ln = lambda v, ga, be: (v - v.mean(-1, keepdim=True)) / torch.sqrt(v.var(-1, unbiased=False, keepdim=True) + 1e-5) * ga.double() + be.double()
+    ref = (ln(x, g1, b1) @ Wo.double() + bo.double()) * torch.sigmoid(ln(z.double(), g2, b2) @ Wg.double() + bg.double()) + z.double()
+    check(zd, ref, 3e-6, f'dual gemm L={L}')
