@@ -458,6 +458,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
             *rc = ABX_ERR_ARG;
             return 0;
         }
+        // (128 x 192 tiles - A read and split once per row - need 2 x 96 accumulator registers and spill at 256 VGPRs)
         const long long mt = ((long long)g.M + 127) / 128, ntn = ((long long)g.N + 95) / 96;
         hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(dual)");

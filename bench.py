@@ -87,8 +87,9 @@ class OpTimer:
             N = B.shape[-1]
             c_planes = C.dtype == torch.int16
             kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
-                                             split=kw.get('B3') is not None, exact=kw.get('exact'))
-            return kern, 2.0 * nb * M * N * K, 4.0 * nb * (M * K) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * K * N
+                                             split=kw.get('B3') is not None, exact=kw.get('exact'), dual=kw.get('dual') is not None)
+            K2 = kw['dual'][0].shape[-1] if kw.get('dual') is not None else 0
+            return kern, 2.0 * nb * M * N * (K + K2), 4.0 * nb * (M * (K + K2)) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * (K + K2) * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
             return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
