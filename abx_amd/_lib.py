@@ -115,7 +115,9 @@ _PROTOS = {
     'abx_tri_attn_fwd': (I, [C.POINTER(AbxTriAttn), _S]),
     'abx_seq_attn_fwd': (I, [c_f, c_f, c_f, c_f, c_f, I, I, I, I, F, _S]),
     'abx_ipa_pack': (I, [c_f, c_f, c_f, c_f, c_f, c_f, I, I, F, _S]),
-    'abx_ipa_attn': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
+    'abx_ipa_attn': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
+    'abx_ipa_attn_workspace_bytes': (C.c_longlong, [I, I]),
+    'abx_ipa_qpack_bytes': (C.c_longlong, [I, I]),
     'abx_timestep_embedding': (I, [c_f, c_f, I, I, c_f, _S]),
     'abx_assemble_seq': (I, [c_f, LL, c_f, c_f, I, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),

@@ -3,19 +3,20 @@
 //
 //  abx_ipa_pack : one thread per (residue, head): local points -> global frame (r3.rigids_apply, r3.py:9-16) and repack
 //                 the fused projection row into per-head contiguous records so the attention kernel reads them coalesced:
-//                    Q[b][i][h][28] = [ q_scalar*w_s (16) | q_point_global (4x3) ]
+//                    Q[b][i/12][h][(i%12)/2][28][i%2] = [ q_scalar*w_s (16) | q_point_global (4x3) ]  (query pairs interleaved:
+//                                     the weights kernel reads them as wave-uniform float2 for packed FMAs; rows padded to 12)
 //                    K[b][h][j][28] = [ k_scalar (16)     | k_point_global (4x3) ]
 //                    V[b][h][j][40] = [ v_scalar (16)     | v_point_global (8x3) ]
-//  abx_ipa_attn : one workgroup per (b, group of IQ=4 query residues).
-//     phase A  logits[iq][h][j] = q.k + pw[h] * sum|q_pt - k_pt|^2 + bias2d[b,i,j,h]  (direct (q-k)^2 as the reference,
-//              not the expanded form: no cancellation at |x| ~ 10), mask fill finfo.min, into LDS laid out [iq][j][13]
-//     softmax  one wave per (iq, h) row: shuffle max / sum
-//     phase B1 scalar + point outputs: thread per (h, 4 channels of the 40) x 4 key groups, 16-byte loads, LDS reduce
-//     phase B2 attention over the pair slab: lane -> 4 channels (16-byte loads, 512 B coalesced per j), 16 key groups with
-//              >= 4 loads in flight each, 12 heads x 4 channels of accumulators, fixed-order reduction (shuffle + LDS):
-//              streams z[b,i,j,0:128] exactly once per query residue -> HBM-bound (33.6 MB / sample / layer at L=256)
-//     tail     points back to the local frame (r3.invert_rigids, r3.py:54-59), norms sqrt(sum^2 + 1e-8), concat
-//              [scalar 192 | points '(r n)' 288 | norms 96 | pair 1536] = 2112 floats per residue.
+//  abx_ipa_attn : two kernels.
+//     ipa_weights_kernel  one workgroup per (b, 4 query residues), two per CU: logits (direct (q-k)^2 point distances as the
+//              reference, not the expanded form: no cancellation at |x| ~ 10) + pair bias, mask fill finfo.min, LDS-resident
+//              [iq][h][j]; wave-shuffle softmax; the normalised weights go to HBM as attn[b][i][j][12]; scalar + point outputs
+//              (16-byte loads of V, shuffle-folded key groups); points back to the local frame (r3.invert_rigids,
+//              r3.py:54-59), norms sqrt(sum^2 + 1e-8)
+//     ipa_pair_kernel     attention over the pair slab, ONE WAVE per (b, i) row: streams z[b,i,j,0:128] exactly once (512 B
+//              per key, 16 keys in flight per wave, weights through the scalar cache), 24 accumulators per lane, no LDS /
+//              barrier / reduction -> the HBM-bound part (6.3 GB per layer at B = 100, L = 352; + 0.6 GB weights)
+//     feature row [scalar 192 | points '(r n)' 288 | norms 96 | pair 1536] = 2112 floats per residue.
 #include "common.h"
 #include "abx_hip.h"
 
@@ -29,30 +30,40 @@ constexpr int OFF_KV = H * SQK;              // 192
 constexpr int OFF_QP = OFF_KV + H * (SQK + SV);      // 576
 constexpr int OFF_KVP = OFF_QP + 3 * H * PQK;        // 720
 constexpr int NFEAT = H * SV + 3 * H * PV + H * PV + H * CZ;   // 2112
-constexpr int IQ = 4;
-constexpr int LDH = 13;                      // logits row stride over heads: odd -> lane<->j accesses are conflict-free
+
+constexpr int IPA_THREADS = 512;
+constexpr int IQ = 12;                           // query residues per workgroup of the weights kernel
+constexpr int HG = 4, NHG = H / HG;              // heads per workgroup, head groups
 
 __global__ __launch_bounds__(256) void ipa_pack_kernel(const float* __restrict__ proj, const float* __restrict__ rots,
                                                        const float* __restrict__ trans, float* __restrict__ qpack,
                                                        float* __restrict__ kpack, float* __restrict__ vpack, int B, int L,
                                                        float w_s) {
+    const int NIB = (L + IQ - 1) / IQ, LQ = NIB * IQ;           // query rows are padded to whole blocks of IQ
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)B * L * H) return;
+    if (idx >= (long long)B * LQ * H) return;
     const int h = (int)(idx % H);
-    const long long row = idx / H;              // b*L + l
-    const int b = (int)(row / L), l = (int)(row % L);
+    const long long prow = idx / H;             // b*LQ + l
+    const int b = (int)(prow / LQ), l = (int)(prow % LQ);
+    // Q record of (b, l, h): element c of query l sits at [b][l / IQ][h][(l % IQ) / 2][c][l % 2]
+    float* q = qpack + ((((long long)b * NIB + l / IQ) * H + h) * (IQ / 2) + (l % IQ) / 2) * (QREC * 2) + (l & 1);
+    if (l >= L) {                               // pad rows of the last block: zeros (their logits are never used)
+#pragma unroll
+        for (int c = 0; c < QREC; ++c) q[2 * c] = 0.f;
+        return;
+    }
+    const long long row = (long long)b * L + l;
     const float* p = proj + row * NPROJ;
     float R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = rots[row * 9 + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = trans[row * 3 + i];
-    float* q = qpack + (row * H + h) * QREC;
     float* k = kpack + (((long long)b * H + h) * L + l) * QREC;
     float* v = vpack + (((long long)b * H + h) * L + l) * VREC;
 #pragma unroll
     for (int c = 0; c < SQK; ++c) {
-        q[c] = p[h * SQK + c] * w_s;
+        q[2 * c] = p[h * SQK + c] * w_s;
         k[c] = p[OFF_KV + h * (SQK + SV) + c];
         v[c] = p[OFF_KV + h * (SQK + SV) + SQK + c];
     }
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(256) void ipa_pack_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 3; ++r) x[r] = p[OFF_QP + r * (H * PQK) + h * PQK + pt];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) q[SQK + pt * 3 + r] = t[r] + (R[r * 3 + 0] * x[0] + R[r * 3 + 1] * x[1] + R[r * 3 + 2] * x[2]);
+        for (int r = 0; r < 3; ++r) q[2 * (SQK + pt * 3 + r)] = t[r] + (R[r * 3 + 0] * x[0] + R[r * 3 + 1] * x[1] + R[r * 3 + 2] * x[2]);
     }
 #pragma unroll
     for (int pt = 0; pt < PQK + PV; ++pt) {
@@ -82,204 +93,187 @@ __global__ __launch_bounds__(256) void ipa_pack_kernel(const float* __restrict__
     }
 }
 
-constexpr int IPA_THREADS = 512;                 // 8 waves: enough loads in flight to stream the pair slab
-constexpr int NJG2 = IPA_THREADS / 32;           // j-groups of phase B2 (32 lanes x float4 = 128 channels)
-constexpr int NJG1 = 4;                          // j-groups of phase B1 (120 (h, c4) items x 4)
+// LDS row stride of the logits [IQ * HG][LR]: a multiple of 32 plus 12, so the B1 reads of one wave (2 heads x 12 keys) fall
+// into distinct banks
+__host__ __device__ inline int ipa_row_stride(int L) { return ((L + 31) / 32) * 32 + 12; }
 
-__global__ __launch_bounds__(IPA_THREADS) void ipa_attn_kernel(const float* __restrict__ qpack, const float* __restrict__ kpack,
-                                                               const float* __restrict__ vpack, const float* __restrict__ bias2d,
-                                                               const float* __restrict__ z, const float* __restrict__ mask,
-                                                               const float* __restrict__ rots, const float* __restrict__ trans,
-                                                               const float* __restrict__ pw, float* __restrict__ feat, int B, int L) {
+// ---- kernel 1: attention weights + scalar / point outputs ----------------------------------------------------------------
+// One workgroup per (b, IQ = 12 query residues, group of 4 heads); two workgroups per CU (78 KB of LDS each at L = 352) so that
+// the load-latency-bound phases of one overlap the arithmetic of the other.  12 queries share every K / V record fetched.
+//   phase A  wave per (64 keys, head): q.k + pw[h] * sum|q_pt - k_pt|^2 for the 12 queries -> LDS [iq][h][j]
+//   bias     thread per (iq, j): + bias2d[b,i,j, 4 heads] (one 16-byte load), mask fill finfo.min
+//   softmax  one wave per query (its 4 head rows together), shuffle max / sum; the normalised weights go to LDS and to
+//            attn[b][i][head group][j][4] (16 contiguous bytes per lane): the slab kernel streams them
+//   phase B1 scalar + point outputs: lane = (h, 4 of the 40 channels) x 12 key groups inside ONE wave, 16-byte loads of V
+//            (software-pipelined, first round requested before the softmax), key groups folded with shuffles (fixed order)
+//   tail     points back to the local frame (r3.invert_rigids, r3.py:54-59), norms sqrt(sum^2 + 1e-8)
+__global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float* __restrict__ qpack, const float* __restrict__ kpack,
+                                                                     const float* __restrict__ vpack, const float* __restrict__ bias2d,
+                                                                     const float* __restrict__ mask, const float* __restrict__ rots,
+                                                                     const float* __restrict__ trans, const float* __restrict__ pw,
+                                                                     float* __restrict__ attn, float* __restrict__ feat, int B, int L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* lg = smem;                                           // [IQ][L][LDH] logits -> attention weights
-    float* qs = smem + (((size_t)IQ * L * LDH + 3) & ~(size_t)3);   // [IQ][H][QREC]
-    float* opt = qs + IQ * H * QREC;                            // [IQ][H][VREC] scalar+point outputs (global frame)
-    float* red = opt + IQ * H * VREC;                           // [8 waves][H][CZ] partial sums (16-byte aligned)
+    const int LR = ipa_row_stride(L);
+    float* lg = smem;                                           // [IQ * HG][LR] logits -> attention weights
+    float* opt = smem + (size_t)IQ * HG * LR;                   // [IQ][HG][VREC] scalar + point outputs (global frame)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
-    const int i0 = blockIdx.x * IQ;
+    const int hg = blockIdx.x % NHG, h0 = hg * HG;
+    const int iblk = blockIdx.x / NHG, NIB = gridDim.x / NHG;
+    const int i0 = iblk * IQ;
     const int niq = min(IQ, L - i0);
 
-    for (int idx = tid; idx < IQ * H * QREC; idx += IPA_THREADS) {
-        const int iq = idx / (H * QREC);
-        qs[idx] = iq < niq ? qpack[((long long)b * L + i0) * H * QREC + idx] : 0.f;
-    }
-    __syncthreads();
-
-    // ---- phase A: logits -------------------------------------------------------------------------------------
-    // K records of HB heads are fetched together (HB*7 16-byte loads in flight per lane) before any arithmetic
-    constexpr int HB = 3;
-    for (int j = tid; j < L; j += IPA_THREADS) {
-        const float mj = mask[(long long)b * L + j];
-        float mi[IQ];
+    // ---- phase A: scalar + point logits.  A wave takes 64 keys of ONE head per task; the Q records of the block are
+    // wave-uniform and come through the scalar cache as (query pair, channel) float2, so every product is one packed FMA
+    // over two queries with the key channel broadcast: no LDS traffic, 22 VALU instructions per (key, head, query pair)
+    {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float* __restrict__ qb = qpack + (((long long)b * NIB + iblk) * H + h0) * (IQ / 2) * (QREC * 2);
+        const int wpk = (L + 63) >> 6;
+        for (int task = wave; task < HG * wpk; task += IPA_THREADS / 64) {
+            const int hl = __builtin_amdgcn_readfirstlane(task / wpk);
+            const int j = (task - hl * wpk) * 64 + lane;
+            const float* kr = kpack + (((long long)b * H + h0 + hl) * L + min(j, L - 1)) * QREC;
+            f32x4 kq[QREC / 4];
 #pragma unroll
-        for (int iq = 0; iq < IQ; ++iq) mi[iq] = iq < niq ? mask[(long long)b * L + i0 + iq] : 0.f;
-#pragma unroll 1
-        for (int h0 = 0; h0 < H; h0 += HB) {
-            f32x4 kq[HB][QREC / 4];
-            float bz[HB][IQ];
+            for (int c4 = 0; c4 < QREC / 4; ++c4) kq[c4] = *reinterpret_cast<const f32x4*>(kr + c4 * 4);
+            const float pwh = pw[h0 + hl];
+            const f32x2* __restrict__ qh = reinterpret_cast<const f32x2*>(qb + (long long)hl * (IQ / 2) * (QREC * 2));
 #pragma unroll
-            for (int hh = 0; hh < HB; ++hh) {
-                const float* kr = kpack + (((long long)b * H + h0 + hh) * L + j) * QREC;
+            for (int ip = 0; ip < IQ / 2; ++ip) {
+                f32x2 sacc = {0.f, 0.f}, d2 = {0.f, 0.f};
 #pragma unroll
-                for (int c4 = 0; c4 < QREC / 4; ++c4) kq[hh][c4] = *reinterpret_cast<const f32x4*>(kr + c4 * 4);
+                for (int c = 0; c < SQK; ++c) {
+                    const float kc = kq[c >> 2][c & 3];
+                    sacc = __builtin_elementwise_fma(qh[ip * QREC + c], (f32x2){kc, kc}, sacc);
+                }
 #pragma unroll
-                for (int iq = 0; iq < IQ; ++iq)
-                    bz[hh][iq] = iq < niq ? bias2d[(((long long)b * L + i0 + iq) * L + j) * H + h0 + hh] : 0.f;
-            }
-#pragma unroll
-            for (int hh = 0; hh < HB; ++hh) {
-                const int h = h0 + hh;
-                const float pwh = pw[h];
-#pragma unroll
-                for (int iq = 0; iq < IQ; ++iq) {
-                    const float* qr = qs + (iq * H + h) * QREC;
-                    float sacc = 0.f, d2 = 0.f;
-#pragma unroll
-                    for (int c = 0; c < SQK; ++c) sacc = fmaf(qr[c], kq[hh][c >> 2][c & 3], sacc);
-#pragma unroll
-                    for (int c = SQK; c < QREC; ++c) {
-                        const float d = qr[c] - kq[hh][c >> 2][c & 3];
-                        d2 = fmaf(d, d, d2);
-                    }
-                    float v = sacc + pwh * d2;
-                    if (iq < niq) {
-                        v += bz[hh][iq];
-                        if (mi[iq] * mj == 0.f) v = ABX_NEG_MAX;
-                    }
-                    lg[((size_t)iq * L + j) * LDH + h] = v;
+                for (int c = SQK; c < QREC; ++c) {
+                    const float kc = kq[c >> 2][c & 3];
+                    const f32x2 d = qh[ip * QREC + c] - (f32x2){kc, kc};
+                    d2 = __builtin_elementwise_fma(d, d, d2);
+                }
+                if (j < L) {
+                    lg[(size_t)((2 * ip) * HG + hl) * LR + j] = sacc[0] + pwh * d2[0];
+                    lg[(size_t)((2 * ip + 1) * HG + hl) * LR + j] = sacc[1] + pwh * d2[1];
                 }
             }
         }
     }
     __syncthreads();
-    // ---- softmax over j for each (iq, h): 48 rows over 8 waves ------------------------------------------------
-    for (int row = wave; row < IQ * H; row += IPA_THREADS / 64) {
-        const int iq = row / H, h = row % H;
-        float* r = lg + (size_t)iq * L * LDH + h;
-        float mx = -INFINITY;
-        for (int j = lane; j < L; j += 64) mx = fmaxf(mx, r[(size_t)j * LDH]);
-        mx = wave_max(mx);
-        float sm = 0.f;
+    // ---- pair bias and mask: thread per (iq, j), the 4 heads of the group in one 16-byte load
+    for (int idx = tid; idx < niq * L; idx += IPA_THREADS) {
+        const int iq = idx / L, j = idx - iq * L;
+        const long long row = (long long)b * L + i0 + iq;
+        const f32x4 bz = *reinterpret_cast<const f32x4*>(bias2d + (row * L + j) * H + h0);
+        const bool masked = mask[row] * mask[(long long)b * L + j] == 0.f;
+        float* r = lg + (size_t)iq * HG * LR + j;
+#pragma unroll
+        for (int c = 0; c < HG; ++c) r[(size_t)c * LR] = masked ? ABX_NEG_MAX : r[(size_t)c * LR] + bz[c];
+    }
+    // ---- phase B1 set-up: item = (h, c4): 40 items, 5 per wave; the 12 key groups of an item are lanes il, il + 5, ... of its
+    // wave (lanes 60..63 idle).  The first V records are requested now: their latency hides behind the softmax
+    constexpr int NJG = 12, IPW = 5, UB = 4;
+    const int il = lane % IPW, jg = lane / IPW;
+    const int item = wave * IPW + il;                       // 0..39
+    const int hl1 = item / (VREC / 4), c41 = item % (VREC / 4);
+    const float* vb = vpack + ((long long)b * H + h0 + hl1) * L * VREC + c41 * 4;
+    f32x4 vnext[UB];
+    auto load_round = [&](int jb) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) vnext[u] = *reinterpret_cast<const f32x4*>(vb + (long long)min(jb + u * NJG, L - 1) * VREC);
+    };
+    if (jg < NJG) load_round(jg);
+    __syncthreads();
+    // ---- softmax over j, one wave per query: its 4 head rows together (interleaved reductions); the normalised weights go
+    // back to LDS (phase B1) and to HBM as [i][head group][j][4], 16 contiguous bytes per lane
+    for (int iq = wave; iq < niq; iq += IPA_THREADS / 64) {
+        float* r = lg + (size_t)iq * HG * LR;
+        float mx[HG], sm[HG], inv[HG];
+#pragma unroll
+        for (int c = 0; c < HG; ++c) { mx[c] = -INFINITY; sm[c] = 0.f; }
+        for (int j = lane; j < L; j += 64)
+#pragma unroll
+            for (int c = 0; c < HG; ++c) mx[c] = fmaxf(mx[c], r[(size_t)c * LR + j]);
+#pragma unroll
+        for (int c = 0; c < HG; ++c) mx[c] = wave_max(mx[c]);
+        for (int j = lane; j < L; j += 64)
+#pragma unroll
+            for (int c = 0; c < HG; ++c) {
+                const float e = expf(r[(size_t)c * LR + j] - mx[c]);
+                r[(size_t)c * LR + j] = e;
+                sm[c] += e;
+            }
+#pragma unroll
+        for (int c = 0; c < HG; ++c) inv[c] = 1.0f / wave_sum(sm[c]);
+        float* o = attn + ((((long long)b * L + i0 + iq) * NHG + hg) * L) * HG;
         for (int j = lane; j < L; j += 64) {
-            const float e = expf(r[(size_t)j * LDH] - mx);
-            r[(size_t)j * LDH] = e;
-            sm += e;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < HG; ++c) {
+                v[c] = r[(size_t)c * LR + j] * inv[c];
+                r[(size_t)c * LR + j] = v[c];
+            }
+            *reinterpret_cast<f32x4*>(o + (long long)j * HG) = v;
         }
-        sm = wave_sum(sm);
-        const float inv = 1.0f / sm;
-        for (int j = lane; j < L; j += 64) r[(size_t)j * LDH] *= inv;
     }
     __syncthreads();
-    // ---- phase B1: scalar + point outputs.  item = (h, c4): 120 items x NJG1 j-groups, 16-byte loads of V -----------
+    // ---- phase B1: scalar + point outputs; the V records of the next 4 keys are in flight while the current 4 are consumed
     {
-        const int item = tid % (H * VREC / 4), jg = tid / (H * VREC / 4);
-        const int h = item / (VREC / 4), c4 = item % (VREC / 4);
         f32x4 acc[IQ];
 #pragma unroll
         for (int iq = 0; iq < IQ; ++iq) acc[iq] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (jg < NJG1) {
-            const float* vb = vpack + ((long long)b * H + h) * L * VREC + c4 * 4;
-            constexpr int UB = 8;                       // loads in flight per lane
-            for (int jb = jg; jb < L; jb += NJG1 * UB) {
+        if (jg < NJG) {
+            const float* wr = lg + (size_t)hl1 * LR;
+            for (int jb = jg; jb < L; jb += NJG * UB) {
                 f32x4 vv[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int j = min(jb + u * NJG1, L - 1);
-                    vv[u] = *reinterpret_cast<const f32x4*>(vb + (long long)j * VREC);
-                }
+                for (int u = 0; u < UB; ++u) vv[u] = vnext[u];
+                if (jb + NJG * UB < L) load_round(jb + NJG * UB);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const int j = jb + u * NJG1;
+                    const int j = jb + u * NJG;
                     if (j < L) {
 #pragma unroll
                         for (int iq = 0; iq < IQ; ++iq) {
-                            const float w = lg[((size_t)iq * L + j) * LDH + h];
+                            const float w = wr[(size_t)iq * HG * LR + j];
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc[iq][c] = fmaf(w, vv[u][c], acc[iq][c]);
                         }
                     }
                 }
             }
+        }
+        // fold the key groups: (g, g + 6), then (g, g + 3), then g0 + g1 + g2 -> lanes 0..4 (out-of-range sources wrap into
+        // lanes whose results are never used)
 #pragma unroll
-            for (int iq = 0; iq < IQ; ++iq)
-                *reinterpret_cast<f32x4*>(red + ((size_t)(jg * IQ + iq) * H + h) * VREC + c4 * 4) = acc[iq];
+        for (int iq = 0; iq < IQ; ++iq)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = acc[iq][c];
+                x += __shfl(x, lane + 6 * IPW, 64);
+                x += __shfl(x, lane + 3 * IPW, 64);
+                const float x1 = __shfl(x, lane + IPW, 64), x2 = __shfl(x, lane + 2 * IPW, 64);
+                acc[iq][c] = (x + x1) + x2;
+            }
+        if (jg == 0) {
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) *reinterpret_cast<f32x4*>(opt + (size_t)(iq * HG + hl1) * VREC + c41 * 4) = acc[iq];
         }
         __syncthreads();
-        for (int idx = tid; idx < IQ * H * VREC; idx += IPA_THREADS) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int g2 = 0; g2 < NJG1; ++g2) sacc += red[(size_t)g2 * IQ * H * VREC + idx];
-            opt[idx] = sacc;
-        }
-        __syncthreads();
-    }
-    // ---- phase B2: attention over the pair slab: lane -> 4 channels (16-byte loads), 16 j-groups, 48 accumulators ------
-    {
-        const int c4 = tid & 31, jg = tid >> 5;
-        for (int iq = 0; iq < niq; ++iq) {
-            const float* zr = z + (((long long)b * L + i0 + iq) * L) * CZ + c4 * 4;
-            const float* ar = lg + (size_t)iq * L * LDH;
-            f32x4 acc[H];
-#pragma unroll
-            for (int hh = 0; hh < H; ++hh) acc[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            constexpr int UZ = 8;                       // 16-byte slab loads in flight per lane (8 KB per wave)
-            for (int jb = jg; jb < L; jb += NJG2 * UZ) {
-                f32x4 zv[UZ];
-#pragma unroll
-                for (int u = 0; u < UZ; ++u) {
-                    const int j = min(jb + u * NJG2, L - 1);
-                    zv[u] = *reinterpret_cast<const f32x4*>(zr + (long long)j * CZ);
-                }
-#pragma unroll
-                for (int u = 0; u < UZ; ++u) {
-                    const int j = jb + u * NJG2;
-                    if (j < L) {
-                        const float* a12 = ar + (size_t)j * LDH;
-#pragma unroll
-                        for (int hh = 0; hh < H; ++hh) {
-                            const float w = a12[hh];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[hh][c] = fmaf(w, zv[u][c], acc[hh][c]);
-                        }
-                    }
-                }
-            }
-            // the two j-groups of a wave (lanes l, l+32) first, then the 8 waves through LDS, in a fixed order
-#pragma unroll
-            for (int hh = 0; hh < H; ++hh)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[hh][c] += __shfl_xor(acc[hh][c], 32, 64);
-            if (lane < 32) {
-#pragma unroll
-                for (int hh = 0; hh < H; ++hh)
-                    *reinterpret_cast<f32x4*>(red + ((size_t)wave * H + hh) * CZ + c4 * 4) = acc[hh];
-            }
-            __syncthreads();
-            float* fo = feat + ((long long)b * L + i0 + iq) * NFEAT + (H * SV + 4 * H * PV);
-            for (int idx = tid; idx < H * CZ; idx += IPA_THREADS) {
-                float sacc = 0.f;
-#pragma unroll
-                for (int w8 = 0; w8 < IPA_THREADS / 64; ++w8) sacc += red[(size_t)w8 * H * CZ + idx];
-                fo[idx] = sacc;
-            }
-            __syncthreads();
-        }
     }
     // ---- tail: scalar copy, points to the local frame, norms ----------------------------------------------------------
-    for (int idx = tid; idx < IQ * H * SV; idx += IPA_THREADS) {
-        const int iq = idx / (H * SV), r = idx % (H * SV);
-        if (iq < niq) feat[((long long)b * L + i0 + iq) * NFEAT + r] = opt[(iq * H + r / SV) * VREC + (r % SV)];
+    for (int idx = tid; idx < niq * HG * SV; idx += IPA_THREADS) {
+        const int iq = idx / (HG * SV), r = idx % (HG * SV);
+        feat[((long long)b * L + i0 + iq) * NFEAT + h0 * SV + r] = opt[(iq * HG + r / SV) * VREC + (r % SV)];
     }
-    for (int idx = tid; idx < IQ * H * PV; idx += IPA_THREADS) {
-        const int iq = idx / (H * PV), n = idx % (H * PV);
-        if (iq >= niq) continue;
-        const int h = n / PV, pt = n % PV;
+    for (int idx = tid; idx < niq * HG * PV; idx += IPA_THREADS) {
+        const int iq = idx / (HG * PV), nl = idx % (HG * PV);
+        const int hl = nl / PV, pt = nl % PV, n = h0 * PV + nl;
         const long long row = (long long)b * L + i0 + iq;
         const float* R = rots + row * 9;
         const float* t = trans + row * 3;
-        const float* g = opt + (iq * H + h) * VREC + SV + pt * 3;
+        const float* g = opt + (iq * HG + hl) * VREC + SV + pt * 3;
         // invert_rigids: R^T, -R^T t ; apply: R^T g + (-R^T t)   (same association as the reference)
         float loc[3];
 #pragma unroll
@@ -294,32 +288,104 @@ __global__ __launch_bounds__(IPA_THREADS) void ipa_attn_kernel(const float* __re
     }
 }
 
+// ---- kernel 2: attention over the pair slab, out[b,i,h,:] = sum_j attn[b,i,j,h] * z[b,i,j,:] --------------------------------
+// The HBM stream of the IPA layer: z[b,i,:,:] (L x 512 bytes) is read exactly once.  ONE WAVE per (b, i) row: a lane owns 2 of
+// the 128 channels (8-byte loads, 512 contiguous bytes per wave and key), 16 keys in flight; the 16 x 12 weights of those keys
+// are fetched by the same wave as 3 coalesced dwords per lane, together with the slab loads (one latency, not a dependent
+// scalar-cache miss per key; layout [head group][key][4]), parked in a wave-private LDS strip and read back as broadcasts; 24 accumulators per lane, keys
+// summed in order: no block barrier, no cross-lane reduction.
+constexpr int PAIR_WAVES = 4;                    // rows per workgroup
+constexpr int UZ = 16;                           // keys per step
+
+__global__ __launch_bounds__(PAIR_WAVES * 64) void ipa_pair_kernel(const float* __restrict__ attn, const float* __restrict__ z,
+                                                                   float* __restrict__ feat, long long rows, int L) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float wl[PAIR_WAVES][UZ * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * PAIR_WAVES + wave;      // b * L + i
+    if (row >= rows) return;
+    const float* __restrict__ wr = attn + row * L * H;
+    const float* __restrict__ zr = z + row * L * CZ + lane * 2;
+    float* ws = wl[wave];
+    const int nw = L * HG;                                       // weights of this row per head group
+    f32x2 acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = (f32x2){0.f, 0.f};
+    for (int j0 = 0; j0 < L; j0 += UZ) {
+        f32x2 zv[UZ];
+#pragma unroll
+        for (int u = 0; u < UZ; ++u) zv[u] = *reinterpret_cast<const f32x2*>(zr + (long long)min(j0 + u, L - 1) * CZ);
+        float wv[NHG];                                           // head group q: 16 keys x 4 heads = 64 consecutive floats
+#pragma unroll
+        for (int q = 0; q < NHG; ++q) wv[q] = wr[(long long)q * nw + min(j0 * HG + lane, nw - 1)];
+        // the previous step's broadcast reads of this strip have retired (same wave, in-order LDS queue)
+#pragma unroll
+        for (int q = 0; q < NHG; ++q) ws[q * 64 + lane] = wv[q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < UZ; ++u) {
+            if (j0 + u < L) {
+                f32x4 w4[H / 4];
+#pragma unroll
+                for (int q = 0; q < NHG; ++q) w4[q] = *reinterpret_cast<const f32x4*>(ws + q * 64 + u * HG);
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float wh = w4[h >> 2][h & 3];
+                    acc[h][0] = fmaf(wh, zv[u][0], acc[h][0]);
+                    acc[h][1] = fmaf(wh, zv[u][1], acc[h][1]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* fo = feat + row * NFEAT + (H * SV + 4 * H * PV) + lane * 2;
+#pragma unroll
+    for (int h = 0; h < H; ++h) *reinterpret_cast<f32x2*>(fo + h * CZ) = acc[h];
+}
+
 }  // namespace
 
 extern "C" int abx_ipa_pack(const float* proj, const float* rots, const float* trans, float* qpack, float* kpack,
                             float* vpack, int B, int L, float scalar_weight, hipStream_t st) {
     ABX_REQUIRE(proj && rots && trans && qpack && kpack && vpack && B > 0 && L > 0, "abx_ipa_pack: bad args");
-    const long long n = (long long)B * L * H;
+    const long long n = (long long)B * ((L + IQ - 1) / IQ) * IQ * H;
     hipLaunchKernelGGL(ipa_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, proj, rots, trans, qpack, kpack,
                        vpack, B, L, scalar_weight);
     return abx_check_launch("abx_ipa_pack");
 }
 
+extern "C" long long abx_ipa_qpack_bytes(int B, int L) {
+    return (long long)B * ((L + IQ - 1) / IQ) * IQ * H * QREC * sizeof(float);
+}
+
+extern "C" long long abx_ipa_attn_workspace_bytes(int B, int L) {
+    return (long long)B * L * L * H * sizeof(float);
+}
+
 extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
-                            const float* mask, const float* rots, const float* trans, const float* point_weights, float* feat,
-                            int B, int L, hipStream_t st) {
-    ABX_REQUIRE(qpack && kpack && vpack && bias2d && z && mask && rots && trans && point_weights && feat, "abx_ipa_attn: null");
-    ABX_REQUIRE(B > 0 && L > 0 && B <= 65535, "abx_ipa_attn: bad sizes");
-    const size_t lds = ((((size_t)IQ * L * LDH + 3) & ~(size_t)3) + IQ * H * QREC + IQ * H * VREC + (size_t)(IPA_THREADS / 64) * H * CZ) * sizeof(float);
+                            const float* mask, const float* rots, const float* trans, const float* point_weights, float* attn_ws,
+                            float* feat, int B, int L, hipStream_t st) {
+    ABX_REQUIRE(qpack && kpack && vpack && bias2d && z && mask && rots && trans && point_weights && attn_ws && feat,
+                "abx_ipa_attn: null");
+    ABX_REQUIRE(B > 0 && L > 0 && B <= 65535 && (long long)B * L < (1ll << 31), "abx_ipa_attn: bad sizes");
+    const size_t lds = ((size_t)IQ * HG * ipa_row_stride(L) + IQ * HG * VREC) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_attn: L too large for LDS-resident logits");
     static thread_local bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_attn_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_weights_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) { abx_set_error("abx_ipa_attn: hipFuncSetAttribute failed"); return (int)e; }
         configured = true;
     }
-    hipLaunchKernelGGL(ipa_attn_kernel, dim3((L + IQ - 1) / IQ, B), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, z, mask,
-                       rots, trans, point_weights, feat, B, L);
-    return abx_check_launch("abx_ipa_attn");
+    hipLaunchKernelGGL(ipa_weights_kernel, dim3(((L + IQ - 1) / IQ) * NHG, B), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, mask,
+                       rots, trans, point_weights, attn_ws, feat, B, L);
+    int rc = abx_check_launch("abx_ipa_attn(weights)");
+    if (rc) return rc;
+    const long long rows = (long long)B * L;
+    hipLaunchKernelGGL(ipa_pair_kernel, dim3((unsigned)((rows + PAIR_WAVES - 1) / PAIR_WAVES)), dim3(PAIR_WAVES * 64), 0, st, attn_ws, z,
+                       feat, rows, L);
+    return abx_check_launch("abx_ipa_attn(pair slab)");
 }

@@ -388,20 +388,21 @@ class Engine:
         ops.layernorm(zi, *P.ln(P_IPA + 'init_pair_layer_norm'), out=zi)
         bias2d = w384[M2 * 128:M2 * 140].view(M2, 12)
         _lin(P, P_IPA + 'attention_module.proj_pair', zi, bias2d, alpha=P.ipa_w2d)
+        attn_ws = w384[M2 * 140:M2 * 152].view(M2, 12)
         init_q = ws.get('f_iq', (M1, 4)); init_t = ws.get('f_it', (M1, 3))
         cur_q = ws.get('f_q', (M1, 4)); cur_t = ws.get('f_t', (M1, 3)); cur_R = ws.get('f_R', (M1, 9))
         delta_q = ws.get('f_dq', (M1, 4))
         rig_in = st['rigids_t'][b0:b1].contiguous()
         ops.frames_init(rig_in, init_q, init_t, cur_q, cur_t, cur_R, delta_q, M1, ic.position_scale)
         proj = ws.get('i_proj', (M1, 1152))
-        qpack = ws.get('i_qp', (M1 * 12 * 28,)); kpack = ws.get('i_kp', (M1 * 12 * 28,)); vpack = ws.get('i_vp', (M1 * 12 * 40,))
+        qpack = ws.get('i_qp', (ops.ipa_qpack_numel(Bc, L),)); kpack = ws.get('i_kp', (M1 * 12 * 28,)); vpack = ws.get('i_vp', (M1 * 12 * 40,))
         ifeat = ws.get('i_feat', (M1, 2112))
         h1 = ws.get('i_h1', (M1, NC)); h2 = ws.get('i_h2', (M1, NC))
         upd = ws.get('i_upd', (M1, 6))
         for _ in range(ic.num_layer):
             ops.gemm(s, P.wt[P_IPA + 'attention_module.proj'], proj, bias=P.b[P_IPA + 'attention_module.proj'], exact=1)
             ops.ipa_pack(proj, cur_R, cur_t, qpack, kpack, vpack, Bc, L, P.ipa_ws)
-            ops.ipa_attn(qpack, kpack, vpack, bias2d, zi, mask_f, cur_R, cur_t, P.ipa_pw, ifeat, Bc, L)
+            ops.ipa_attn(qpack, kpack, vpack, bias2d, zi, mask_f, cur_R, cur_t, P.ipa_pw, ifeat, Bc, L, attn_ws=attn_ws)
             _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)
             ops.layernorm(s, *P.ln(P_IPA + 'attention_layer_norm'), out=s)
             _lin(P, P_IPA + 'transition_module.0', s, h1, act=1)

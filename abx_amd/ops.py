@@ -321,14 +321,24 @@ def seq_attn(qkv, biasT, keymask, gate, out, B, L, H=32, D=17):
     return out
 
 
+def ipa_qpack_numel(B, L):
+    """floats in the Q pack of abx_ipa_pack (query rows padded to blocks of 12)."""
+    return _lib.load().abx_ipa_qpack_bytes(B, L) // 4
+
+
 def ipa_pack(proj, rots, trans, qpack, kpack, vpack, B, L, w_s):
+    assert qpack.numel() >= ipa_qpack_numel(B, L)
     check(_lib.load().abx_ipa_pack(_p(proj), _p(rots), _p(trans), _p(qpack), _p(kpack), _p(vpack), B, L, float(w_s), _stream()),
           'abx_ipa_pack')
 
 
-def ipa_attn(qpack, kpack, vpack, bias2d, z, mask, rots, trans, pw, feat, B, L):
+def ipa_attn(qpack, kpack, vpack, bias2d, z, mask, rots, trans, pw, feat, B, L, attn_ws=None):
+    """attn_ws: (B*L*L, 12) fp32 scratch for the attention weights (allocated here when the caller has no workspace)."""
+    if attn_ws is None:
+        attn_ws = torch.empty(_lib.load().abx_ipa_attn_workspace_bytes(B, L) // 4, device=feat.device, dtype=torch.float32)
+    assert attn_ws.numel() >= B * L * L * 12 and attn_ws.is_contiguous()
     check(_lib.load().abx_ipa_attn(_p(qpack), _p(kpack), _p(vpack), _p(bias2d), _p(z), _p(mask), _p(rots), _p(trans), _p(pw),
-                                   _p(feat), B, L, _stream()), 'abx_ipa_attn')
+                                   _p(attn_ws), _p(feat), B, L, _stream()), 'abx_ipa_attn')
 
 
 _FREQS = {}

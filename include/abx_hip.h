@@ -148,12 +148,16 @@ int abx_seq_attn_fwd(const float* qkv, const float* bias, const float* keymask, 
  * [q_scalar 192 | kv_scalar 384 | q_point_local 144 | kv_point_local 432] into global-frame packs
  * (r3.rigids_apply, r3.py:9-16); abx_ipa_attn does logits (scalar + point distance + pair bias), mask, softmax_j and the
  * three outputs (scalar, points back in the local frame + norms, attention over the pair slab), writing the
- * 2112-wide concat [scalar | points (r n) | norms | pair] that final_proj consumes. */
+ * 2112-wide concat [scalar | points (r n) | norms | pair] that final_proj consumes.  Two launches: the attention weights
+ * (kept in attn_ws [B][L][3 head groups][L][4] fp32, abx_ipa_attn_workspace_bytes) with the scalar / point outputs, then the stream over
+ * the pair slab z [B][L][L][128]. */
 int abx_ipa_pack(const float* proj, const float* rots, const float* trans, float* qpack, float* kpack, float* vpack,
                  int B, int L, float scalar_weight, hipStream_t stream);
 int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
                  const float* mask, const float* rots, const float* trans, const float* point_weights /* [12] */,
-                 float* feat, int B, int L, hipStream_t stream);
+                 float* attn_ws, float* feat, int B, int L, hipStream_t stream);
+long long abx_ipa_attn_workspace_bytes(int B, int L);
+long long abx_ipa_qpack_bytes(int B, int L);   /* size of qpack: query rows padded to blocks of 12, pairs interleaved */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Embedding assembly (seqformer.py:49-119,170-223) and small pair-stack helpers

@@ -482,9 +482,12 @@ def test_seq_attn(ops):
     check(out.view(B, L, -1), o, 5e-6, 'seq_attn')
 
 
-def test_ipa_core(ops, params, cfg):
+@pytest.mark.parametrize('L', [37, 131])
+def test_ipa_core(ops, params, cfg, L):
+    """IPA core against the oracle; L = 37: one partial 12-query block tail and a single 64-key wave task per head,
+    L = 131: three key tasks per head, 11 query blocks (last one 11 of 12)."""
     from oracle import abx_oracle as O
-    B, L = 2, 37
+    B = 2
     c = cfg.model.heads.diffusion_module.IPA
     s = torch.randn(B, L, 256, generator=g(40))
     z = torch.randn(B, L, L, 128, generator=g(41))
@@ -504,7 +507,7 @@ def test_ipa_core(ops, params, cfg):
     ops.gemm(s.view(M1, 256).to(DEV), P.wt[pre + 'proj'], proj, bias=P.b[pre + 'proj'])
     bias2d = torch.empty(B * L * L, 12, device=DEV)
     ops.gemm(z.view(-1, 128).to(DEV), P.wt[pre + 'proj_pair'], bias2d, bias=P.b[pre + 'proj_pair'], alpha=P.ipa_w2d)
-    qp = torch.empty(M1 * 12 * 28, device=DEV); kp = torch.empty(M1 * 12 * 28, device=DEV); vp = torch.empty(M1 * 12 * 40, device=DEV)
+    qp = torch.empty(ops.ipa_qpack_numel(B, L), device=DEV); kp = torch.empty(M1 * 12 * 28, device=DEV); vp = torch.empty(M1 * 12 * 40, device=DEV)
     Rd, td = rots.reshape(M1, 9).contiguous().to(DEV), trans.reshape(M1, 3).contiguous().to(DEV)
     ops.ipa_pack(proj, Rd, td, qp, kp, vp, B, L, P.ipa_ws)
     feat = torch.full((M1, 2112), float('nan'), device=DEV)

@@ -192,7 +192,7 @@ def main():
         ms = timeit(lambda: ops.transpose_last2(bT.view(Bc * 4, L, L), bT2.view(Bc * 4, L, L)))
         rec('transpose_last2 (bias)', ms, 0, 8.0 * Bc * 4 * LL)
     if not only or 'ipa' in only:
-        qp, kp, vp = r(M1 * 12 * 28), r(M1 * 12 * 28), r(M1 * 12 * 40)
+        qp, kp, vp = r(ops.ipa_qpack_numel(Bc, L)), r(M1 * 12 * 28), r(M1 * 12 * 40)
         bias2d, zz = r(M2, 12), r(M2, 128)
         mask = torch.ones(Bc, L, device=DEV)
         R, t = r(M1, 9), r(M1, 3)

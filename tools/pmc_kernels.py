@@ -53,7 +53,7 @@ elif which == 'tri':
         ops.tri_attn(x, bT, mask, o, Bc, L, True, bias_is_qk=True)
 elif which == 'ipa':
     M1 = Bc * L
-    qp, kp, vp = r(M1 * 12 * 28), r(M1 * 12 * 28), r(M1 * 12 * 40)
+    qp, kp, vp = r(ops.ipa_qpack_numel(Bc, L)), r(M1 * 12 * 28), r(M1 * 12 * 40)
     bias2d, zi, mask = r(M2, 12), r(M2, 128), torch.ones(Bc, L, device=DEV)
     R = torch.eye(3, device=DEV).reshape(1, 9).repeat(M1, 1).contiguous()
     t, pw, feat = r(M1, 3), -torch.rand(12, device=DEV), torch.empty(M1, 2112, device=DEV)
