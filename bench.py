@@ -94,8 +94,9 @@ class OpTimer:
             Bc, L = args[4], args[5]
             return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
         if name == 'ipa_attn':
-            Bc, L = args[-2], args[-1]
-            return 'ipa_attn_kernel', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12)
+            Bc, L = args[10], args[11]
+            # two launches (ipa_weights_kernel + ipa_pair_kernel); bytes: pair slab + pair bias + the weights written and re-read
+            return 'ipa_attn (weights + pair slab kernels)', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12 + 24)
         return name, 0.0, 0.0
 
     def __enter__(self):
