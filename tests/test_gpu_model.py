@@ -480,16 +480,18 @@ class _GemmSpy:
         self.ops.gemm = self.orig
 
 
-@pytest.mark.parametrize('w', [dict(L_heavy=55, L_light=47, L_antigen=29, cdr=(30, 41)),      # L = 131 (odd)
-                               dict(L_heavy=50, L_light=44, L_antigen=24, cdr=(30, 39))])     # L = 118 (L % 4 == 2)
-def test_any_length_takes_the_plane_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser, w):
+@pytest.mark.parametrize('w,B', [(dict(L_heavy=55, L_light=47, L_antigen=29, cdr=(30, 41)), 4),      # L = 131 (odd)
+                                 (dict(L_heavy=50, L_light=44, L_antigen=24, cdr=(30, 39)), 4),      # L = 118 (L % 4 == 2)
+                                 # L = 402 > 384: the 4-slot triangle-attention instantiation (4 query tiles per wave, 4 key
+                                 # chunks), 7 key tasks per head and 34 query blocks in the IPA weights kernel
+                                 (dict(L_heavy=126, L_light=110, L_antigen=166, cdr=(100, 112)), 1)])
+def test_any_length_takes_the_plane_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser, w, B):
     """residue counts that are not multiples of 4 (the real complexes are L = 230 and 261) run the triangle
     multiplication on the same glu -> bf16 planes -> plane contraction route as L = 352, through the padded pair-row maps.
     One full call (3 passes), 4 samples with different noise and a masked antigen tail, HIP vs oracle."""
     from oracle import abx_oracle as O
     from abx_amd import sampler, ops
     model, D = gpu_model
-    B = 4
     L = w['L_heavy'] + w['L_light'] + w['L_antigen']
     assert L % 4 != 0 and ops.gemm_split_eligible(L * L, 128, 192, B)
     b = _synthetic_batch(D, w, B=B, n_masked_tail=2)
