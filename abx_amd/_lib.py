@@ -41,6 +41,7 @@ class AbxGemm(C.Structure):
         ('A2', c_f), ('sA2b', LL), ('sA2m', LL), ('K2', I),
         ('B2_split', C.c_void_p), ('sB23p', LL), ('sB23n', LL), ('sB23k', LL),
         ('ln2_csum', c_f), ('bias2', c_f),
+        ('out_ln_w', c_f), ('out_ln_b', c_f), ('out_ln_eps', F),
         ('exact', I),
         ('tune', I),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),

@@ -442,6 +442,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(!g.ln_stats || g.ln_csum, "abx_gemm: LayerNorm needs the column sums of the gamma-scaled weights");
     ABX_REQUIRE(!(g.ln_csum && g.a_relu), "abx_gemm: LayerNorm and relu-on-load are exclusive");
     if (g.ln_csum && !g.ln_stats && g.ln_eps <= 0.f) g.ln_eps = 1e-5f;
+    if (g.out_ln_w && g.out_ln_eps <= 0.f) g.out_ln_eps = 1e-5f;
     const bool akc = g.sAk == 1;
     // 16-byte vector loads need aligned bases and strides that are multiples of 4 elements
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -463,6 +464,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(g.batch <= 65535, "abx_gemm: batch > 65535 (exact fp32 kernels)");
     ABX_REQUIRE(!g.glu, "abx_gemm: glu is served by the split-bf16 kernels only (large problems, K % 16 == 0)");
     ABX_REQUIRE(!g.A2, "abx_gemm: the dual GEMM is served by the split-bf16 kernels only");
+    ABX_REQUIRE(!g.out_ln_w, "abx_gemm: out_ln is served by the split-bf16 kernels only");
     const long long mt128 = ((long long)g.M + 127) / 128;
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);

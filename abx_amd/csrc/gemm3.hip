@@ -302,7 +302,7 @@ __device__ __forceinline__ bool gemm3_row_stats(const AbxGemm& g, float* st_lds,
     return gstats != nullptr || ln_inline;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS>
+template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false>
 __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN];
@@ -311,7 +311,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     float* st_lds = smem;                                   // [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     __syncthreads();
-    gemm_epilogue<BM, BN, WM, WN, EDGE, TS>(g, st_lds, smem + 2 * BM, acc, mt * BM, nt * BN, b, stats);
+    gemm_epilogue<BM, BN, WM, WN, EDGE, TS, OLN>(g, st_lds, smem + 2 * BM, acc, mt * BM, nt * BN, b, stats);
 }
 
 // Dual GEMM (the TriangleMultiplication tail, seqformer.py:496-503): out = epi(A' B) * sigmoid(LN(A2) B2 + bias2) (+ resid).
@@ -366,6 +366,23 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS>(g, smem, mt, nt, b);
     else gemm3_block<BM, BN, WM, WN, AMODE, true, TS>(g, smem, mt, nt, b);
+}
+
+// Linear -> LayerNorm over the output row (out_ln): k-contiguous fp32 A, one n-tile, plain store
+template <int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm3_oln_kernel(const AbxGemm g) {
+    constexpr int OPER = (2 * BM * 64 + 2 * 3 * BN * 32) / 4;
+    constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;
+    constexpr int EPI = 2 * BM + 4 * 32 * (TGW * 32 + 4);
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntm = (g.M + BM - 1) / BM;
+    const long long nwg = gridDim.x, bid = blockIdx.x;
+    const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const long long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / ntm), mt = (int)(wgid - (long long)b * ntm);
+    const bool interior = (mt + 1) * BM <= g.M && BN <= g.N;
+    if (interior) gemm3_block<BM, BN, WM, WN, 0, false, false, true>(g, smem, mt, 0, b);
+    else gemm3_block<BM, BN, WM, WN, 0, true, false, true>(g, smem, mt, 0, b);
 }
 
 template <int BM, int BN, int WM, int WN, int MINW>
@@ -448,6 +465,17 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if (((long long)g.M + 127) / 128 * (((long long)g.N + 127) / 128) * g.batch >= (1LL << 31)) return 1;
     if (g.A_split && (long long)(g.K / 16) * g.sA3k >= (1LL << 31)) return 1;
     if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
+    if (g.out_ln_w) {
+        if (g.N > 128 || g.c_transposed || g.C_split || g.A2 || g.A_split || g.sAk != 1 || !g.out_ln_b) {
+            abx_set_error("abx_gemm: out_ln needs N <= 128, a k-contiguous fp32 A and a plain store (split-bf16 path)");
+            *rc = ABX_ERR_ARG;
+            return 0;
+        }
+        const long long mt = ((long long)g.M + 127) / 128;
+        hipLaunchKernelGGL((gemm3_oln_kernel<128, 128, 32, 128, 3>), dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
+        *rc = abx_check_launch("abx_gemm(out_ln)");
+        return 0;
+    }
     if (g.A2) {
         // dual GEMM: 128 x 96 tiles (two accumulator sets of 48 registers)
         if (g.A_split || g.c_transposed || g.glu || !g.B2_split || g.K2 % 16 != 0 || !al16(g.A2) || g.sA2m % 4 != 0 || g.sA2b % 4 != 0 ||

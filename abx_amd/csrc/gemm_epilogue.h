@@ -6,7 +6,7 @@
 #include "common.h"
 #include "abx_hip.h"
 
-template <int BM, int BN, int WM, int WN, bool EDGE, bool TS>
+template <int BM, int BN, int WM, int WN, bool EDGE, bool TS, bool OLN = false>
 __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __restrict__ st_lds, float* __restrict__ scratch,
                                               f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats,
                                               f32x16 (*acc2)[WM / 32][WN / 32] = nullptr, const float* __restrict__ st2_lds = nullptr) {
@@ -92,6 +92,58 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             for (int c = 0; c < 4; ++c) if (c < cnt) Cb[off_c + c] = v[c];
         }
     };
+    // LayerNorm over the output columns (out_ln_w; its own kernel instantiation: the extra live ranges must not cost the plain
+    // kernels registers): the wave holds whole rows (WAVES_N == 1, one n-tile), so the row statistics
+    // are a 32-lane butterfly over the accumulators; two passes (mean, then centred squares) like torch's LayerNorm
+    constexpr bool pre = OLN;
+    if constexpr (OLN) {
+        static_assert(!TS && WAVES_N == 1, "out_ln: plain store, whole rows per wave");
+        {
+            float gam[TN], bet[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + j * 32 + (lane & 31);
+                const bool nok = n < g.N;
+                gam[j] = nok ? g.out_ln_w[n] : 0.f;
+                bet[j] = nok ? g.out_ln_b[n] : 0.f;
+            }
+            const float invn = 1.0f / (float)g.N;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * WM + i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                    float sm = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const bool nok = n0 + j * 32 + (lane & 31) < g.N;
+                        float v = epi1(acc[i][j][r], ml, j);
+                        if (acc2) {
+                            const float gv = st2_lds[2 * ml + 1] * ((*acc2)[i][j][r] - st2_lds[2 * ml] * csum2[j]) + bias2[j];
+                            v *= 1.0f / (1.0f + expf(-gv));
+                        }
+                        acc[i][j][r] = nok ? v : 0.f;
+                        sm += acc[i][j][r];
+                    }
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                    const float mean = sm * invn;
+                    float sq = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const bool nok = n0 + j * 32 + (lane & 31) < g.N;
+                        const float d = nok ? acc[i][j][r] - mean : 0.f;
+                        sq = fmaf(d, d, sq);
+                    }
+#pragma unroll
+                    for (int o = 1; o < 32; o <<= 1) sq += __shfl_xor(sq, o, 64);
+                    const float rstd = 1.0f / sqrtf(sq * invn + g.out_ln_eps);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] = (acc[i][j][r] - mean) * rstd * gam[j] + bet[j];
+                }
+            }
+        }
+    }
     if constexpr (!TS) {
         // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][GW + 4] in column groups of GW <= 96
         // and leaves as float4 along n
@@ -111,8 +163,8 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                         const int ml = wm * WM + i * 32 + mloc;
 #pragma unroll
                         for (int j = 0; j < TG; ++j) {
-                            float v = epi1(acc[i][jg + j][rq * 4 + c], ml, jg + j);
-                            if (acc2) {      // dual GEMM: times sigmoid(LN-folded gate accumulator + bias2)
+                            float v = pre ? acc[i][jg + j][rq * 4 + c] : epi1(acc[i][jg + j][rq * 4 + c], ml, jg + j);
+                            if (acc2 && !pre) {      // dual GEMM: times sigmoid(LN-folded gate accumulator + bias2)
                                 const float gv = st2_lds[2 * ml + 1] * ((*acc2)[i][jg + j][rq * 4 + c] - st2_lds[2 * ml] * csum2[jg + j]) + bias2[jg + j];
                                 v *= 1.0f / (1.0f + expf(-gv));
                             }

@@ -384,8 +384,12 @@ class Engine:
         s = ws.get('i_s', (M1, NC))
         _lin(P, P_IPA + 'proj_seq', s0, s)
         zi = w384[:M2 * 128].view(M2, 128)
-        _lin(P, P_IPA + 'proj_init_pair_act', z2, zi)
-        ops.layernorm(zi, *P.ln(P_IPA + 'init_pair_layer_norm'), out=zi)
+        if P.gemm_mode == 2:
+            # Linear -> LayerNorm in one kernel (the 128 output channels of a row sit in one wave tile of the split-bf16 GEMM)
+            _lin(P, P_IPA + 'proj_init_pair_act', z2, zi, out_ln=P.ln(P_IPA + 'init_pair_layer_norm'))
+        else:
+            _lin(P, P_IPA + 'proj_init_pair_act', z2, zi)
+            ops.layernorm(zi, *P.ln(P_IPA + 'init_pair_layer_norm'), out=zi)
         bias2d = w384[M2 * 128:M2 * 140].view(M2, 12)
         _lin(P, P_IPA + 'attention_module.proj_pair', zi, bias2d, alpha=P.ipa_w2d)
         attn_ws = w384[M2 * 140:M2 * 152].view(M2, 12)

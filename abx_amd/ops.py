@@ -101,7 +101,7 @@ def split_weights(Wt):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -114,7 +114,8 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     pair=(L, Lp): the M rows are padded pair positions i*Lp + j (Lp % 4 == 0, any L); a_pair: A is the UNpadded (b, L*L, K) pair
     tensor; c_pair: Cout / gate / resid are UNpadded (b, L*L, N) pair tensors (pad rows dropped).  rowscale is indexed by GEMM row.
     dual=(A2, B3_2, csum2, bias2): Cout = epi(A' B) * sigmoid(LN(A2) @ W2 + bias2) (+ resid): A2 (b, rows, K2) k-contiguous fp32 (the
-    UNpadded pair tensor when pair is given), B3_2 = split_weights of the gamma-scaled gate weights (K2, N), csum2 their column sums."""
+    UNpadded pair tensor when pair is given), B3_2 = split_weights of the gamma-scaled gate weights (K2, N), csum2 their column sums.
+    out_ln=(gamma, beta[, eps]): LayerNorm over the N output columns right after bias / alpha / act (split-bf16 path only, N <= 128)."""
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
@@ -208,6 +209,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         g.ln2_csum, g.bias2 = _p(_f32(csum2)), _p(bias2)
         if g.ln_eps == 0:
             g.ln_eps = 1e-5
+    if out_ln is not None:
+        assert out_ln[0].numel() == N and out_ln[1].numel() == N
+        g.out_ln_w, g.out_ln_b = _p(_f32(out_ln[0])), _p(_f32(out_ln[1]))
+        g.out_ln_eps = float(out_ln[2]) if len(out_ln) > 2 else 1e-5
     g.bias = _p(bias)
     g.alpha = float(alpha)
     g.act = int(act)

@@ -93,6 +93,10 @@ typedef struct AbxGemm {
     const float* A2; long long sA2b, sA2m; int K2;
     const unsigned short* B2_split; long long sB23p, sB23n, sB23k;   /* gate weights as k-tiled planes (abx_split_weights) */
     const float* ln2_csum; const float* bias2;     /* [N] column sums of the gamma-scaled gate weights, folded bias */
+    /* LayerNorm over the N OUTPUT columns (gamma, beta; eps), applied right after bias / alpha / act and before rowscale / gate /
+     * resid: Linear -> LayerNorm without a round trip of the rows through HBM (score_network.py:117-120).  Needs a kernel whose
+     * wave tile holds whole rows: split-bf16 path only (its own 128x128-tile instantiation), N <= 128, k-contiguous fp32 A, plain store */
+    const float* out_ln_w; const float* out_ln_b; float out_ln_eps;
     int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split
                                                       into 3 bf16 pieces, 6 products, fp32 accumulate - csrc/gemm3.hip);
                                                       1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32);

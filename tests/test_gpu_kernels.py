@@ -903,3 +903,21 @@ def test_gemm_dual_proj_out_times_gate(ops, L):
     ln = lambda v, ga, be: (v - v.mean(-1, keepdim=True)) / torch.sqrt(v.var(-1, unbiased=False, keepdim=True) + 1e-5) * ga.double() + be.double()
     ref = (ln(x, g1, b1) @ Wo.double() + bo.double()) * torch.sigmoid(ln(z.double(), g2, b2) @ Wg.double() + bg.double()) + z.double()
     check(zd, ref, 3e-6, f'dual gemm L={L}')
+
+
+@pytest.mark.parametrize('N,M,exact', [(128, 40 * 40 * 9 + 37, 2), (96, 129 * 130, 2)])
+def test_gemm_output_layernorm(ops, N, M, exact):
+    """Linear -> LayerNorm in the GEMM epilogue (out_ln; IpaScore's proj_init_pair_act + init_pair_layer_norm,
+    score_network.py:117-120): split-bf16 128x128 tiles with a full / partial (N = 96) row and a ragged last row tile; against fp64."""
+    ge = g(131)
+    K = 192
+    x = torch.randn(M, K, generator=ge) * 1.5 + 0.3
+    W, b = torch.randn(K, N, generator=ge) / 12, torch.randn(N, generator=ge) * 0.2
+    ga, be = 1 + 0.2 * torch.randn(N, generator=ge), 0.1 * torch.randn(N, generator=ge)
+    Wd = W.to(DEV)
+    out = torch.full((M, N), float('nan'), device=DEV)
+    ops.gemm(x.to(DEV), Wd, out, bias=b.to(DEV), B3=ops.split_weights(Wd) if exact == 2 else None, exact=exact,
+             out_ln=(ga.to(DEV), be.to(DEV)))
+    y = x.double() @ W.double() + b.double()
+    ref = (y - y.mean(-1, keepdim=True)) / torch.sqrt(y.var(-1, unbiased=False, keepdim=True) + 1e-5) * ga.double() + be.double()
+    check(out, ref, 5e-6, f'gemm out_ln N={N}')
