@@ -11,8 +11,8 @@
 //     O^T[d][q]   += sum_key V[key][d] * P[key][q]    (P fragments feed the B operand straight from registers)
 // The orientation (starting / ending node) is expressed only through strides; no transposed copy of the pair stack.
 //
-// abx_seq_attn_fwd — sequence attention with 32-head pair bias (seqformer.py:314-356, split_first=False :278-281);
-// 0.8 % of the step, one thread per query with K/V of the (b, h) pair in LDS.
+// abx_seq_attn_fwd — sequence attention with 32-head pair bias (seqformer.py:314-356, split_first=False :278-281):
+// lanes are keys so that the bias rows are read coalesced, K/V of the (b, h) pair in LDS.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -558,54 +558,143 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
     }
 }
 
-// ---- sequence attention: block = (256 queries, h, b); K/V of (b,h) in LDS; one thread per query ----------------
-template <int D>
-__global__ __launch_bounds__(256) void seq_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
-                                                       const float* __restrict__ keymask, const float* __restrict__ gate,
-                                                       float* __restrict__ out, int L, int H, float scale) {
+// ---- sequence attention with pair bias (seqformer.py:314-356): 32 heads x 17 channels, bias (b, h, q, k) ---------------------------
+// The bias stream (L^2 floats per (b, h): 1.6 GB per launch at B = 100, L = 352) is the only real traffic, so the kernel is laid
+// out around reading it coalesced: a wave takes 4 queries at a time and its LANES ARE KEYS (key = lane + 64 m), each bias row is
+// read as contiguous 256-byte segments.  K and V of the (b, h) pair sit in LDS as [key][20] (17 channels + zero pad: 16-byte
+// reads); the 4 x 17 query values are wave-uniform.
+//   logits  lane: 17 FMAs per (query, key) against its K row (read once for the 4 queries), + bias, key mask
+//   softmax per query over lanes (wave max / sum, base 2)
+//   PV      the weights go through a wave-private LDS strip and the lanes regroup as (query, 4 channels, key quarter): one
+//           16-byte V read + one weight read per 4 FMAs; the 17th channel as (query, key sixteenth); shuffle folds, fixed order
+// NT threads share the K / V of one (b, h) pair: 16 waves (4 per SIMD, hiding the LDS / shuffle latencies) while the weight strips fit
+template <int NK, int NT>
+__global__ __launch_bounds__(NT) void seq_attn2_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                        const float* __restrict__ keymask, const float* __restrict__ gate,
+                                                        float* __restrict__ out, int L, int H, float scale, int qblk) {
+    constexpr int D = 17, DP = 20, QW = 4, LP = NK * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;             // [L][D]
-    float* Vs = smem + L * D;     // [L][D]
+    float* Ks = smem;                       // [L][DP]
+    float* Vs = smem + (size_t)L * DP;      // [L][DP]
+    float* pw = Vs + (size_t)L * DP;        // [waves][QW][LP]
     const int h = blockIdx.y, b = blockIdx.z;
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long ld = (long long)H * 3 * D;
     const float* rowb = qkv + (long long)b * L * ld + (long long)h * 3 * D;
-    for (int idx = threadIdx.x; idx < L * D; idx += 256) {
-        const int key = idx / D, d = idx % D;
-        Ks[idx] = rowb[(long long)key * ld + D + d];
-        Vs[idx] = rowb[(long long)key * ld + 2 * D + d];
+    for (int idx = tid; idx < L * DP; idx += NT) {
+        const int key = idx / DP, d = idx - key * DP;
+        Ks[idx] = d < D ? rowb[(long long)key * ld + D + d] : 0.f;
+        Vs[idx] = d < D ? rowb[(long long)key * ld + 2 * D + d] : 0.f;
     }
     __syncthreads();
-    if (qi >= L) return;
-    float q[D], acc[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        q[d] = rowb[(long long)qi * ld + d] * scale;
-        acc[d] = 0.f;
-    }
-    const float* bp = bias + (((long long)b * H + h) * L + qi) * L;
+    const float qs = scale * LOG2E;
     const float* km = keymask ? keymask + (long long)b * L : nullptr;
-    float m = -INFINITY, l = 0.f;
-    for (int k = 0; k < L; ++k) {
-        float s = 0.f;
+    // per-lane key clamps: +inf valid, finfo.min masked (the reference REPLACES the logit: every finite logit is >= finfo.min),
+    // -inf beyond L
+    float clampv[NK];
 #pragma unroll
-        for (int d = 0; d < D; ++d) s = fmaf(q[d], Ks[k * D + d], s);
-        s += bp[k];
-        if (km && km[k] == 0.f) s = ABX_NEG_MAX;
-        const float mn = fmaxf(m, s);
-        const float al = expf(m - mn), p = expf(s - mn);
-        l = l * al + p;
-#pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = acc[d] * al + p * Vs[k * D + d];
-        m = mn;
+    for (int m = 0; m < NK; ++m) {
+        const int k = lane + 64 * m;
+        clampv[m] = k < L ? ((!km || km[k] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
     }
-    const float inv = 1.0f / l;
-    const long long o = ((long long)b * L + qi) * H * D + (long long)h * D;
+    float* pww = pw + (size_t)wave * QW * LP;
+    const int q_end = min((int)(blockIdx.x + 1) * qblk, L);
+    for (int qb = blockIdx.x * qblk + wave * QW; qb < q_end; qb += (NT / 64) * QW) {
+        // ---- bias rows of the 4 queries (coalesced), issued first
+        float bz[QW][NK];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        float v = acc[d] * inv;
-        if (gate) v *= 1.0f / (1.0f + expf(-gate[o + d]));
-        out[o + d] = v;
+        for (int qq = 0; qq < QW; ++qq) {
+            const float* bp = bias + (((long long)b * H + h) * L + min(qb + qq, L - 1)) * L;
+#pragma unroll
+            for (int m = 0; m < NK; ++m) bz[qq][m] = bp[min(lane + 64 * m, L - 1)];
+        }
+        // ---- logits (base 2)
+        float sc[QW][NK];
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            const float* kr = Ks + (size_t)min(lane + 64 * m, L - 1) * DP;
+            f32x4 kv[DP / 4];
+#pragma unroll
+            for (int c = 0; c < DP / 4; ++c) kv[c] = *reinterpret_cast<const f32x4*>(kr + c * 4);
+#pragma unroll
+            for (int qq = 0; qq < QW; ++qq) {
+                const float* qp = rowb + (long long)min(qb + qq, L - 1) * ld;          // wave-uniform
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) acc = fmaf(qp[d] * qs, kv[d >> 2][d & 3], acc);
+                sc[qq][m] = fminf(fmaf(bz[qq][m], LOG2E, acc), clampv[m]);
+            }
+        }
+        // ---- softmax over the keys (lanes x NK), the 4 queries interleaved
+        float inv[QW];
+#pragma unroll
+        for (int qq = 0; qq < QW; ++qq) {
+            float mx = sc[qq][0];
+#pragma unroll
+            for (int m = 1; m < NK; ++m) mx = fmaxf(mx, sc[qq][m]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < NK; ++m) {
+                const float pv = __builtin_amdgcn_exp2f(sc[qq][m] - mx);
+                sc[qq][m] = pv;
+                sm += pv;
+            }
+            inv[qq] = 1.0f / wave_sum(sm);
+        }
+#pragma unroll
+        for (int qq = 0; qq < QW; ++qq)
+#pragma unroll
+            for (int m = 0; m < NK; ++m) pww[qq * LP + lane + 64 * m] = sc[qq][m];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- PV, channels 0..15: lane = (query, channel quad, key quarter)
+        const int qq = lane >> 4, qi = qb + qq;
+        const float myinv = qq == 0 ? inv[0] : (qq == 1 ? inv[1] : (qq == 2 ? inv[2] : inv[3]));
+        const float* pr = pww + qq * LP;
+        const long long orow = ((long long)b * L + min(qi, L - 1)) * H * D + (long long)h * D;
+        {
+            const int dg = (lane >> 2) & 3, kg = lane & 3;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int k = kg; k < L; k += 4) {
+                const float w = pr[k];
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(Vs + (size_t)k * DP + dg * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(w, v4[c], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] += __shfl_xor(acc[c], 1, 64);
+                acc[c] += __shfl_xor(acc[c], 2, 64);
+            }
+            if (kg == 0 && qi < q_end) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = acc[c] * myinv;
+                    if (gate) v *= 1.0f / (1.0f + expf(-gate[orow + dg * 4 + c]));
+                    out[orow + dg * 4 + c] = v;
+                }
+            }
+        }
+        // ---- channel 16: lane = (query, key sixteenth)
+        {
+            const int kg = lane & 15;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int k = kg; k < L; k += 16) acc = fmaf(pr[k], Vs[(size_t)k * DP + 16], acc);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            if (kg == 0 && qi < q_end) {
+                float v = acc * myinv;
+                if (gate) v *= 1.0f / (1.0f + expf(-gate[orow + 16]));
+                out[orow + 16] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -664,9 +753,32 @@ extern "C" int abx_seq_attn_fwd(const float* qkv, const float* bias, const float
                                 int B, int L, int H, int D, float scale, hipStream_t st) {
     ABX_REQUIRE(qkv && bias && out && B > 0 && L > 0 && H > 0, "abx_seq_attn_fwd: bad args");
     ABX_REQUIRE(D == 17, "abx_seq_attn_fwd: head dim must be 17 (544 / 32)");
-    const size_t lds = (size_t)2 * L * D * sizeof(float);
-    ABX_REQUIRE(lds <= 64 * 1024, "abx_seq_attn_fwd: L too large");
-    hipLaunchKernelGGL((seq_attn_kernel<17>), dim3((L + 255) / 256, H, B), dim3(256), lds, st, qkv, bias, keymask, gate, out, L,
-                       H, scale);
-    return abx_check_launch("abx_seq_attn_fwd");
+    ABX_REQUIRE(H <= 65535 && B <= 65535, "abx_seq_attn_fwd: grid too large");
+    const int nk = (L + 63) / 64;
+    ABX_REQUIRE(nk <= 12, "abx_seq_attn_fwd: L too large (L <= 716)");
+    const int nkt = nk <= 2 ? 2 : (nk <= 4 ? 4 : (nk <= 6 ? 6 : (nk <= 8 ? 8 : 12)));       // keys per lane of the instantiation
+    const int nt = nkt <= 6 ? 1024 : (nkt <= 8 ? 512 : 256);
+    // one workgroup per (b, h) (every wave passes over 4 queries at a time); long complexes split the queries
+    const int nb = (L + 511) / 512;
+    const int qblk = (((L + nb - 1) / nb) + 3) / 4 * 4;
+    const size_t lds = ((size_t)2 * L * 20 + (size_t)(nt / 64) * 4 * nkt * 64) * sizeof(float);
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_seq_attn_fwd: L too large for the LDS-resident K / V (L <= 716)");
+    const dim3 grid((L + qblk - 1) / qblk, H, B), block(nt);
+    static thread_local bool configured[5] = {false, false, false, false, false};
+    auto launch = [&](auto kern, int id) -> int {
+        if (!configured[id]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+            if (e != hipSuccess) { abx_set_error("abx_seq_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
+            configured[id] = true;
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, st, qkv, bias, keymask, gate, out, L, H, scale, qblk);
+        return abx_check_launch("abx_seq_attn_fwd");
+    };
+    switch (nkt) {
+        case 2: return launch(&seq_attn2_kernel<2, 1024>, 0);
+        case 4: return launch(&seq_attn2_kernel<4, 1024>, 1);
+        case 6: return launch(&seq_attn2_kernel<6, 1024>, 2);
+        case 8: return launch(&seq_attn2_kernel<8, 512>, 3);
+        default: return launch(&seq_attn2_kernel<12, 256>, 4);
+    }
 }

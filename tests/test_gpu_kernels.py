@@ -467,14 +467,19 @@ def test_tri_attn_all_keys_masked_row_and_spike(ops, exact, L, spike):
         check(out.view(B, L, L, C), o, 5e-6, f'tri_attn mask all={bool(mask.all())}')
 
 
-def test_seq_attn(ops):
+@pytest.mark.parametrize('L', [52, 131, 230, 402])
+def test_seq_attn(ops, L):
+    """L = 52: one key per lane slot, partial; 131: three key slots (4-slot instantiation), one query block; 230: two query
+    blocks of 128; 402: three query blocks, 7 key slots (8-slot instantiation).  One sample has every key masked but two."""
     from oracle import abx_oracle as O
-    B, L, H, D = 2, 52, 32, 17
+    B, H, D = 2, 32, 17
     qkv = torch.randn(B, L, H, 3 * D, generator=g(34))
     bias = torch.randn(B, H, L, L, generator=g(35))
     gate = torch.randn(B, L, H * D, generator=g(36))
     mask = torch.rand(B, L, generator=g(37)) > 0.2
-    out = torch.empty(B * L, H * D, device=DEV)
+    mask[1, 2:] = False
+    mask[1, :2] = True
+    out = torch.full((B * L, H * D), float('nan'), device=DEV)
     ops.seq_attn(qkv.view(B * L, -1).to(DEV), bias.to(DEV), mask.float().to(DEV), gate.view(B * L, -1).to(DEV), out, B, L)
     t = qkv.permute(0, 2, 1, 3)[:, None].double()
     q, k, v = torch.chunk(t, 3, dim=-1)

@@ -215,6 +215,11 @@ def main():
         f = torch.empty(M2, 128, device=DEV)
         ms = timeit(lambda: ops.opm_features(lr, f, Bc, L, 64))
         rec('opm_features', ms, 0, 4.0 * M2 * 128)
+        qkv, gate = r(M1, 32 * 51), r(M1, 544)
+        biasT = r(Bc, 32, LL)
+        o5 = torch.empty(M1, 544, device=DEV)
+        ms = timeit(lambda: ops.seq_attn(qkv, biasT, torch.ones(Bc, L, device=DEV), gate, o5, Bc, L))
+        rec('seq_attn', ms, 4.0 * Bc * 32 * LL * 17, 4.0 * Bc * 32 * LL)
     od = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out')
     os.makedirs(od, exist_ok=True)
     open(os.path.join(od, 'kbench.txt'), 'w').write('\n'.join(out) + '\n')
