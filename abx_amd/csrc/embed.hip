@@ -204,6 +204,26 @@ __global__ __launch_bounds__(256) void opm_features_kernel(const float* __restri
     feat[p * 2 * C + C + c] = lv - rv;
 }
 
+// the same with 16-byte accesses: thread per (b, i, j, 4 channels); a pair row leaves as two contiguous C*4-byte segments
+__global__ __launch_bounds__(256) void opm_features4_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                            long long ld, float* __restrict__ feat, int B, int L, int C4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * L * L * C4) return;
+    const int c4 = (int)(idx % C4);
+    const long long p = idx / C4;
+    const int j = (int)(p % L);
+    const long long bi = p / L;
+    const int b = (int)(bi / L);
+    const f32x4 lv = *reinterpret_cast<const f32x4*>(left + ((long long)b * L + j) * ld + c4 * 4);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(right + bi * ld + c4 * 4);
+    f32x4 pr, df;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pr[c] = lv[c] * rv[c]; df[c] = lv[c] - rv[c]; }
+    float* o = feat + p * (8 * C4) + c4 * 4;
+    *reinterpret_cast<f32x4*>(o) = pr;
+    *reinterpret_cast<f32x4*>(o + 4 * C4) = df;
+}
+
 __global__ void pair_mask_kernel(const float* __restrict__ mask, float* __restrict__ out, int B, int L, int Lp) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)B * L * Lp) return;
@@ -382,6 +402,14 @@ extern "C" int abx_opm_features(const float* left, const float* right, long long
                                 hipStream_t st) {
     ABX_REQUIRE(left && right && feat && B > 0 && L > 0 && C > 0, "abx_opm_features: bad args");
     const long long total = (long long)B * L * L * C;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (C % 4 == 0 && ld % 4 == 0 && al16(left) && al16(right) && al16(feat)) {
+        ABX_REQUIRE((total / 4 + 255) / 256 < (1LL << 31), "abx_opm_features: grid too large");
+        hipLaunchKernelGGL(opm_features4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, left, right, ld, feat, B, L,
+                           C / 4);
+        return abx_check_launch("abx_opm_features");
+    }
+    ABX_REQUIRE((total + 255) / 256 < (1LL << 31), "abx_opm_features: grid too large");
     hipLaunchKernelGGL(opm_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, left, right, ld, feat, B, L, C);
     return abx_check_launch("abx_opm_features");
 }

@@ -31,12 +31,14 @@ GEMM_EXACT = False   # True: every GEMM on the exact fp32 MFMA kernel (v_mfma_f3
                      # split-bf16 kernels of csrc/gemm3.hip (fp32-accurate)
 
 
-def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False, split=False, exact=None, a_split=False, dual=False):
+def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False, split=False, exact=None, a_split=False, dual=False, out_ln=False):
     """Name of the kernel instantiation abx_gemm launches for a problem (mirror of the selection in csrc/gemm.hip and
     csrc/gemm3.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
     b = lambda x: 'true' if x else 'false'
     if dual:
         return 'gemm3_dual_kernel<128, 96, 32, 96, 3>'
+    if out_ln:
+        return 'gemm3_oln_kernel<128, 128, 32, 128, 3>'
     exact = 1 if GEMM_EXACT else int(exact or 0)
     blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
     wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128

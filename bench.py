@@ -87,7 +87,8 @@ class OpTimer:
             N = B.shape[-1]
             c_planes = C.dtype == torch.int16
             kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
-                                             split=kw.get('B3') is not None, exact=kw.get('exact'), dual=kw.get('dual') is not None)
+                                             split=kw.get('B3') is not None, exact=kw.get('exact'), dual=kw.get('dual') is not None,
+                                             out_ln=kw.get('out_ln') is not None)
             K2 = kw['dual'][0].shape[-1] if kw.get('dual') is not None else 0
             return kern, 2.0 * nb * M * N * (K + K2), 4.0 * nb * (M * (K + K2)) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * (K + K2) * N
         if name == 'tri_attn':
@@ -100,7 +101,7 @@ class OpTimer:
         return name, 0.0, 0.0
 
     def __enter__(self):
-        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name')
+        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel')
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
             if callable(fn) and not name.startswith('_') and name not in skip and getattr(fn, '__module__', '') == self.ops.__name__:
