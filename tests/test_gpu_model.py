@@ -220,8 +220,11 @@ def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_di
     """Driver-level parity with the split-bf16 kernels active (L = 112, 3 samples: every GEMM, the plane contraction and the
     triangle attention run on the bf16 matrix cores), TEACHER-FORCED (SURVEY §7 hard part 1a): the warm-up call and every grid
     point of a 3-point trajectory start from the ORACLE's state (rigids_t, seq_t, self-conditioning tensors), so each call and
-    each reverse step is compared on identical inputs at 1e-4-class tolerances, for both HIP arithmetic paths.  Then the
-    free-running HIP sampler against the free-running oracle under the same injected noise: tokens exact at every step."""
+    each reverse step is compared on identical inputs at 1e-4-class tolerances, for both HIP arithmetic paths.  Inside a call the
+    two recycles feed DISCRETE decisions back (distogram bins of prev_pos, argmax tokens): both sides are traced, and a sample whose
+    recycle decisions differ from the oracle's is excused from the tight comparison only if every difference is a genuine tie (a
+    pseudo-beta distance within 1e-3 A of a bin boundary / a logit margin below 1e-3) and at most one sample per call is affected.
+    Then the free-running HIP sampler against the free-running oracle under the same injected noise: tokens exact at every step."""
     from oracle import abx_oracle as O
     from abx_amd import sampler, ops
     from abx_amd.model.abx import get_prev
@@ -242,21 +245,77 @@ def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_di
     dt = torch.tensor(1 / num_t)
     steps = np.linspace(0.01, 1.0, num_t)[::-1]
 
+    import abx_amd.model.abx as abx_mod
+
+    class trace_recycles:
+        """Records (distogram bins, argmax tokens, + for the oracle: pseudo-beta distances and logits) at every get_prev of a call."""
+        def __init__(self, mod, oracle):
+            self.mod, self.oracle, self.rec = mod, oracle, []
+
+        def __enter__(self):
+            self.orig = self.mod.get_prev
+
+            def wrapped(batch, value, conf):
+                out = self.orig(batch, value, conf)
+                item = dict(bins=out['prev_pos'].detach().cpu().clone(), seq_0=value['heads']['sequence_module']['seq_0'].detach().cpu().clone())
+                if self.oracle:
+                    pb = O.pseudo_beta_v2(value['heads']['folding']['final_atom_positions']).double()
+                    item['dist'] = (pb[:, :, None] - pb[:, None]).norm(dim=-1)
+                    item['logits'] = value['heads']['sequence_module']['logits'].double().clone()
+                self.rec.append(item)
+                return out
+            self.mod.get_prev = wrapped
+            return self
+
+        def __exit__(self, *exc):
+            self.mod.get_prev = self.orig
+
+    def oracle_call(state):
+        with trace_recycles(O, True) as tr:
+            r = O.score_network(params, state, cfg, oracle_diffuser)
+        return r, tr.rec
+
     def hip_call(state, exact):
         """One HIP ScoreNetwork call on a device copy of the oracle's state."""
         bb = to_dev({k: (v.clone() if torch.is_tensor(v) else v) for k, v in state.items()})
         ops.GEMM_EXACT = exact
         try:
-            r = model(bb)
+            with trace_recycles(abx_mod, False) as tr:
+                r = model(bb)
             torch.cuda.synchronize()
         finally:
             ops.GEMM_EXACT = False
-        return bb, r
+        return bb, r, tr.rec
 
-    def compare_call(tag, state_before, ro, state_after):
+    def tied_samples(name, htrace, otrace):
+        """Samples whose recycle decisions differ from the oracle's; every difference must be a tie."""
+        assert len(htrace) == len(otrace) == cfg.model.num_recycle
+        tied = torch.zeros(B, dtype=torch.bool)
+        for r, (hh, oo) in enumerate(zip(htrace, otrace)):
+            mism = hh['bins'] != oo['bins']
+            if mism.any():
+                assert float((oo['dist'][mism][:, None] - breaks[None]).abs().min(dim=1).values.max()) < 1e-3, f'{name}: recycle {r} bins'
+                assert int((hh['bins'][mism] - oo['bins'][mism]).abs().max()) == 1
+                tied |= mism.flatten(1).any(dim=1)
+            ms = hh['seq_0'] != oo['seq_0']
+            if ms.any():
+                top2 = oo['logits'][ms].topk(2, dim=-1).values
+                assert float((top2[:, 0] - top2[:, 1]).max()) < 1e-3, f'{name}: recycle {r} tokens'
+                tied |= ms.any(dim=1)
+        assert int(tied.sum()) <= 1, f'{name}: {int(tied.sum())} samples hit a tie inside the call'
+        return tied
+
+    def compare_call(tag, state_before_all, ro_all, state_after_all, otrace):
         for exact in (False, True):
-            bb, rh = hip_call(state_before, exact)
+            bb_all, rh_all, htrace = hip_call(state_before_all, exact)
             name = f'{tag} {"exact" if exact else "split"}'
+            keep = ~tied_samples(name, htrace, otrace)
+
+            def pick(tree):
+                return {k: (pick(v) if isinstance(v, dict) else
+                            (v[keep.to(v.device)] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v)) for k, v in tree.items()}
+            rh, ro, bb = pick(rh_all), pick(ro_all), pick(bb_all)
+            state_before, state_after = pick(state_before_all), pick(state_after_all)
             f, fr = rh['heads']['folding'], ro['heads']['folding']
             assert torch.equal(rh['heads']['sequence_module']['seq_0'].cpu(), ro['heads']['sequence_module']['seq_0']), name + ' seq_0'
             assert torch.equal(bb['seq_t'].cpu(), state_after['seq_t']), name + ' seq_t after the call'
@@ -279,14 +338,13 @@ def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_di
                 dist = (pb[:, :, None] - pb[:, None]).norm(dim=-1)
                 assert float((dist[mism][:, None] - breaks[None]).abs().min(dim=1).values.max()) < 1e-3
                 assert int((hip_bins[mism] - ora_bins[mism]).abs().max()) == 1
-        return rh
 
     clone = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
     # ---- warm-up call (inference.py:209-211): fp32 t, no self-conditioning state yet
     st = O.set_t_feats(clone(cpu0), oracle_diffuser, steps[0], torch.ones(B))
     before = clone(st)
-    ro = O.score_network(params, st, cfg, oracle_diffuser)
-    compare_call('warm-up', before, ro, st)
+    ro, otr = oracle_call(st)
+    compare_call('warm-up', before, ro, st, otr)
     st.update(O.get_prev(st, ro, cfg))
     # ---- grid points
     for k, t in enumerate(steps):
@@ -294,8 +352,8 @@ def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_di
             t_ = torch.tile(torch.tensor(t), (B,))
             st = O.set_t_feats(st, oracle_diffuser, t_, torch.ones(B))
         before = clone(st)
-        ro = O.score_network(params, st, cfg, oracle_diffuser)
-        compare_call(f'grid point {k}', before, ro, st)
+        ro, otr = oracle_call(st)
+        compare_call(f'grid point {k}', before, ro, st, otr)
         if t > 0.01:
             fo = ro['heads']['folding']
             st.update(O.get_prev(st, ro, cfg))
