@@ -138,6 +138,35 @@ def test_short_trajectory_matches_reference_golden(gpu_model, cfg):
     assert len(only_last) == 1 and torch.equal(only_last[0]['seq'], traj[-1]['seq'])
 
 
+def test_hip_built_igso3_tables_run_the_golden_trajectory(params, cfg, tmp_path):
+    """every other model-level test injects reference-pinned IGSO(3) tables (set_tables).  Here the tables come
+    from abx_igso3_tables (the product's default path: FullDiffuser.to(device) with an empty cache directory) and the reference's
+    recorded num_t = 4 trajectory is replayed under its own noise: tokens exact at every step, frames / atoms at the tolerance of
+    the pinned-table test (the table entries a trajectory visits are the well-conditioned ones)."""
+    import copy
+    from abx_amd import sampler
+    from abx_amd.model.abx import ScoreNetwork
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    dc = copy.deepcopy(cfg.diffuser)
+    dc.so3.cache_dir = str(tmp_path / 'igso3_cache')            # empty: the tables are built by the HIP kernel
+    D = FullDiffuser(dc).to(DEV)
+    assert os.path.exists(os.path.join(D._cache_path(), 'score_norms.npy'))
+    model = ScoreNetwork(cfg.model, D)
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).eval()
+    tj = load_npz('traj_tiny.npz')
+    b = to_dev(feat_batch_from_golden(load_npz('feat_tiny.npz')))
+
+    def noise_fn(k):
+        return dict(z_rot=tt(tj[f'n{k}.z_rot']).to(DEV), z_trans=tt(tj[f'n{k}.z_trans']).to(DEV), jumps=tt(tj[f'n{k}.jumps']).to(DEV))
+
+    traj = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=4, noise_fn=noise_fn)
+    for k, d in enumerate(traj):
+        assert np.array_equal(d['seq'].cpu().numpy(), tj[f'k{k}.seq']), f'step {k}: tokens differ'
+        close(d['atom14_results'], tj[f'k{k}.atom14'], 5e-3, 1e-4, f'step {k} atom14')
+    close(traj[-1]['rigids_t'], tj['final.rigids_t'], 2e-3, 1e-4, 'final rigids')
+
+
 def _synthetic_batch(D, name, B, seed=3, n_masked_tail=0, dev=DEV):
     from abx_amd import synthetic, features
     w = synthetic.WORKLOADS[name] if isinstance(name, str) else name
