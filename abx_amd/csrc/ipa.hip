@@ -96,6 +96,13 @@ __global__ __launch_bounds__(256) void ipa_pack_kernel(const float* __restrict__
 // LDS row stride of the logits [IQ * HG][LR]: a multiple of 32 plus 12, so the B1 reads of one wave (2 heads x 12 keys) fall
 // into distinct banks
 __host__ __device__ inline int ipa_row_stride(int L) { return ((L + 31) / 32) * 32 + 12; }
+constexpr int RED_I = IQ * 4 + 4;                       // floats per (key group, item) slot of the B1 fold: 48 + 4 pad
+constexpr int RED_G = (HG * VREC / 4) * RED_I + 4;      // floats per key group: 40 slots + 4 pad
+// floats of the logits region [IQ * HG][LR]; the fold of phase B1 reuses it as [6 key groups][40 items][IQ][4]
+__host__ __device__ inline size_t ipa_logits_floats(int L) {
+    const size_t lgf = (size_t)IQ * HG * ipa_row_stride(L), redf = (size_t)6 * RED_G;
+    return lgf > redf ? lgf : redf;
+}
 
 // ---- kernel 1: attention weights + scalar / point outputs ----------------------------------------------------------------
 // One workgroup per (b, IQ = 12 query residues, group of 4 heads); two workgroups per CU (78 KB of LDS each at L = 352) so that
@@ -105,7 +112,7 @@ __host__ __device__ inline int ipa_row_stride(int L) { return ((L + 31) / 32) * 
 //   softmax  one wave per query (its 4 head rows together), shuffle max / sum; the normalised weights go to LDS and to
 //            attn[b][i][head group][j][4] (16 contiguous bytes per lane): the slab kernel streams them
 //   phase B1 scalar + point outputs: lane = (h, 4 of the 40 channels) x 12 key groups inside ONE wave, 16-byte loads of V
-//            (software-pipelined, first round requested before the softmax), key groups folded with shuffles (fixed order)
+//            (software-pipelined, first round requested before the softmax), key groups folded through LDS in a fixed order
 //   tail     points back to the local frame (r3.invert_rigids, r3.py:54-59), norms sqrt(sum^2 + 1e-8)
 __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float* __restrict__ qpack, const float* __restrict__ kpack,
                                                                      const float* __restrict__ vpack, const float* __restrict__ bias2d,
@@ -115,11 +122,16 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LR = ipa_row_stride(L);
     float* lg = smem;                                           // [IQ * HG][LR] logits -> attention weights
-    float* opt = smem + (size_t)IQ * HG * LR;                   // [IQ][HG][VREC] scalar + point outputs (global frame)
+    float* opt = smem + ipa_logits_floats(L);                   // [IQ][HG][VREC] scalar + point outputs (global frame)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int hg = blockIdx.x % NHG, h0 = hg * HG;
-    const int iblk = blockIdx.x / NHG, NIB = gridDim.x / NHG;
+    // 1-D grid, XCD x (= blockIdx & 7: workgroups are dealt round-robin to the 8 XCDs) owns the samples b = x, x + 8, ...: the
+    // K / V packs of a sample and the bias lines shared by its three head groups are fetched into ONE L2 instead of eight
+    const int NIB = (L + IQ - 1) / IQ, per_b = NIB * NHG;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / per_b) * 8 + xcd, wb = slot % per_b;
+    if (b >= B) return;
+    const int hg = wb % NHG, h0 = hg * HG;
+    const int iblk = wb / NHG;
     const int i0 = iblk * IQ;
     const int niq = min(IQ, L - i0);
 
@@ -244,18 +256,52 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
                 }
             }
         }
-        // fold the key groups: (g, g + 6), then (g, g + 3), then g0 + g1 + g2 -> lanes 0..4 (out-of-range sources wrap into
-        // lanes whose results are never used)
+        // fold the key groups through the (now free) logits region in three rounds, (g, g + 6), then (g, g + 3), then
+        // (g0 + g1) + g2: fixed order, no long shuffle chains (their live ranges spilled)
+        float* red = lg;                                    // [6 key groups][40 items][IQ][4] (+ padding)
+        auto slot_of = [&](int g) { return red + (size_t)g * RED_G + (size_t)item * RED_I; };     // padded strides: distinct banks
+        __syncthreads();                                    // every wave has consumed its weights
+        if (jg >= 6 && jg < NJG) {
 #pragma unroll
-        for (int iq = 0; iq < IQ; ++iq)
+            for (int iq = 0; iq < IQ; ++iq) *reinterpret_cast<f32x4*>(slot_of(jg - 6) + iq * 4) = acc[iq];
+        }
+        __syncthreads();
+        if (jg < 6) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float x = acc[iq][c];
-                x += __shfl(x, lane + 6 * IPW, 64);
-                x += __shfl(x, lane + 3 * IPW, 64);
-                const float x1 = __shfl(x, lane + IPW, 64), x2 = __shfl(x, lane + 2 * IPW, 64);
-                acc[iq][c] = (x + x1) + x2;
+            for (int iq = 0; iq < IQ; ++iq) {
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(slot_of(jg) + iq * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[iq][c] += o4[c];
             }
+        }
+        __syncthreads();
+        if (jg >= 3 && jg < 6) {
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) *reinterpret_cast<f32x4*>(slot_of(jg - 3) + iq * 4) = acc[iq];
+        }
+        __syncthreads();
+        if (jg < 3) {
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) {
+                const f32x4 o4 = *reinterpret_cast<const f32x4*>(slot_of(jg) + iq * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[iq][c] += o4[c];
+            }
+        }
+        __syncthreads();
+        if (jg == 1 || jg == 2) {
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) *reinterpret_cast<f32x4*>(slot_of(jg - 1) + iq * 4) = acc[iq];
+        }
+        __syncthreads();
+        if (jg == 0) {
+#pragma unroll
+            for (int iq = 0; iq < IQ; ++iq) {
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(slot_of(0) + iq * 4), x2 = *reinterpret_cast<const f32x4*>(slot_of(1) + iq * 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[iq][c] = (acc[iq][c] + x1[c]) + x2[c];
+            }
+        }
         if (jg == 0) {
 #pragma unroll
             for (int iq = 0; iq < IQ; ++iq) *reinterpret_cast<f32x4*>(opt + (size_t)(iq * HG + hl1) * VREC + c41 * 4) = acc[iq];
@@ -371,7 +417,7 @@ extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float*
     ABX_REQUIRE(qpack && kpack && vpack && bias2d && z && mask && rots && trans && point_weights && attn_ws && feat,
                 "abx_ipa_attn: null");
     ABX_REQUIRE(B > 0 && L > 0 && B <= 65535 && (long long)B * L < (1ll << 31), "abx_ipa_attn: bad sizes");
-    const size_t lds = ((size_t)IQ * HG * ipa_row_stride(L) + IQ * HG * VREC) * sizeof(float);
+    const size_t lds = (ipa_logits_floats(L) + IQ * HG * VREC) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_attn: L too large for LDS-resident logits");
     static thread_local bool configured = false;
     if (!configured) {
@@ -380,7 +426,9 @@ extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float*
         if (e != hipSuccess) { abx_set_error("abx_ipa_attn: hipFuncSetAttribute failed"); return (int)e; }
         configured = true;
     }
-    hipLaunchKernelGGL(ipa_weights_kernel, dim3(((L + IQ - 1) / IQ) * NHG, B), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, mask,
+    const long long nwg = (long long)((B + 7) / 8) * 8 * ((L + IQ - 1) / IQ) * NHG;
+    ABX_REQUIRE(nwg < (1LL << 31), "abx_ipa_attn: grid too large");
+    hipLaunchKernelGGL(ipa_weights_kernel, dim3((unsigned)nwg), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, mask,
                        rots, trans, point_weights, attn_ws, feat, B, L);
     int rc = abx_check_launch("abx_ipa_attn(weights)");
     if (rc) return rc;
