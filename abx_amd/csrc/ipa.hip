@@ -411,29 +411,40 @@ extern "C" long long abx_ipa_attn_workspace_bytes(int B, int L) {
     return (long long)B * L * L * H * sizeof(float);
 }
 
-extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
-                            const float* mask, const float* rots, const float* trans, const float* point_weights, float* attn_ws,
-                            float* feat, int B, int L, hipStream_t st) {
-    ABX_REQUIRE(qpack && kpack && vpack && bias2d && z && mask && rots && trans && point_weights && attn_ws && feat,
-                "abx_ipa_attn: null");
-    ABX_REQUIRE(B > 0 && L > 0 && B <= 65535 && (long long)B * L < (1ll << 31), "abx_ipa_attn: bad sizes");
+extern "C" int abx_ipa_weights(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* mask,
+                               const float* rots, const float* trans, const float* point_weights, float* attn_ws, float* feat, int B,
+                               int L, hipStream_t st) {
+    ABX_REQUIRE(qpack && kpack && vpack && bias2d && mask && rots && trans && point_weights && attn_ws && feat, "abx_ipa_weights: null");
+    ABX_REQUIRE(B > 0 && L > 0 && B <= 65535 && (long long)B * L < (1ll << 31), "abx_ipa_weights: bad sizes");
     const size_t lds = (ipa_logits_floats(L) + IQ * HG * VREC) * sizeof(float);
-    ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_attn: L too large for LDS-resident logits");
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_weights: L too large for LDS-resident logits");
     static thread_local bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_weights_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) { abx_set_error("abx_ipa_attn: hipFuncSetAttribute failed"); return (int)e; }
+        if (e != hipSuccess) { abx_set_error("abx_ipa_weights: hipFuncSetAttribute failed"); return (int)e; }
         configured = true;
     }
     const long long nwg = (long long)((B + 7) / 8) * 8 * ((L + IQ - 1) / IQ) * NHG;
-    ABX_REQUIRE(nwg < (1LL << 31), "abx_ipa_attn: grid too large");
+    ABX_REQUIRE(nwg < (1LL << 31), "abx_ipa_weights: grid too large");
     hipLaunchKernelGGL(ipa_weights_kernel, dim3((unsigned)nwg), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, mask,
                        rots, trans, point_weights, attn_ws, feat, B, L);
-    int rc = abx_check_launch("abx_ipa_attn(weights)");
-    if (rc) return rc;
+    return abx_check_launch("abx_ipa_weights");
+}
+
+extern "C" int abx_ipa_pair(const float* attn_ws, const float* z, float* feat, int B, int L, hipStream_t st) {
+    ABX_REQUIRE(attn_ws && z && feat && B > 0 && L > 0 && (long long)B * L < (1ll << 31), "abx_ipa_pair: bad args");
     const long long rows = (long long)B * L;
     hipLaunchKernelGGL(ipa_pair_kernel, dim3((unsigned)((rows + PAIR_WAVES - 1) / PAIR_WAVES)), dim3(PAIR_WAVES * 64), 0, st, attn_ws, z,
                        feat, rows, L);
-    return abx_check_launch("abx_ipa_attn(pair slab)");
+    return abx_check_launch("abx_ipa_pair");
+}
+
+extern "C" int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
+                            const float* mask, const float* rots, const float* trans, const float* point_weights, float* attn_ws,
+                            float* feat, int B, int L, hipStream_t st) {
+    ABX_REQUIRE(z != nullptr, "abx_ipa_attn: null");
+    const int rc = abx_ipa_weights(qpack, kpack, vpack, bias2d, mask, rots, trans, point_weights, attn_ws, feat, B, L, st);
+    if (rc) return rc;
+    return abx_ipa_pair(attn_ws, z, feat, B, L, st);
 }

@@ -406,7 +406,8 @@ class Engine:
         for _ in range(ic.num_layer):
             ops.gemm(s, P.wt[P_IPA + 'attention_module.proj'], proj, bias=P.b[P_IPA + 'attention_module.proj'], exact=1)
             ops.ipa_pack(proj, cur_R, cur_t, qpack, kpack, vpack, Bc, L, P.ipa_ws)
-            ops.ipa_attn(qpack, kpack, vpack, bias2d, zi, mask_f, cur_R, cur_t, P.ipa_pw, ifeat, Bc, L, attn_ws=attn_ws)
+            ops.ipa_weights(qpack, kpack, vpack, bias2d, mask_f, cur_R, cur_t, P.ipa_pw, attn_ws, ifeat, Bc, L)
+            ops.ipa_pair(attn_ws, zi, ifeat, Bc, L)
             _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)
             ops.layernorm(s, *P.ln(P_IPA + 'attention_layer_norm'), out=s)
             _lin(P, P_IPA + 'transition_module.0', s, h1, act=1)

@@ -328,6 +328,18 @@ def seq_attn(qkv, biasT, keymask, gate, out, B, L, H=32, D=17):
     return out
 
 
+def ipa_weights(qpack, kpack, vpack, bias2d, mask, rots, trans, pw, attn_ws, feat, B, L):
+    """First launch of the IPA core: attention weights -> attn_ws, scalar / point outputs -> feat[:, :576]."""
+    assert attn_ws.numel() >= B * L * L * 12 and attn_ws.is_contiguous()
+    check(_lib.load().abx_ipa_weights(_p(qpack), _p(kpack), _p(vpack), _p(bias2d), _p(mask), _p(rots), _p(trans), _p(pw), _p(attn_ws),
+                                      _p(feat), B, L, _stream()), 'abx_ipa_weights')
+
+
+def ipa_pair(attn_ws, z, feat, B, L):
+    """Second launch: attention over the pair slab z (B*L*L, 128) -> feat[:, 576:]."""
+    check(_lib.load().abx_ipa_pair(_p(attn_ws), _p(z), _p(feat), B, L, _stream()), 'abx_ipa_pair')
+
+
 def ipa_qpack_numel(B, L):
     """floats in the Q pack of abx_ipa_pack (query rows padded to blocks of 12)."""
     return _lib.load().abx_ipa_qpack_bytes(B, L) // 4

@@ -96,8 +96,14 @@ class OpTimer:
             return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
         if name == 'ipa_attn':
             Bc, L = args[10], args[11]
-            # two launches (ipa_weights_kernel + ipa_pair_kernel); bytes: pair slab + pair bias + the weights written and re-read
             return 'ipa_attn (weights + pair slab kernels)', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12 + 24)
+        if name == 'ipa_pair':
+            Bc, L = args[3], args[4]
+            # the HBM stream of the IPA layer: the pair slab read once + the 12 weights per pair
+            return 'ipa_pair_kernel', 2.0 * Bc * L * L * 12 * 128, 4.0 * Bc * L * L * (128 + 12)
+        if name == 'ipa_weights':
+            Bc, L = args[10], args[11]
+            return 'ipa_weights_kernel', 2.0 * Bc * L * L * 12 * (28 + 40), 4.0 * Bc * L * L * (12 + 12)
         return name, 0.0, 0.0
 
     def __enter__(self):
@@ -494,7 +500,7 @@ def main():
         tot_ms = sum(s[1] for s in summ)
         name, ms, calls, fl, by = summ[0]
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
-        if name.startswith('ipa_attn'):
+        if name.startswith('ipa_'):
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
         elif name.startswith('gemm3_kernel') or name.startswith('tri_attn3') or name.startswith('tri_attn4'):
             # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs six bf16 MFMA
@@ -511,6 +517,14 @@ def main():
         roof.update(frac=roof['achieved'] / roof['peak'], traffic=traffic, kernel=name, calls_per_step=calls,
                     avg_launch_ms=ms / calls, share_of_step=ms / tot_ms)
         result['roofline'] = roof
+        # the kernel north_star calls HBM-bound (the IPA pair-slab stream), priced the same way next to the dominant one
+        for nm, ms2, calls2, fl2, by2 in summ:
+            if nm == 'ipa_pair_kernel':
+                tr2 = json.load(open(pmc)).get(nm, {}).get('hbm_bytes_per_launch') if os.path.exists(pmc) else None
+                result['roofline_ipa_pair_slab'] = {
+                    'bound': 'hbm', 'achieved': by2 / (ms2 / 1e3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': by2 / (ms2 / 1e3) / 1e9 / HBM_PEAK_GBS, 'traffic': tr2, 'kernel': nm, 'calls_per_step': calls2,
+                    'avg_launch_ms': ms2 / calls2, 'share_of_step': ms2 / tot_ms}
         result['op_profile_ms'] = [{'op': s[0], 'ms': round(s[1], 3), 'calls': s[2], 'avg_ms': round(s[1] / s[2], 4),
                                     'tflops': (s[3] / (s[1] / 1e3) / 1e12 if s[3] else None)} for s in summ[:40]]
 

@@ -160,6 +160,11 @@ int abx_ipa_pack(const float* proj, const float* rots, const float* trans, float
 int abx_ipa_attn(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* z,
                  const float* mask, const float* rots, const float* trans, const float* point_weights /* [12] */,
                  float* attn_ws, float* feat, int B, int L, hipStream_t stream);
+/* the two launches of abx_ipa_attn, separately callable (profiling; feat rows: weights writes [0, 576), pair writes [576, 2112)) */
+int abx_ipa_weights(const float* qpack, const float* kpack, const float* vpack, const float* bias2d, const float* mask,
+                    const float* rots, const float* trans, const float* point_weights, float* attn_ws, float* feat, int B, int L,
+                    hipStream_t stream);
+int abx_ipa_pair(const float* attn_ws, const float* z, float* feat, int B, int L, hipStream_t stream);
 long long abx_ipa_attn_workspace_bytes(int B, int L);
 long long abx_ipa_qpack_bytes(int B, int L);   /* size of qpack: query rows padded to blocks of 12, pairs interleaved */
 
