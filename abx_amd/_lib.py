@@ -117,6 +117,7 @@ _PROTOS = {
     'abx_seq_attn_fwd': (I, [c_f, c_f, c_f, c_f, c_f, I, I, I, I, F, _S]),
     'abx_ipa_pack': (I, [c_f, c_f, c_f, c_f, c_f, c_f, I, I, F, _S]),
     'abx_ipa_attn': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
+    'abx_debug_poison_lds': (I, [C.c_uint, _S]),
     'abx_ipa_weights': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),
     'abx_ipa_pair': (I, [c_f, c_f, c_f, I, I, _S]),
     'abx_ipa_attn_workspace_bytes': (C.c_longlong, [I, I]),

@@ -37,3 +37,30 @@ extern "C" int abx_init(int device) {
     }
     return ABX_OK;
 }
+
+// Diagnostics: overwrite the LDS of every CU with a bit pattern (one 160 KB workgroup per CU slot, a few rounds), so that a test
+// can show that no kernel's result depends on what an earlier workgroup - possibly of another process sharing the GPU - left
+// in LDS (tests/test_gpu_model.py::test_results_do_not_depend_on_stale_lds).
+namespace {
+__global__ __launch_bounds__(1024) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned lds_words[];
+    constexpr int WORDS = 160 * 1024 / 4;
+    for (int i = threadIdx.x; i < WORDS; i += 1024) lds_words[i] = pattern;
+    __syncthreads();
+    // keep the stores alive and the workgroup resident for a moment
+    unsigned acc = 0;
+    for (int i = threadIdx.x; i < WORDS; i += 1024) acc ^= lds_words[i];
+    if (acc == 0x12345678u && sink) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int abx_debug_poison_lds(unsigned pattern, hipStream_t st) {
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { abx_set_error("abx_debug_poison_lds: hipFuncSetAttribute failed"); return (int)e; }
+        configured = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(256 * 4), dim3(1024), 160 * 1024, st, pattern, (unsigned*)nullptr);
+    return abx_check_launch("abx_debug_poison_lds");
+}

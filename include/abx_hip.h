@@ -31,6 +31,8 @@ int abx_version(void);
 const char* abx_last_error_string(void);
 /* device properties sanity check: returns 0 when the current device is gfx950 */
 int abx_init(int device);
+/* diagnostics: fill the LDS of every CU with `pattern` (results must not depend on stale LDS contents) */
+int abx_debug_poison_lds(unsigned pattern, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Dense contractions.  Replaces every torch Linear / LayerNorm->Linear / einsum on the path:

@@ -234,3 +234,18 @@ def test_per_sample_init_noise_is_batch_invariant():
         assert torch.equal(a[k][2:3], b[k]), k
     assert not torch.equal(b['trans_z'], c['trans_z'])
     assert features.per_sample_init_noise([], 12, seed=5) is None
+
+
+def test_design_driver_complex_list_and_sample_names(tmp_path):
+    """abx_amd.design: the complexes of a run (files + index file relative to --pdb_dir) and the per-sample output stems carry
+    GLOBAL sample ids, so the shards of different ranks never collide."""
+    from abx_amd import design, sampler
+    lst = tmp_path / 'idx.txt'
+    lst.write_text('6ct7_H_L_S\n\n# skipped\n6qd7_X_Z_F|E.pdb   # trailing comment\n')
+    got = design.complex_list(['a_H_L_A.pdb'], str(lst), '/data')
+    assert got == ['/data/a_H_L_A.pdb', '/data/6ct7_H_L_S.pdb', '/data/6qd7_X_Z_F|E.pdb']
+    assert design.complex_list(['/abs/x_H_L_A.pdb'], None, '/data') == ['/abs/x_H_L_A.pdb']
+    assert design.sample_names('6ct7_H_L_S', [0], 1) == ['6ct7_H_L_S']
+    ids = sampler.shard_sample_ids(100, 7, 8)
+    assert ids == list(range(88, 100))
+    assert design.sample_names('6qd7_X_Z_F|E', ids, 100)[:2] == ['6qd7-088_X_Z_F|E', '6qd7-089_X_Z_F|E']
