@@ -901,3 +901,54 @@ def test_design_driver_two_ranks_shard_the_samples(tmp_path):
             for c in ca:
                 fa_, fb_ = chain_feature(ca[c]), chain_feature(cb2[c])
                 assert len(fa_['str_seq']) == len(fb_['str_seq']) and np.isfinite(fb_['coords']).all(), (f, c)
+
+
+def test_results_do_not_depend_on_stale_lds(gpu_model, cfg):
+    """No kernel may read LDS it has not written: one ScoreNetwork call (L = 112: split-bf16 GEMMs, plane contraction, both
+    attentions, IPA) is repeated with the LDS of every CU overwritten (abx_debug_poison_lds: NaN pattern, then large finite
+    garbage) before EVERY launch of the library; every output must be bit-identical to the un-poisoned call."""
+    import ctypes as C
+    from abx_amd import _lib, ops, sampler
+    model, D = gpu_model
+    w = dict(L_heavy=46, L_light=40, L_antigen=26, cdr=(28, 36))
+    b0 = _synthetic_batch(D, w, B=2, n_masked_tail=2)
+    b0 = sampler.set_t_feats(b0, D, torch.full((2,), 0.5, dtype=torch.float64, device=DEV), torch.ones(2, device=DEV))
+    real = _lib.load()
+    pattern = [None]
+    count = [0]
+
+    class Poisoning:
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+            if not name.startswith('abx_') or name in ('abx_debug_poison_lds', 'abx_last_error_string', 'abx_version') or 'bytes' in name:
+                return fn
+
+            def call(*a):
+                if pattern[0] is not None:
+                    assert real.abx_debug_poison_lds(pattern[0], C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+                    count[0] += 1
+                return fn(*a)
+            return call
+
+    def run(pat):
+        pattern[0] = pat
+        try:
+            bb = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b0.items()}
+            r = model(bb)
+            torch.cuda.synchronize()
+        finally:
+            pattern[0] = None
+        f = r['heads']['folding']
+        return [r['representations']['pair'].clone(), r['representations']['seq'].clone(), f['rigids'].clone(), f['rot_score'].clone(),
+                f['final_atom14_positions'].clone(), r['heads']['sequence_module']['logits'].clone()]
+
+    orig = _lib.load
+    _lib.load = lambda: Poisoning()
+    try:
+        ref = run(None)
+        for pat in (0x7fc00000, 0x7f7fffff):
+            got = run(pat)
+            assert all(torch.equal(x, y) for x, y in zip(ref, got)), hex(pat)
+    finally:
+        _lib.load = orig
+    assert count[0] > 500
