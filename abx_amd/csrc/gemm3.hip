@@ -198,11 +198,20 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 #pragma unroll
     for (int j = 0; j < TN; ++j) offB[j] = plane_off<BN>(0, wn * WN + j * 32 + (lane & 31), h);
 
+    // a wave whose 32 rows all lie beyond M (the last row tile of a ragged M: e.g. the 4th wave of the third 128-row tile of the
+    // L = 352 contraction) takes part in the DMA and the barriers but skips its B-fragment reads and MFMAs
+    const bool rows_live = m0 + wm * WM < g.M;
+    if (!rows_live) {
+        for (int t = 0; t < nk; ++t) {
+            issue_b(min(t + 1, nk - 1));
+            issue_a(min(t + RING - 1, nk - 1));
+            wait_vm_and_barrier<0>();
+        }
+    } else
     for (int t = 0; t < nk; ++t) {
         // next tiles
         issue_b(min(t + 1, nk - 1));
         issue_a(min(t + RING - 1, nk - 1));
-
         const char* as = As + (t % RING) * A_STAGE;
         const char* bs = Bs + (t & 1) * B_STAGE;
         bf16x8 a[TM][3];
