@@ -449,7 +449,11 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 // Returns 1 when the problem is not served by this path (the caller falls back to the exact kernel).
 int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (!g.B_split || g.K % 16 != 0 || g.N <= 64) return 1;
+    // N <= 32 with split weights: the skinny projections of the pair stack (4 / 12 / 32 bias channels from 192- / 128-wide rows):
+    // HBM streams of the A operand, served by a 128 x 32 tile of the same DMA pipeline (7 blocks per CU keep the stream fed)
+    const bool narrow = g.B_split && g.N <= 32 && !g.A_split && g.sAk == 1 && !g.glu && !g.C_split && !g.A2 && !g.out_ln_w &&
+                        g.a_pair_transpose <= 0 && g.pair_Lp == 0;
+    if (!g.B_split || g.K % 16 != 0 || (g.N <= 64 && !narrow)) return 1;
     const long long mt128 = ((long long)g.M + 127) / 128;
     // exact == 2: the caller fixed the arithmetic class of this op (results must not depend on how many samples share a launch)
     if (g.exact != 2 && mt128 * (((long long)g.N + 127) / 128) * g.batch < ABX_SPLIT_MIN_TILES) return 1;
@@ -499,6 +503,14 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         const long long mt = ((long long)g.M + 127) / 128, ntn = ((long long)g.N + 95) / 96;
         hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(dual)");
+        return 0;
+    }
+    if (narrow) {
+        const long long mt = ((long long)g.M + 127) / 128;
+        dim3 grid((unsigned)(mt * g.batch), 1, 1), block(256);
+        if (g.c_transposed) hipLaunchKernelGGL((gemm3_kernel<128, 32, 32, 32, 0, true, 6>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm3_kernel<128, 32, 32, 32, 0, false, 6>), grid, block, 0, st, g);
+        *rc = abx_check_launch("abx_gemm(narrow)");
         return 0;
     }
     const long long pad128 = ((g.N + 127) / 128) * 128, pad192 = ((g.N + 191) / 192) * 192;

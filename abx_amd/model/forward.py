@@ -104,6 +104,14 @@ class Packed:
             self._split_cache[key] = self._split(self.wt[key])
         return self._split_cache[key]
 
+    def split_narrow(self, wt, key):
+        """bf16x3 image of a skinny (N <= 32) weight matrix: the pair-stack bias projections stream their 9.5 GB A operand
+        through the 128 x 32 tile of the split-bf16 GEMM (DMA pipeline) instead of the exact kernel's register-staged loads."""
+        ck = ('narrow', key)
+        if ck not in self._split_cache:
+            self._split_cache[ck] = ops.split_weights(wt) if (wt.is_cuda and wt.shape[0] % 16 == 0) else None
+        return self._split_cache[ck]
+
 
 class Workspace:
     def __init__(self, device):
@@ -126,15 +134,20 @@ class Workspace:
         return buf[:n].view(*shape)
 
 
-def _lin(P, name, x, out, **kw):
+def _lin(P, name, x, out, narrow=False, **kw):
     kw.setdefault('exact', P.gemm_mode)
-    return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), B3=P.split(name), **kw)
+    w3 = P.split(name)
+    if narrow and w3 is None and kw['exact'] == 2:
+        w3 = P.split_narrow(P.wt[name], name)
+    return ops.gemm(x, P.wt[name], out, bias=P.b.get(name), B3=w3, **kw)
 
 
-def _ln_lin(P, name, ln_name, stats, x, out, **kw):
+def _ln_lin(P, name, ln_name, stats, x, out, narrow=False, **kw):
     """out = epi(LN(x) @ W^T + b) with the LayerNorm folded into the GEMM epilogue."""
     wt, csum, bias, w3 = P.ln_linear(name, ln_name)
     kw.setdefault('exact', P.gemm_mode)
+    if narrow and w3 is None and kw['exact'] == 2:
+        w3 = P.split_narrow(wt, (name, ln_name))
     return ops.gemm(x, wt, out, bias=bias, ln=(stats, csum), B3=w3, **kw)
 
 
@@ -272,7 +285,7 @@ class Engine:
         pre = P_BLK + 'seq_attn.'
         H = c.seqformer.seq_attention_with_pair_bias.num_head
         biasT = ws.get('biasT', (Bc, H, LL))
-        _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', None, z3, biasT.transpose(1, 2))
+        _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', None, z3, biasT.transpose(1, 2), narrow=True)
         qkv = ws.get('s_a', (M1, 3 * WS_))
         sgate = ws.get('s_b', (M1, WS_))
         so = ws.get('s_c', (M1, WS_))
@@ -357,7 +370,7 @@ class Engine:
             pre = P_BLK + name + '.'
             _ln_lin(P, pre + 'qkvg', pre + 'norm', None, z2, w768)
             bT = ws.get('biasT', (Bc, 4, LL))
-            _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2))
+            _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True)
             o = w384[:M2 * 192].view(M2, 192)
             # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
             # i.e. the transpose (2 MB per sample); starting node: a padded copy only when L % 4 != 0
@@ -391,7 +404,7 @@ class Engine:
             _lin(P, P_IPA + 'proj_init_pair_act', z2, zi)
             ops.layernorm(zi, *P.ln(P_IPA + 'init_pair_layer_norm'), out=zi)
         bias2d = w384[M2 * 128:M2 * 140].view(M2, 12)
-        _lin(P, P_IPA + 'attention_module.proj_pair', zi, bias2d, alpha=P.ipa_w2d)
+        _lin(P, P_IPA + 'attention_module.proj_pair', zi, bias2d, alpha=P.ipa_w2d, narrow=True)
         attn_ws = w384[M2 * 140:M2 * 152].view(M2, 12)
         init_q = ws.get('f_iq', (M1, 4)); init_t = ws.get('f_it', (M1, 3))
         cur_q = ws.get('f_q', (M1, 4)); cur_t = ws.get('f_t', (M1, 3)); cur_R = ws.get('f_R', (M1, 9))

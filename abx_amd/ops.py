@@ -42,6 +42,8 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     exact = 1 if GEMM_EXACT else int(exact or 0)
     blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
     wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128
+    if exact != 1 and split and N <= 32 and a_kcontig and not a_split and K % 16 == 0:
+        return f'gemm3_kernel<128, 32, 32, 32, 0, {b(transposed)}, 6>'
     if exact != 1 and split and N > 64 and (blocks128 >= 256 or exact == 2) and K % 16 == 0 and (a_kcontig or a_split or M % 4 == 0):
         amode = 2 if a_split else (0 if a_kcontig else 1)
         pad128, pad192 = ((N + 127) // 128) * 128, ((N + 191) // 192) * 192

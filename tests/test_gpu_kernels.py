@@ -926,3 +926,36 @@ def test_gemm_output_layernorm(ops, N, M, exact):
     y = x.double() @ W.double() + b.double()
     ref = (y - y.mean(-1, keepdim=True)) / torch.sqrt(y.var(-1, unbiased=False, keepdim=True) + 1e-5) * ga.double() + be.double()
     check(out, ref, 5e-6, f'gemm out_ln N={N}')
+
+
+@pytest.mark.parametrize('N,K,transposed,ln', [(4, 192, True, True), (32, 192, True, True), (12, 128, False, False)])
+def test_gemm_narrow_split_tile(ops, N, K, transposed, ln):
+    """The skinny pair-stack projections (triangle-attention bias 192 -> 4, sequence-attention pair bias 192 -> 32, IPA pair
+    bias 128 -> 12) on the 128 x 32 tile of the split-bf16 GEMM: LayerNorm folded (inline statistics) or plain with alpha,
+    transposed (b, N, rows) or plain store, ragged last row tile; against fp64."""
+    ge = g(140 + N)
+    Bc, rows = 3, 37 * 37
+    x = torch.randn(Bc, rows, K, generator=ge) * 1.7 + 0.4
+    W, b = torch.randn(N, K, generator=ge) / 12, torch.randn(N, generator=ge) * 0.1
+    ga, be = 1 + 0.1 * torch.randn(K, generator=ge), 0.1 * torch.randn(K, generator=ge)
+    if ln:
+        wt, cs, bias = fold_ln(W, b, ga, be)
+        xn = (x.double() - x.double().mean(-1, keepdim=True)) / torch.sqrt(x.double().var(-1, unbiased=False, keepdim=True) + 1e-5) * ga.double() + be.double()
+        ref = xn @ W.double().t() + b.double()
+        kw = dict(ln=(None, cs), bias=bias)
+        alpha = 1.0
+    else:
+        wt, bias, alpha = W.t().contiguous().to(DEV), b.to(DEV), 0.577
+        ref = (x.double() @ W.double().t() + b.double()) * alpha
+        kw = dict(bias=bias, alpha=alpha)
+    w3 = ops.split_weights(wt)
+    assert ops.gemm_kernel_name(rows, N, K, Bc, transposed=transposed, split=True, exact=2).startswith('gemm3_kernel<128, 32, 32, 32, 0')
+    if transposed:
+        out = torch.full((Bc, N, rows), float('nan'), device=DEV)
+        ops.gemm(x.to(DEV), wt, out.transpose(1, 2), B3=w3, exact=2, **kw)
+        got = out.transpose(1, 2)
+    else:
+        out = torch.full((Bc, rows, N), float('nan'), device=DEV)
+        ops.gemm(x.to(DEV), wt, out, B3=w3, exact=2, **kw)
+        got = out
+    check(got, ref, 5e-6, f'narrow split gemm N={N}')
