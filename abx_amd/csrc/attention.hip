@@ -204,7 +204,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
                 if (a.gate) {
                     const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * (1.0f / (1.0f + expf(-gv[r])));
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * sigmoidf_(gv[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= inv;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             if (a.gate) {
                 const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * (1.0f / (1.0f + expf(-gv[r])));
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * sigmoidf_(gv[r]);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= inv;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(NT) void seq_attn2_kernel(const float* __restrict__
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float v = acc[c] * myinv;
-                    if (gate) v *= 1.0f / (1.0f + expf(-gate[orow + dg * 4 + c]));
+                    if (gate) v *= sigmoidf_(gate[orow + dg * 4 + c]);
                     out[orow + dg * 4 + c] = v;
                 }
             }
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(NT) void seq_attn2_kernel(const float* __restrict__
             for (int o = 1; o < 16; o <<= 1) acc += __shfl_xor(acc, o, 64);
             if (kg == 0 && qi < q_end) {
                 float v = acc * myinv;
-                if (gate) v *= 1.0f / (1.0f + expf(-gate[orow + 16]));
+                if (gate) v *= sigmoidf_(gate[orow + 16]);
                 out[orow + 16] = v;
             }
         }

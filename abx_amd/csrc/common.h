@@ -55,6 +55,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Gates: 1 / (1 + e^-x) as v_exp_f32 + v_rcp_f32 (1 ulp each: relative error < 3e-7) - 4 VALU instructions instead of the ~18 of
+// expf + IEEE division; the pair stack evaluates ~47 G gates per step (glu, final gate, attention gates), beside the MFMAs
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 
 #define ABX_NEG_MAX (-3.4028234663852886e38f)  // torch.finfo(float32).min

@@ -34,7 +34,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
         if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
         v = (v + bias[j]) * g.alpha;
         if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2) v = 1.0f / (1.0f + expf(-v));
+        else if (g.act == 2) v = sigmoidf_(v);
         return v;
     };
     // 4 consecutive elements along the contiguous output dimension: gate / residual reads and the store are 16-byte accesses
@@ -53,7 +53,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             f32x4 gv = load4(gt + off_g, g_vec, cnt);
             if (gsig) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) gv[c] = 1.0f / (1.0f + expf(-gv[c]));
+                for (int c = 0; c < 4; ++c) gv[c] = sigmoidf_(gv[c]);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] *= gv[c];
@@ -120,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                         float v = epi1(acc[i][j][r], ml, j);
                         if (acc2) {
                             const float gv = st2_lds[2 * ml + 1] * ((*acc2)[i][j][r] - st2_lds[2 * ml] * csum2[j]) + bias2[j];
-                            v *= 1.0f / (1.0f + expf(-gv));
+                            v *= sigmoidf_(gv);
                         }
                         acc[i][j][r] = nok ? v : 0.f;
                         sm += acc[i][j][r];
@@ -166,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                             float v = pre ? acc[i][jg + j][rq * 4 + c] : epi1(acc[i][jg + j][rq * 4 + c], ml, jg + j);
                             if (acc2 && !pre) {      // dual GEMM: times sigmoid(LN-folded gate accumulator + bias2)
                                 const float gv = st2_lds[2 * ml + 1] * ((*acc2)[i][jg + j][rq * 4 + c] - st2_lds[2 * ml] * csum2[jg + j]) + bias2[jg + j];
-                                v *= 1.0f / (1.0f + expf(-gv));
+                                v *= sigmoidf_(gv);
                             }
                             wsc[mloc * LW + j * 32 + (lane & 31)] = v;
                         }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const float gv = epi1(acc[i][(j | 1) < TN ? (j | 1) : j][rq * 4 + c], wm * WM + mloc + c, (j | 1) < TN ? (j | 1) : j);
-                                v[c] *= 1.0f / (1.0f + expf(-gv));
+                                v[c] *= sigmoidf_(gv);
                             }
                         }
                     }
