@@ -171,8 +171,12 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     const bool relu = g.a_relu != 0;
     const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
     float lshift[TM];
+    f32x2 ls2[TM], lq2[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) ls[i] = lq[i] = lshift[i] = 0.f;
+    for (int i = 0; i < TM; ++i) {
+        ls[i] = lq[i] = lshift[i] = 0.f;
+        ls2[i] = lq2[i] = (f32x2){0.f, 0.f};
+    }
 
     // prologue
     issue_a(0);
@@ -233,13 +237,18 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                 }
                 if (ln_inline) {
                     // statistics of the row from this lane's 8 k (the other k half sits in lane ^ 32), shifted by the row's
-                    // first element so that E[x^2] - mean^2 does not cancel when |mean| >> sigma
+                    // first element so that E[x^2] - mean^2 does not cancel when |mean| >> sigma.  Packed math: two elements
+                    // per VALU instruction (even / odd partial sums, folded after the loop)
                     if (t == 0) lshift[i] = __shfl(x[0], lane & 31, 64);
+                    const f32x2 sh2 = {lshift[i], lshift[i]};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        x[e] -= lshift[i];
-                        ls[i] += x[e];
-                        lq[i] = fmaf(x[e], x[e], lq[i]);
+                    for (int e = 0; e < 4; ++e) {
+                        f32x2 xp = {x[2 * e], x[2 * e + 1]};
+                        xp -= sh2;
+                        ls2[i] += xp;
+                        lq2[i] = __builtin_elementwise_fma(xp, xp, lq2[i]);
+                        x[2 * e] = xp[0];
+                        x[2 * e + 1] = xp[1];
                     }
                 }
                 if (relu) {
@@ -275,6 +284,11 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                         acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
         }
         wait_vm_and_barrier<0>();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        ls[i] = ls2[i][0] + ls2[i][1];
+        lq[i] = lq2[i][0] + lq2[i][1];
     }
     // drain the (redundant) tail DMA before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
