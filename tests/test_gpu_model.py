@@ -572,7 +572,10 @@ class _GemmSpy:
                                  (dict(L_heavy=50, L_light=44, L_antigen=24, cdr=(30, 39)), 4),      # L = 118 (L % 4 == 2)
                                  # L = 402 > 384: the 4-slot triangle-attention instantiation (4 query tiles per wave, 4 key
                                  # chunks), 7 key tasks per head and 34 query blocks in the IPA weights kernel
-                                 (dict(L_heavy=126, L_light=110, L_antigen=166, cdr=(100, 112)), 1)])
+                                 (dict(L_heavy=126, L_light=110, L_antigen=166, cdr=(100, 112)), 1),
+                                 # L = 65: the first length of the split-bf16 arithmetic class, single partial tiles everywhere
+                                 (dict(L_heavy=30, L_light=25, L_antigen=10, cdr=(15, 22)), 4),
+                                 (dict(L_heavy=80, L_light=70, L_antigen=41, cdr=(50, 61)), 2)])         # L = 191
 def test_any_length_takes_the_plane_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser, w, B):
     """residue counts that are not multiples of 4 (the real complexes are L = 230 and 261) run the triangle
     multiplication on the same glu -> bf16 planes -> plane contraction route as L = 352, through the padded pair-row maps.
@@ -581,7 +584,7 @@ def test_any_length_takes_the_plane_path_vs_oracle(gpu_model, params, cfg, oracl
     from abx_amd import sampler, ops
     model, D = gpu_model
     L = w['L_heavy'] + w['L_light'] + w['L_antigen']
-    assert L % 4 != 0 and ops.gemm_split_eligible(L * L, 128, 192, B)
+    assert L % 4 != 0 and ops.gemm_mode(L) == 2
     b = _synthetic_batch(D, w, B=B, n_masked_tail=2)
     t_ = torch.full((B,), 0.4040404040404041, dtype=torch.float64, device=DEV)
     b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
