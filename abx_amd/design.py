@@ -4,6 +4,7 @@ and write the PDB files (per step in trajectory mode, asynchronously).
 
     python -m abx_amd.design --pdb_file 6ct7_H_L_S.pdb --num_samples 100 --mode design --output_dir out/      (raw PDB, 8f-1)
     python -m abx_amd.design --workload L256 --num_samples 4 --mode trajectory --num_t 10 --output_dir out/   (synthetic complex)
+    python -m abx_amd.design --pdb_file 6ct7_H_L_S.pdb --mode optimize --optimize_steps 10 --guidance --num_samples 100     (config 4)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m abx_amd.design \
         --pdb_list diffab_test.txt --pdb_dir pdbs/ --num_samples 100 --output_dir out/                        (a test set on 8 GPUs)
 
@@ -65,6 +66,9 @@ def main(argv=None):
     ap.add_argument('--output_dir', default='design_out')
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--device', default=None, help='default: cuda:<LOCAL_RANK>')
+    ap.add_argument('--guidance', action='store_true', help='structural-violation guidance (clash + C-N bond terms, abx_clash_grad) on')
+    ap.add_argument('--guidance_scale', type=float, nargs=2, default=[1.0, 1.0], metavar=('TRANS', 'ROT'),
+                    help='step scales of the guidance gradients on the translation / rotation scores')
     ap.add_argument('--debug_one_gpu', action='store_true', help='debugging on a 1-GPU box: every rank uses cuda:0 and the gloo backend')
     a = ap.parse_args(argv)
 
@@ -88,6 +92,10 @@ def main(argv=None):
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
 
+    guide = None
+    if a.guidance:
+        from .guidance import ViolationGuidance
+        guide = ViolationGuidance(scale_trans=a.guidance_scale[0], scale_rot=a.guidance_scale[1])
     N = a.num_samples
     ids = sampler.shard_sample_ids(N, rank, world)             # the global sample ids this rank runs, for every complex
     n = len(ids)
@@ -122,7 +130,7 @@ def main(argv=None):
             diffuser.seed = a.seed
             writer = TrajectoryWriter(meta, a.output_dir, multi=a.mode == 'trajectory')
             traj = sampler.sample_fn(batch, cfg, diffuser, model, mode=a.mode, num_t=a.num_t,
-                                     sample_ids=torch.tensor(ids, device=dev, dtype=torch.int64), on_record=writer.submit)
+                                     sample_ids=torch.tensor(ids, device=dev, dtype=torch.int64), on_record=writer.submit, guidance=guide)
             torch.cuda.synchronize()
             files += writer.close()
             local = {'seq': traj[-1]['seq'], 'pLDDT': traj[-1]['pLDDT']}
