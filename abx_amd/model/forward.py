@@ -417,7 +417,7 @@ class Engine:
         h1 = ws.get('i_h1', (M1, NC)); h2 = ws.get('i_h2', (M1, NC))
         upd = ws.get('i_upd', (M1, 6))
         for _ in range(ic.num_layer):
-            ops.gemm(s, P.wt[P_IPA + 'attention_module.proj'], proj, bias=P.b[P_IPA + 'attention_module.proj'], exact=1)
+            _lin(P, P_IPA + 'attention_module.proj', s, proj)
             ops.ipa_pack(proj, cur_R, cur_t, qpack, kpack, vpack, Bc, L, P.ipa_ws)
             ops.ipa_weights(qpack, kpack, vpack, bias2d, mask_f, cur_R, cur_t, P.ipa_pw, attn_ws, ifeat, Bc, L)
             ops.ipa_pair(attn_ws, zi, ifeat, Bc, L)
