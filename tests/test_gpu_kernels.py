@@ -467,10 +467,11 @@ def test_tri_attn_all_keys_masked_row_and_spike(ops, exact, L, spike):
         check(out.view(B, L, L, C), o, 5e-6, f'tri_attn mask all={bool(mask.all())}')
 
 
-@pytest.mark.parametrize('L', [52, 131, 230, 402])
+@pytest.mark.parametrize('L', [52, 131, 230, 402, 600])
 def test_seq_attn(ops, L):
     """L = 52: one key per lane slot, partial; 131: three key slots (4-slot instantiation), one query block; 230: two query
-    blocks of 128; 402: three query blocks, 7 key slots (8-slot instantiation).  One sample has every key masked but two."""
+    blocks of 128; 402: three query blocks, 7 key slots (8-slot instantiation); 600: the 12-slot / 4-wave instantiation, two query blocks.  One sample has every key
+    masked but two."""
     from oracle import abx_oracle as O
     B, H, D = 2, 32, 17
     qkv = torch.randn(B, L, H, 3 * D, generator=g(34))
@@ -487,10 +488,11 @@ def test_seq_attn(ops, L):
     check(out.view(B, L, -1), o, 5e-6, 'seq_attn')
 
 
-@pytest.mark.parametrize('L', [37, 131])
+@pytest.mark.parametrize('L', [37, 131, 402])
 def test_ipa_core(ops, params, cfg, L):
     """IPA core against the oracle; L = 37: one partial 12-query block tail and a single 64-key wave task per head,
-    L = 131: three key tasks per head, 11 query blocks (last one 11 of 12)."""
+    L = 131: three key tasks per head, 11 query blocks (last one 11 of 12); L = 402: 7 key tasks per head, 34 query blocks, 78 KB of
+    logits per workgroup."""
     from oracle import abx_oracle as O
     B = 2
     c = cfg.model.heads.diffusion_module.IPA
