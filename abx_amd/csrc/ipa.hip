@@ -7,15 +7,16 @@
 //                                     the weights kernel reads them as wave-uniform float2 for packed FMAs; rows padded to 12)
 //                    K[b][h][j][28] = [ k_scalar (16)     | k_point_global (4x3) ]
 //                    V[b][h][j][40] = [ v_scalar (16)     | v_point_global (8x3) ]
-//  abx_ipa_attn : two kernels.
-//     ipa_weights_kernel  one workgroup per (b, 4 query residues), two per CU: logits (direct (q-k)^2 point distances as the
-//              reference, not the expanded form: no cancellation at |x| ~ 10) + pair bias, mask fill finfo.min, LDS-resident
-//              [iq][h][j]; wave-shuffle softmax; the normalised weights go to HBM as attn[b][i][j][12]; scalar + point outputs
-//              (16-byte loads of V, shuffle-folded key groups); points back to the local frame (r3.invert_rigids,
+//  abx_ipa_attn : two kernels (abx_ipa_weights + abx_ipa_pair).
+//     ipa_weights_kernel  one workgroup per (b, 12 query residues, 4 heads), two per CU, samples pinned to XCDs: logits (direct
+//              (q-k)^2 point distances as the reference, not the expanded form: no cancellation at |x| ~ 10; Q through the
+//              scalar cache, packed FMAs over query pairs) + pair bias, mask fill finfo.min, LDS-resident [iq][h][j];
+//              wave-shuffle softmax; the normalised weights go to HBM as attn[b][i][head group][j][4]; scalar + point outputs
+//              (16-byte loads of V, key groups folded through LDS); points back to the local frame (r3.invert_rigids,
 //              r3.py:54-59), norms sqrt(sum^2 + 1e-8)
-//     ipa_pair_kernel     attention over the pair slab, ONE WAVE per (b, i) row: streams z[b,i,j,0:128] exactly once (512 B
-//              per key, 16 keys in flight per wave, weights through the scalar cache), 24 accumulators per lane, no LDS /
-//              barrier / reduction -> the HBM-bound part (6.3 GB per layer at B = 100, L = 352; + 0.6 GB weights)
+//     ipa_pair_kernel     attention over the pair slab, ONE WAVE per (b, i) row: streams z[b,i,j,0:128] exactly once (16 keys
+//              in flight per wave, their weights parked in a wave-private LDS strip), no block barrier, no cross-lane
+//              reduction -> the HBM-bound part (6.3 GB per layer at B = 100, L = 352; + 0.6 GB weights)
 //     feature row [scalar 192 | points '(r n)' 288 | norms 96 | pair 1536] = 2112 floats per residue.
 #include "common.h"
 #include "abx_hip.h"
