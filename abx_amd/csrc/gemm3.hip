@@ -114,13 +114,17 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         for (int i = 0; i < NLA; ++i) {
             const int r = (wave * NLA + i) * 16 + (lane >> 2), p = lane & 3;
             const int kq = p ^ ((r >> 2) & 3);                 // physical 16-byte slot p of row r holds logical k-quad kq
-            long long gr = min(m0 + r, g.M - 1);
+            const int gri = min(m0 + r, g.M - 1);                    // (32-bit: M < 2^31; 64-bit divisions cost ~80 instructions)
+            long long gr = gri;
             if (g.a_pair) {
                 // padded pair position (i, j) of the GEMM -> row of the unpadded pair tensor (pad columns re-read column L-1;
                 // their outputs are zeroed by the row scale / never stored)
-                const int pi = (int)(gr / g.pair_Lp), pj = min((int)(gr - (long long)pi * g.pair_Lp), g.pair_L - 1);
+                const int pi = gri / g.pair_Lp, pj = min(gri - pi * g.pair_Lp, g.pair_L - 1);
                 gr = g.a_pair_transpose > 0 ? (long long)pj * g.pair_L + pi : (long long)pi * g.pair_L + pj;
-            } else if (g.a_pair_transpose > 0) gr = (gr % g.a_pair_transpose) * g.a_pair_transpose + gr / g.a_pair_transpose;
+            } else if (g.a_pair_transpose > 0) {
+                const int qi = gri / g.a_pair_transpose;
+                gr = (long long)(gri - qi * g.a_pair_transpose) * g.a_pair_transpose + qi;
+            }
             offsA[i] = (unsigned)(((gr - row0) * g.sAm + kq * 4) * 4);
         }
         a_step = BK * 4;
