@@ -83,11 +83,13 @@ class AbxReverseArgs(C.Structure):
         ('rot_score', c_f), ('trans_score', c_f), ('ts_is_f32', I), ('logits', c_f),
         ('diffuse_mask', c_f), ('t', c_f), ('dt', F),
         ('z_rot', c_f), ('z_trans', c_f), ('jumps', c_f),
+        ('u_jumps', c_f),
+        ('dt_dev', c_f),
         ('seed', C.c_ulonglong), ('sample_ids', c_f), ('step', I),
         ('step_dev', c_f),
         ('exp_max_sigma', F), ('exp_min_sigma', F), ('min_b', F), ('bdiff', F), ('coord_scale', F), ('rate_const', F),
         ('noise_scale', F), ('center', I),
-        ('rigid_out', c_f), ('seq_out', c_f), ('rates_out', c_f),
+        ('rigid_out', c_f), ('seq_out', c_f), ('rates_out', c_f), ('jumps_out', c_f),
         ('B', I), ('L', I),
     ]
 

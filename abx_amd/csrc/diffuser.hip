@@ -78,6 +78,23 @@ struct Philox {
 };
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
 
+// Poisson(lam) count as a pure function of one uniform u in (0, 1): the smallest k with u <= cdf(k), the pmf terms built by the
+// fp32 recurrence p_k = p_{k-1} * (lam / k) from p_0 = (float)exp(-(double)lam) (a correctly rounded start: the same bits on the
+// device and in the oracle's restatement, oracle/abx_oracle.py::poisson_icdf).  The walk stops when the fp32 cdf no longer grows
+// past the mode (a u above the saturated sum would otherwise run to the cap and throw the token to 0 / 19) and at k = 64.
+__device__ __forceinline__ int poisson_icdf(float lam, float u) {
+    float pk = (float)exp(-(double)lam), cdf = pk;
+    int kk = 0;
+    while (u > cdf && kk < 64) {
+        ++kk;
+        pk *= lam / (float)kk;
+        const float nc = cdf + pk;
+        if (nc == cdf && (float)kk > lam) break;
+        cdf = nc;
+    }
+    return kk;
+}
+
 template <typename T>
 __device__ __forceinline__ void rotvec_to_quat(const T* v, T* q) {
     const T ang = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -118,8 +135,9 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const AbxReverseArgs 
     double* x1s = sh;
     double* part = sh + (size_t)L * 3;                              // [4 waves][3]
     const double t = a.t[b];
-    const double dt = (double)a.dt;                                 // fp32 0-dim tensor value
-    const double sqdt = (double)sqrtf(a.dt);
+    const float dtf = a.dt_dev ? *a.dt_dev : a.dt;                  // fp32 0-dim tensor value
+    const double dt = (double)dtf;
+    const double sqdt = (double)sqrtf(dtf);
     // so3 diffusion coefficient: sqrt(2 (e^max - e^min) sigma / e^sigma)
     const double sig = log(t * (double)a.exp_max_sigma + (1.0 - t) * (double)a.exp_min_sigma);
     const double g_so3 = sqrt((double)(2.f * (a.exp_max_sigma - a.exp_min_sigma)) * sig / exp(sig));
@@ -229,20 +247,23 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const AbxReverseArgs 
 #pragma unroll
             for (int s = 0; s < 20; ++s) inner += p[s] * (s == s2 ? q_same : q_diff);
             float rate = ((long long)s2 == xt) ? 0.f : a.rate_const * inner;
-            const float lam = rate * a.dt;
+            const float lam = rate * dtf;
             if (a.rates_out) a.rates_out[i * 20 + s2] = lam;
             float jumps;
             if (a.jumps) {
                 jumps = a.jumps[i * 20 + s2];
             } else {
-                uint32_t r4[4];
-                ph2.next(r4);
-                const float u = u01(r4[0]);
-                float pk = expf(-lam), cdf = pk;
-                int kk = 0;
-                while (u > cdf && kk < 64) { ++kk; pk *= lam / (float)kk; cdf += pk; }
-                jumps = (float)kk;
+                float u;
+                if (a.u_jumps) {
+                    u = a.u_jumps[i * 20 + s2];
+                } else {
+                    uint32_t r4[4];
+                    ph2.next(r4);
+                    u = u01(r4[0]);
+                }
+                jumps = (float)poisson_icdf(lam, u);
             }
+            if (a.jumps_out) a.jumps_out[i * 20 + s2] = jumps;
             overall += jumps * (float)((long long)s2 - xt);
         }
         float xp = (float)xt + overall;

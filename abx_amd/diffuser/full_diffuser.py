@@ -169,7 +169,10 @@ class FullDiffuser:
 
     # ---- reverse step -------------------------------------------------------------------------------------------------------
     def reverse(self, rigid_t, seq_t, rot_score, trans_score, logits_t, t, dt, diffuse_mask=None, center=True,
-                noise_scale=1.0, noise=None, sample_ids=None, step=None, step_dev=None):
+                noise_scale=1.0, noise=None, sample_ids=None, step=None, step_dev=None, rates_out=None, jumps_out=None):
+        """full_diffuser.py:174-227.  Extension kwargs (not in the reference): `noise` = recorded draws {'z_rot','z_trans'[,'jumps']}
+        or {'u_jumps'} (B,L,20) uniforms that drive the Poisson inverse cdf; `sample_ids` / `step` / `step_dev` key the device
+        Philox streams; `rates_out` / `jumps_out` (B,L,20) fp32 receive the Poisson rates * dt and the applied jump counts."""
         dev = rigid_t.device
         self.to(dev)
         B, L = rigid_t.shape[:2]
@@ -186,19 +189,30 @@ class FullDiffuser:
             ts = ts.float()
         out_r = torch.empty(B, L, 7, dtype=torch.float64, device=dev)
         out_s = torch.empty(B, L, dtype=torch.int64, device=dev)
+        # the reference's loop hands dt over as a 0-dim device tensor (inference.py:198-199): read it on the device, no host sync
+        dt_dev = dt.to(torch.float32).reshape(1).contiguous() if (torch.is_tensor(dt) and dt.is_cuda) else None
         kw = dict(rigid_in=rigid_in, rigid_is_f64=int(rigid_in.dtype == torch.float64), seq_in=seq_t.to(torch.int64).contiguous(),
                   rot_score=rot_score.float().contiguous(), trans_score=ts, ts_is_f32=int(ts.dtype == torch.float32),
                   logits=logits_t.float().contiguous(), diffuse_mask=diffuse_mask.to(torch.int32).contiguous(),
-                  t=t.to(torch.float64).contiguous(), dt=float(dt), seed=int(self.seed), step=int(step),
+                  t=t.to(torch.float64).contiguous(), dt=0.0 if dt_dev is not None else float(dt), seed=int(self.seed), step=int(step),
                   exp_max_sigma=self.exp_max_sigma, exp_min_sigma=self.exp_min_sigma, min_b=self.min_b_f32,
                   bdiff=self.bdiff_f32, coord_scale=self.coord_scale_f32, rate_const=self.rate_const,
                   noise_scale=float(noise_scale), center=int(bool(center)), rigid_out=out_r, seq_out=out_s, B=B, L=L)
         if noise is not None:
-            kw.update(z_rot=noise['z_rot'].float().contiguous(), z_trans=noise['z_trans'].float().contiguous())
+            if noise.get('z_rot') is not None:
+                kw.update(z_rot=noise['z_rot'].float().contiguous(), z_trans=noise['z_trans'].float().contiguous())
             if noise.get('jumps') is not None:
                 kw.update(jumps=noise['jumps'].float().contiguous())
+            if noise.get('u_jumps') is not None:
+                kw.update(u_jumps=noise['u_jumps'].float().contiguous())
+        for name, buf in (('rates_out', rates_out), ('jumps_out', jumps_out)):
+            if buf is not None:
+                assert buf.dtype == torch.float32 and buf.is_contiguous() and buf.shape == (B, L, 20)
+                kw[name] = buf
         if sample_ids is not None:
             kw.update(sample_ids=sample_ids.to(torch.int64).contiguous())
+        if dt_dev is not None:
+            kw.update(dt_dev=dt_dev)
         if step_dev is not None:
             assert step_dev.dtype == torch.int32 and step_dev.is_cuda
             kw.update(step_dev=step_dev)

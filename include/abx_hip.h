@@ -255,19 +255,26 @@ int abx_igso3_tables(const float* sigma, const float* omega, int num_sigma, int 
 /* One reverse step of all three processes in float64 with injected or device-generated noise, mask merge after all three.
  * rigid_in f32 or f64 (B,L,7); rot_score f32; trans_score f64 (or f32 when ts_is_f32); logits f32 (B,L,20); t (B,) double.
  * Noise: z_rot,z_trans f32 (B,L,3), jumps f32 (B,L,20) when given; otherwise Philox4x32-10 keyed by (seed, sample id, residue, step).
- * Outputs rigid_out f64 (B,L,7), seq_out int64 (B,L).  Also writes the Poisson rates*dt when rates_out != NULL. */
+ * The Poisson jump counts (discrete_diffuser.py:182-183) are a pure function of one uniform each: the inverse cdf of
+ * Poisson(rate*dt) (fp32 pmf recurrence from (float)exp(-(double)lam), see diffuser.hip::poisson_icdf) evaluated at
+ * u_jumps[b,l,s] in (0,1) when given (jumps == NULL), else at the Philox uniform of (sample id, residue, step, draw s).
+ * Outputs rigid_out f64 (B,L,7), seq_out int64 (B,L).  Optional: rates_out (B,L,20) = the Poisson rates * dt,
+ * jumps_out (B,L,20) = the jump counts that were applied. */
 typedef struct AbxReverseArgs {
     const void* rigid_in; int rigid_is_f64;
     const long long* seq_in;
     const float* rot_score; const void* trans_score; int ts_is_f32; const float* logits;
     const int* diffuse_mask; const double* t; float dt;
     const float* z_rot; const float* z_trans; const float* jumps;
+    const float* u_jumps;                    /* optional (B,L,20) uniforms in (0,1) driving the Poisson inverse cdf (jumps == NULL) */
+    const float* dt_dev;                     /* optional DEVICE float: overrides `dt` (the reference's loop passes dt as a 0-dim
+                                                device tensor, inference.py:198-199: no device-to-host read on the step path) */
     unsigned long long seed; const long long* sample_ids; int step;
     const int* step_dev;                     /* optional DEVICE int: overrides `step` (a hipGraph-captured reverse step reads the
                                                 current step index at replay time instead of a value frozen at capture) */
     float exp_max_sigma, exp_min_sigma, min_b, bdiff, coord_scale, rate_const;
     float noise_scale; int center;
-    double* rigid_out; long long* seq_out; float* rates_out;
+    double* rigid_out; long long* seq_out; float* rates_out; float* jumps_out;
     int B, L;
 } AbxReverseArgs;
 int abx_reverse_step(const AbxReverseArgs* a, hipStream_t stream);

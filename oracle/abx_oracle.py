@@ -708,21 +708,57 @@ class OracleR3:
         return self.unscale(x_t), self.score(x_t, x_0, t)
 
 
+def poisson_icdf(lam, u, cap=64):
+    """Poisson(lam) count as a pure function of one uniform u in (0,1) - restatement of abx_amd/csrc/diffuser.hip::poisson_icdf
+    (the build's device sampler for discrete_diffuser.py:182-183; the reference draws torch.poisson, whose stream cannot be
+    reproduced): smallest k with u <= cdf(k), fp32 pmf recurrence p_k = p_{k-1} * (lam / k) from p_0 = float32(exp(-float64(lam))),
+    stop when the fp32 cdf no longer grows past the mode, cap at 64.  lam, u: float32 arrays of one shape -> float32 counts."""
+    lam = np.asarray(lam, dtype=np.float32)
+    u = np.asarray(u, dtype=np.float32)
+    pk = np.exp(-lam.astype(np.float64)).astype(np.float32)
+    cdf = pk.copy()
+    kk = np.zeros(lam.shape, dtype=np.int32)
+    active = u > cdf
+    k = 0
+    while active.any() and k < cap:
+        k += 1
+        kk = np.where(active, k, kk)
+        pk = np.where(active, pk * (lam / np.float32(k)), pk).astype(np.float32)
+        nc = (cdf + pk).astype(np.float32)
+        stalled = active & (nc == cdf) & (np.float32(k) > lam)
+        cdf = np.where(active & ~stalled, nc, cdf)
+        active = active & ~stalled & (u > cdf)
+    return kk.astype(np.float32)
+
+
 class OracleSeq:
-    def __init__(self, conf):
+    def __init__(self, conf, eigh=False):
+        """eigh=True follows the reference's route to q_t0 literally (fp32 eigh factors of the rate matrix,
+        discrete_diffuser.py:15-26,53-67): used to pin `reverse_rates` against the reference-recorded Poisson rates at 1e-6.  The
+        default is the closed form the HIP kernel evaluates; the reference's fp32 eigh factors carry up to 3.3e-5 relative error
+        on the off-diagonal entries at small t (measured against fp64: tests/test_oracle_golden.py), the closed form 1.4e-7."""
         self.K = 20
         self.rate_const = conf['rate_const']
         r = self.rate_const * torch.ones(self.K, self.K)
         r = r - torch.diag(torch.diag(r))
         r = r - torch.diag(torch.sum(r, dim=1))
         self.rate_matrix = r.float()
+        self.eigh = eigh
+        if eigh:
+            ev, evec = torch.linalg.eigh(r)
+            self.eigvals, self.eigvecs = ev.float(), evec.float()
 
     def transition(self, t):
         """Closed form of V exp(lambda t) V^T for the uniform-rate generator (discrete_diffuser.py:53-67):
         exp(-K r t) I + (1 - exp(-K r t))/K, entries < 1e-8 -> 0."""
         t = t.float()
-        e = torch.exp(-self.K * self.rate_const * t)[:, None, None]
-        q = e * torch.eye(self.K)[None] + (1 - e) / self.K
+        if self.eigh:
+            K = self.K
+            q = self.eigvecs.reshape(1, K, K) @ torch.diag_embed(torch.exp(self.eigvals.reshape(1, K) * t.reshape(-1, 1))) @ \
+                self.eigvecs.T.reshape(1, K, K)
+        else:
+            e = torch.exp(-self.K * self.rate_const * t)[:, None, None]
+            q = e * torch.eye(self.K)[None] + (1 - e) / self.K
         q = torch.where(q < 1e-8, torch.zeros_like(q), q)
         return q
 
@@ -736,8 +772,11 @@ class OracleSeq:
         rates = fwd * ((p0t / denom) @ qt0)
         return rates.scatter(2, x_t[..., None], 0.0), x_t
 
-    def reverse(self, x_t, logits, t, dt, jumps=None):
+    def reverse(self, x_t, logits, t, dt, jumps=None, u_jumps=None):
+        """jumps: recorded Poisson draws; u_jumps: uniforms for the inverse-cdf sampler the HIP kernel uses (poisson_icdf)."""
         rates, x_t = self.reverse_rates(x_t, logits, t)
+        if jumps is None and u_jumps is not None:
+            jumps = torch.from_numpy(poisson_icdf((rates * dt).numpy(), u_jumps.numpy()))
         if jumps is None:
             jumps = torch.poisson(rates * dt)
         diffs = torch.arange(self.K).view(1, 1, self.K) - x_t[..., None]
@@ -785,13 +824,13 @@ class OracleDiffuser:
 
     def reverse(self, rigid_t, seq_t, rot_score, trans_score, logits_t, t, dt, diffuse_mask, noise=None,
                 center=True, noise_scale=1.0):
-        """noise: {'z_rot','z_trans' (B,L,3) f32, 'jumps' (B,L,20) f32}; drawn in that order if absent."""
+        """noise: {'z_rot','z_trans' (B,L,3) f32, 'jumps' (B,L,20) f32 | 'u_jumps' (B,L,20) uniforms}; drawn in that order if absent."""
         trans_t, rot_t = rigid_t[..., 4:], quat_to_rotvec(rigid_t[..., :4])
         z_rot = noise['z_rot'] if noise else torch.randn(rot_score.shape)
         rot1 = self.so3.reverse(rot_t, rot_score, t, dt, noise_scale * z_rot)
         z_tr = noise['z_trans'] if noise else torch.randn(trans_score.shape)
         tr1 = self.r3.reverse(trans_t, trans_score, t, dt, noise_scale * z_tr, center)
-        seq1 = self.seq.reverse(seq_t, logits_t, t, dt, noise['jumps'] if noise else None)
+        seq1 = self.seq.reverse(seq_t, logits_t, t, dt, noise.get('jumps') if noise else None, noise.get('u_jumps') if noise else None)
         m = diffuse_mask
         tr1 = _mask_merge(tr1, trans_t, m[..., None])
         rot1 = _mask_merge(rot1, rot_t, m[..., None])

@@ -754,6 +754,142 @@ def test_reverse_step_golden(ops, cfg):
         assert (ts.cpu() - tt(s[f's{i}.trans_score_scaling'])).abs().max() < 1e-12
 
 
+def _token_diffuser(cfg):
+    from abx_amd.diffuser.full_diffuser import FullDiffuser
+    D = FullDiffuser(cfg.diffuser)
+    D.set_tables(torch.zeros(1000, 1000), torch.zeros(1000, 1000), torch.zeros(1000, 1000), DEV)
+    return D
+
+
+def _token_step(D, x_t, logits, t, dt, dm=None, noise=None, **kw):
+    """abx_reverse_step with neutral rigid inputs: returns (seq_out, rates * dt, applied jump counts)."""
+    B, L = x_t.shape
+    rig = torch.zeros(B, L, 7, dtype=torch.float64, device=DEV)
+    rig[..., 0] = 1.0
+    z3 = torch.zeros(B, L, 3, device=DEV)
+    rates = torch.full((B, L, 20), -1.0, device=DEV)
+    jumps = torch.full((B, L, 20), -1.0, device=DEV)
+    if dm is None:
+        dm = torch.ones(B, L, dtype=torch.int32, device=DEV)
+    _, seq = D.reverse(rig, x_t.to(DEV), z3, z3.double(), logits.to(DEV), torch.full((B,), float(t), dtype=torch.float64, device=DEV),
+                       dt, dm, noise=noise, rates_out=rates, jumps_out=jumps, **kw)
+    return seq.cpu(), rates.cpu(), jumps.cpu()
+
+
+def test_reverse_step_token_rates_vs_reference_and_oracle(ops, cfg):
+    """the reverse RATES of the default product path (softmax -> ratio -> inner -> rate * dt,
+    diffuser.hip) against the argument of the reference's own torch.poisson call (rates_tiny.npz) and against the oracle's
+    closed-form restatement: t in {1, 0.5, 0.02}, dt in {0.01, 0.1}, tokens 0 / 19 / out of range, a masked residue block.
+    dt arrives once as a host float and once as the 0-dim device tensor of the reference's loop (inference.py:198-199)."""
+    from oracle import abx_oracle as O
+    z = load_npz('rates_tiny.npz')
+    x_t, lg = tt(z['x_t']), tt(z['logits'])
+    B, L = x_t.shape
+    D = _token_diffuser(cfg)
+    seq_o = O.OracleSeq({'rate_const': float(z['rate_const'])})
+    dm = torch.ones(B, L, dtype=torch.int32)
+    dm[:, 30:] = 0                                                            # fixed residues keep their token
+    for ci, c in enumerate(z['cases']):
+        t, dt = float(z[c + '.t']), tt(z[c + '.dt'])
+        ref = tt(z[c + '.lam'])
+        jn = tt(z[c + '.jumps'])
+        dt_arg = dt.to(DEV) if ci % 2 else float(dt)
+        seq, lam, ja = _token_step(D, x_t, lg, t, dt_arg, dm=dm.to(DEV), noise=dict(jumps=jn.to(DEV)))
+        ro, _ = seq_o.reverse_rates(x_t, lg, torch.tensor(t))
+        lo = ro * dt
+        assert torch.equal(lam == 0, ref == 0) and torch.equal(lam == 0, lo == 0)
+        pos = ref > 0
+        rel_o = ((lam - lo).abs() / lo.abs().clamp_min(1e-30))[pos]
+        rel_r = ((lam - ref).abs() / ref.abs().clamp_min(1e-30))[pos]
+        assert float(rel_o.max()) < 2e-6, (c, 'vs oracle', float(rel_o.max()))   # same closed-form q_t0: fp32 rounding only
+        assert float(rel_r.max()) < 1e-4, (c, 'vs reference', float(rel_r.max()))  # the reference's fp32 eigh route (3e-5 off fp64)
+        assert torch.equal(ja, jn)
+        want = tt(z[c + '.x_new']).long()
+        want = torch.where(dm.bool(), want, x_t)
+        assert torch.equal(seq, want), c
+
+
+def _peaky_logits(B, L, x_t, gen):
+    lg = 3.0 * torch.randn(B, L, 20, generator=gen)
+    peaked = torch.rand(B, L, generator=gen) < 0.3
+    tgt = (x_t.clamp(0, 19) + torch.randint(1, 20, (B, L), generator=gen)) % 20
+    pk = torch.zeros(B, L, 20)
+    pk.scatter_(2, tgt[..., None], 30.0)
+    return torch.where(peaked[..., None], pk, lg)
+
+
+def test_reverse_step_uniform_driven_poisson_exact_tokens(ops, cfg):
+    """the Poisson draw is a pure function of one uniform.  On identical uniforms (2e6 draws, rates * dt up
+    to ~5) the kernel's jump counts equal the oracle's restatement of the inverse cdf bit for bit, and the tokens equal the
+    oracle's end-to-end tau-leaping step (own rates) except where a uniform sits within fp32 rounding of a cdf edge."""
+    from oracle import abx_oracle as O
+    B, L = 50, 1000
+    ge = g(301)
+    x_t = torch.randint(0, 20, (B, L), generator=ge)
+    lg = _peaky_logits(B, L, x_t, ge)
+    u = (torch.randint(0, 1 << 24, (B, L, 20), generator=ge).float() + 0.5) / float(1 << 24)
+    D = _token_diffuser(cfg)
+    seq_o = O.OracleSeq({'rate_const': D.rate_const})
+    n_big = 0
+    for t, dt in ((0.02, 0.1), (0.5, 0.01)):
+        seq, lam, ja = _token_step(D, x_t, lg, t, dt, noise=dict(u_jumps=u.to(DEV)))
+        n_big += int((lam > 3).sum())
+        want_j = torch.from_numpy(O.poisson_icdf(lam.numpy(), u.numpy()))
+        assert torch.equal(ja, want_j), f'{int((ja != want_j).sum())} jump counts differ from the inverse-cdf restatement'
+        diffs = torch.arange(20).view(1, 1, 20) - x_t[..., None]
+        want = torch.clamp(x_t + (want_j * diffs).sum(-1), 0, 19).long()
+        assert torch.equal(seq, want)
+        # end to end against the oracle's own rates: a count may differ only where the two fp32 rate evaluations straddle u
+        ro, _ = seq_o.reverse_rates(x_t, lg, torch.tensor(t))
+        jo = torch.from_numpy(O.poisson_icdf((ro * np.float32(dt)).numpy(), u.numpy()))
+        bad = ja != jo
+        assert int(bad.sum()) <= 8, int(bad.sum())
+        if bad.any():
+            from scipy.stats import poisson
+            lb, ub, kb = lam[bad].double().numpy(), u[bad].double().numpy(), torch.minimum(ja, jo)[bad].numpy()
+            assert np.all(np.abs(poisson.cdf(kb, lb) - ub) < 2e-6 * np.maximum(1.0, lb))
+        so = seq_o.reverse(x_t, lg, torch.tensor(t), torch.tensor(np.float32(dt)), u_jumps=u).long()
+        assert int((seq != so).sum()) <= int(bad.any(-1).sum())
+    assert n_big > 1000                                                    # the vectors reach large rates
+
+
+def test_reverse_step_philox_poisson_statistics(ops, cfg):
+    """the device-RNG path.  With flat logits every off-token rate of a residue is the same lam; the Philox
+    jump counts over 4e5 draws must have the Poisson pmf (chi-square against scipy), mean = var = lam, for lam ~ 0.0016, 0.5, 2.1."""
+    from scipy.stats import poisson
+    B, L = 20, 1000
+    ge = g(302)
+    x_t = torch.randint(0, 20, (B, L), generator=ge)
+    lg = torch.zeros(B, L, 20)
+    D = _token_diffuser(cfg)
+    D.seed = 4242
+    ids = torch.arange(B, device=DEV) + 100
+    for t, dt in ((0.5, 0.01), (0.02, 0.2), (0.02, 0.85)):
+        seq, lam, ja = _token_step(D, x_t, lg, t, dt, sample_ids=ids, step=3)
+        off = lam > 0
+        assert int(off.sum()) == B * L * 19
+        lam0 = float(lam[off].double().mean())
+        assert float(lam[off].max() - lam[off].min()) < 1e-5 * lam0
+        k = ja[off].double().numpy()
+        n = k.size
+        assert abs(k.mean() - lam0) < 5 * np.sqrt(lam0 / n), (k.mean(), lam0)
+        assert abs(k.var() - lam0) < 5 * np.sqrt((lam0 + 2 * lam0 ** 2) / n) + 1e-6, (k.var(), lam0)
+        kmax = int(max(3, poisson.ppf(1 - 1e-4, lam0)))
+        obs = np.array([(k == i).sum() for i in range(kmax)] + [(k >= kmax).sum()], dtype=np.float64)
+        exp = np.array([poisson.pmf(i, lam0) for i in range(kmax)] + [poisson.sf(kmax - 1, lam0)]) * n
+        keep = exp > 5
+        chi2 = float((((obs - exp) ** 2) / exp)[keep].sum())
+        assert chi2 < 40 + 3 * keep.sum(), (chi2, obs, exp)
+        # the current token never jumps onto itself and the applied jumps reproduce the tokens
+        assert float(ja[~off].abs().max()) == 0
+        diffs = torch.arange(20).view(1, 1, 20) - x_t[..., None]
+        assert torch.equal(seq, torch.clamp(x_t + (ja * diffs).sum(-1), 0, 19).long())
+        # another step index / another sample id gives other draws; the same key the same draws
+        _, _, jb = _token_step(D, x_t, lg, t, dt, sample_ids=ids, step=3)
+        _, _, jc = _token_step(D, x_t, lg, t, dt, sample_ids=ids, step=4)
+        assert torch.equal(ja, jb) and not torch.equal(ja, jc)
+
+
 def test_reverse_step_device_rng_properties(ops, cfg):
     """Philox path: deterministic, batch-composition invariant (keyed by sample id), fixed residues untouched."""
     from abx_amd.diffuser.full_diffuser import FullDiffuser

@@ -375,3 +375,66 @@ def test_esm_hook_matches_reference(esm_setup, pinned_diffuser):
         b2[k] = tt(g['in.' + k])
     r0 = O.score_network(params, b2, cfg0, pinned_diffuser)
     assert float((r0['representations']['seq'] - tt(g['out.seq'])).abs().max()) > 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# token reverse rates and the inverse-cdf Poisson sampler (discrete_diffuser.py:130-190)
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_token_reverse_rates_match_reference_recorded_poisson_argument(cfg):
+    """rates_tiny.npz holds the ARGUMENT of the reference's torch.poisson call (reverse_rates * dt) at t in {1, 0.5, 0.02},
+    dt in {0.01, 0.1}, tokens 0 / 19 / out of range, peaked and flat logits.  The literal (fp32 eigh) route reproduces it to
+    2e-6; the closed-form route (what the HIP kernel evaluates) differs only through the reference's own eigh rounding."""
+    z = load_npz('rates_tiny.npz')
+    x_t, lg = tt(z['x_t']), tt(z['logits'])
+    lit = O.OracleSeq({'rate_const': float(z['rate_const'])}, eigh=True)
+    closed = O.OracleSeq({'rate_const': float(z['rate_const'])})
+    for c in z['cases']:
+        t, dt, ref = torch.tensor(float(z[c + '.t'])), tt(z[c + '.dt']), tt(z[c + '.lam'])
+        assert ref.dtype == torch.float32
+        for seq, tol in ((lit, 2e-6), (closed, 1e-4)):
+            r, xc = seq.reverse_rates(x_t, lg, t)
+            lam = r * dt
+            assert torch.equal(lam == 0, ref == 0)                                  # zero exactly at the current token
+            assert torch.equal(xc, torch.clamp(x_t, 0, 19))
+            rel = ((lam - ref).abs() / ref.abs().clamp_min(1e-30))[ref > 0]
+            assert float(rel.max()) < tol, (c, float(rel.max()))
+        # and the recorded draw applied to the tokens gives the reference's x_new on both routes
+        for seq in (lit, closed):
+            assert torch.equal(seq.reverse(x_t, lg, t, dt, jumps=tt(z[c + '.jumps'])), tt(z[c + '.x_new']))
+    assert float(tt(z['c21.lam']).max()) > 4.0                                      # the vectors do reach rate * dt ~ 5
+
+
+def test_closed_form_transition_is_closer_to_fp64_than_the_reference_route():
+    lit, closed = O.OracleSeq({'rate_const': 0.3}, eigh=True), O.OracleSeq({'rate_const': 0.3})
+    for t in (1.0, 0.5, 0.1, 0.02):
+        e = np.exp(-6.0 * t)
+        truth = e * np.eye(20) + (1 - e) / 20
+        el = np.abs(lit.transition(torch.tensor([t])).double().numpy()[0] - truth) / truth
+        ec = np.abs(closed.transition(torch.tensor([t])).double().numpy()[0] - truth) / truth
+        assert ec.max() < 3e-7 and ec.max() <= el.max() and el.max() < 1e-4
+
+
+def test_poisson_icdf_is_the_poisson_inverse_cdf():
+    """Exact against a float64 cdf table away from the fp32 rounding of the cdf edges; mean / variance over 4e5 draws."""
+    from scipy.stats import poisson
+    rng = np.random.default_rng(5)
+    lam = np.concatenate([np.zeros(10), rng.uniform(0, 0.05, 100000), rng.uniform(0, 5.0, 100000), [5.0, 4.736, 1e-8, 20.0]]).astype(np.float32)
+    u = ((rng.integers(0, 1 << 24, lam.shape).astype(np.float32) + 0.5) / np.float32(1 << 24)).astype(np.float32)
+    k = O.poisson_icdf(lam, u)
+    assert k.dtype == np.float32 and k.min() >= 0 and k.max() <= 64
+    lo = poisson.cdf(k - 1, lam.astype(np.float64))          # u must lie in (cdf(k-1), cdf(k)]
+    hi = poisson.cdf(k, lam.astype(np.float64))
+    tol = 4e-7
+    assert np.all(u.astype(np.float64) > lo - tol) and np.all(u.astype(np.float64) <= hi + tol)
+    assert np.all(k[:10] == 0)
+    # saturated tail: a uniform above the largest fp32 cdf value must not run to the cap
+    top = np.float32(1.0) - np.float32(2.0 ** -25)
+    kt = O.poisson_icdf(np.array([0.5, 3.0, 0.01], np.float32), np.array([top, top, top], np.float32))
+    assert np.all(kt < 40), kt
+    sel = slice(100010, 200010)
+    draws = np.stack([O.poisson_icdf(lam[sel], ((rng.integers(0, 1 << 24, 100000).astype(np.float32) + 0.5) / np.float32(1 << 24)))
+                      for _ in range(4)])
+    lm = lam[sel].astype(np.float64)
+    assert abs(draws.mean() - lm.mean()) < 4 * np.sqrt(lm.mean() / draws.size)
+    resid = (draws - lm[None]) ** 2
+    assert abs(resid.mean() - lm.mean()) < 0.02 * lm.mean()                        # Var = lam
