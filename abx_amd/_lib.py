@@ -97,8 +97,9 @@ class AbxReverseArgs(C.Structure):
 class AbxGuidanceArgs(C.Structure):
     _fields_ = [
         ('atom14', c_f), ('atom_mask', c_f), ('aatype', c_f), ('chain_id', c_f),
+        ('residx', c_f),
         ('radius', c_f), ('frame_trans', c_f),
-        ('overlap_tolerance', F), ('between_chain_factor', F), ('bond_tolerance_factor', F), ('w_clash', F), ('w_bond', F),
+        ('overlap_tolerance', F), ('between_chain_factor', F), ('bond_tolerance_factor', F), ('w_clash', F), ('w_bond', F), ('w_angle', F),
         ('energy', c_f), ('grad_atom', c_f), ('grad_trans', c_f), ('grad_rot', c_f),
         ('B', I), ('L', I),
     ]

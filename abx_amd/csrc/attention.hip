@@ -719,14 +719,8 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
         ABX_REQUIRE(nbh8 * a.S < (1LL << 31), "abx_tri_attn_fwd: grid too large");
         const dim3 grid((unsigned)(nbh8 * a.S)), block(TRI_THREADS);
-        static thread_local bool configured4[3] = {false, false, false};      // once per instantiation (not inside a graph capture)
         auto launch = [&](auto kern, size_t lds4) -> int {
-            bool& done = configured4[slots <= 2 ? 0 : (slots <= 4 ? 1 : 2)];
-            if (!done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-                if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
-                done = true;
-            }
+            if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds4, "abx_tri_attn_fwd")) return rc;
             hipLaunchKernelGGL(kern, grid, block, lds4, st, a);
             return abx_check_launch("abx_tri_attn_fwd");
         };
@@ -738,13 +732,7 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout of the exact kernel (L <= 389)");
-    static thread_local size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_attn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) { abx_set_error("abx_tri_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
-        configured = 160 * 1024;
-    }
+    if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(tri_attn_kernel), 160 * 1024, "abx_tri_attn_fwd")) return rc;
     hipLaunchKernelGGL(tri_attn_kernel, dim3(a.H, a.S, a.B), dim3(TRI_THREADS), lds, st, a);
     return abx_check_launch("abx_tri_attn_fwd");
 }
@@ -764,13 +752,8 @@ extern "C" int abx_seq_attn_fwd(const float* qkv, const float* bias, const float
     const size_t lds = ((size_t)2 * L * 20 + (size_t)(nt / 64) * 4 * nkt * 64) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_seq_attn_fwd: L too large for the LDS-resident K / V (L <= 716)");
     const dim3 grid((L + qblk - 1) / qblk, H, B), block(nt);
-    static thread_local bool configured[5] = {false, false, false, false, false};
-    auto launch = [&](auto kern, int id) -> int {
-        if (!configured[id]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-            if (e != hipSuccess) { abx_set_error("abx_seq_attn_fwd: hipFuncSetAttribute failed"); return (int)e; }
-            configured[id] = true;
-        }
+    auto launch = [&](auto kern, int) -> int {
+        if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, "abx_seq_attn_fwd")) return rc;
         hipLaunchKernelGGL(kern, grid, block, lds, st, qkv, bias, keymask, gate, out, L, H, scale, qblk);
         return abx_check_launch("abx_seq_attn_fwd");
     };

@@ -1,6 +1,10 @@
 // Library-level entry points: version, thread-local error text, device check.
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "common.h"
 #include "abx_hip.h"
 
@@ -15,6 +19,24 @@ int abx_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return ABX_OK;
+}
+
+int abx_ensure_dynamic_lds(const void* kernel, int bytes, const char* what) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (done.count({dev, kernel})) return ABX_OK;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done.insert({dev, kernel});
+    }
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", what, hipGetErrorString(e));
         return (int)e;
     }
     return ABX_OK;
@@ -55,12 +77,7 @@ __global__ __launch_bounds__(1024) void poison_lds_kernel(unsigned pattern, unsi
 }  // namespace
 
 extern "C" int abx_debug_poison_lds(unsigned pattern, hipStream_t st) {
-    static thread_local bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { abx_set_error("abx_debug_poison_lds: hipFuncSetAttribute failed"); return (int)e; }
-        configured = true;
-    }
+    if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(poison_lds_kernel), 160 * 1024, "abx_debug_poison_lds")) return rc;
     hipLaunchKernelGGL(poison_lds_kernel, dim3(256 * 4), dim3(1024), 160 * 1024, st, pattern, (unsigned*)nullptr);
     return abx_check_launch("abx_debug_poison_lds");
 }

@@ -9,6 +9,10 @@
 // thread-local last error text (abx_last_error_string)
 void abx_set_error(const char* msg);
 int abx_check_launch(const char* what);
+// Raise a kernel's dynamic-LDS limit once per (device, kernel): the attribute belongs to the device the calling thread has
+// current, so a process that drives several GPUs configures each of them (a per-thread flag would skip the second device).
+// Returns 0 or the hipError_t; never called inside a graph capture after the first eager launch on a device.
+int abx_ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
 
 #define ABX_REQUIRE(cond, msg)            \
     do {                                  \

@@ -419,13 +419,7 @@ extern "C" int abx_ipa_weights(const float* qpack, const float* kpack, const flo
     ABX_REQUIRE(B > 0 && L > 0 && B <= 65535 && (long long)B * L < (1ll << 31), "abx_ipa_weights: bad sizes");
     const size_t lds = (ipa_logits_floats(L) + IQ * HG * VREC) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_weights: L too large for LDS-resident logits");
-    static thread_local bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ipa_weights_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-        if (e != hipSuccess) { abx_set_error("abx_ipa_weights: hipFuncSetAttribute failed"); return (int)e; }
-        configured = true;
-    }
+    if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_weights_kernel), 160 * 1024, "abx_ipa_weights")) return rc;
     const long long nwg = (long long)((B + 7) / 8) * 8 * ((L + IQ - 1) / IQ) * NHG;
     ABX_REQUIRE(nwg < (1LL << 31), "abx_ipa_weights: grid too large");
     hipLaunchKernelGGL(ipa_weights_kernel, dim3((unsigned)nwg), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, mask,

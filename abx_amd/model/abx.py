@@ -18,7 +18,8 @@ tensor is 9.5 GB at B = 100, L = 352).  A pass never writes the buffer that `bat
 self-conditioning input of the next call is always intact; the representations returned by call n are overwritten during call
 n + 1.  Callers that keep them longer set `ScoreNetwork.clone_outputs = True` (fresh tensors, as the reference returns).
 The trajectory-invariant embeddings travel in `batch['_static']`: their lifetime is that of the batch dict they were built from
-(a new dict = a new complex = recomputed), never that of the module.
+(a new dict = a new complex = recomputed), never that of the module; the entry is keyed by the storage address and version counter of
+`seq`, `fixed_mask` and `atom14_gt_positions`, so refilling a dict with another complex recomputes them too.
 """
 import torch
 from torch import nn
@@ -93,9 +94,6 @@ class ScoreNetwork(nn.Module):
         self._auto_chunks[key] = chunk
         return chunk
 
-    def invalidate_static(self):
-        """Kept for callers of round-1 builds: the static embeddings now live in the batch dict (batch['_static'])."""
-
     def _buf(self, name, shape, dtype, device):
         b = self._bufs.get(name)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype or b.device != device:
@@ -119,7 +117,10 @@ class ScoreNetwork(nn.Module):
                          prev_pair=torch.zeros([B, L, L, WZ], device=device))
         shared = bool(batch.get('_shared_context', False)) or B == 1
         # Residue/PairEmbedding depend on the fixed context only: built once per batch dict and carried in it
-        skey = (id(self), self._engine_serial, B, L, shared)
+        # (keyed by the identity AND version of the context tensors: a caller that refills one dict with another complex of the same
+        # shape, in place or by replacing the tensors, gets fresh embeddings)
+        ctx = tuple((batch[k].data_ptr(), batch[k]._version) for k in ('seq', 'fixed_mask', 'atom14_gt_positions'))
+        skey = (id(self), self._engine_serial, B, L, shared, ctx)
         hit = batch.get('_static')
         if hit is None or hit[0] != skey:
             hit = (skey, eng.static_embeddings(batch, shared))

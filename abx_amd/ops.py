@@ -502,10 +502,23 @@ def vdw_radius_table(device):
     return _RADIUS[key]
 
 
+_A14MASK = {}
+
+
+def atom14_mask_table(device):
+    """(21, 14) bool: which atom14 slots a residue type fills (cached per device: no host-to-device copy on the step path)."""
+    key = str(device)
+    if key not in _A14MASK:
+        from abx_amd import residue_constants as rc
+        _A14MASK[key] = torch.as_tensor(rc.restype_atom14_mask).to(device=device, dtype=torch.bool).contiguous()
+    return _A14MASK[key]
+
+
 def clash_grad(atom14, atom_mask, aatype, chain_id, frame_trans, overlap_tolerance=1.5, between_chain_factor=0.2,
-               bond_tolerance_factor=12.0, w_clash=1.0, w_bond=1.0):
+               bond_tolerance_factor=12.0, w_clash=1.0, w_bond=1.0, w_angle=1.0, residx=None):
     """Violation energies and gradients (abx_clash_grad).  atom14 (B,L,14,3) f32, atom_mask (B,L,14), aatype (B,L) int64,
-    chain_id (B,L) int32, frame_trans (B,L,3).  -> energy (B,2) [clash, bond], grad_atom (B,L,14,3), grad_trans, grad_rot (B,L,3)."""
+    chain_id (B,L) int32, frame_trans (B,L,3); residx (B,L) int32 or None (None: neighbours are linked by chain id alone, the
+    rule of cal_vio.py:51).  -> energy (B,3) [clash, bond, angle], grad_atom (B,L,14,3), grad_trans, grad_rot (B,L,3)."""
     lib = _lib.load()
     B, L = aatype.shape
     dev = atom14.device
@@ -515,14 +528,17 @@ def clash_grad(atom14, atom_mask, aatype, chain_id, frame_trans, overlap_toleran
     aa = aatype.to(torch.int64).contiguous()
     ch = chain_id.to(torch.int32).contiguous()
     ft = _f32(frame_trans).contiguous()
-    energy = torch.empty(B, 2, device=dev)
+    energy = torch.empty(B, 3, device=dev)
     g_atom = torch.empty(B, L, 14, 3, device=dev)
     g_t = torch.empty(B, L, 3, device=dev)
     g_r = torch.empty(B, L, 3, device=dev)
     ws = torch.empty(max(int(lib.abx_clash_grad_workspace_bytes(B, L)) // 4, 1), device=dev)
     a.atom14, a.atom_mask, a.aatype, a.chain_id, a.radius, a.frame_trans = _p(x), _p(m), _p(aa), _p(ch), _p(vdw_radius_table(dev)), _p(ft)
+    if residx is not None:
+        ri = residx.to(torch.int32).contiguous()
+        a.residx = _p(ri)
     a.overlap_tolerance, a.between_chain_factor, a.bond_tolerance_factor = float(overlap_tolerance), float(between_chain_factor), float(bond_tolerance_factor)
-    a.w_clash, a.w_bond = float(w_clash), float(w_bond)
+    a.w_clash, a.w_bond, a.w_angle = float(w_clash), float(w_bond), float(w_angle)
     a.energy, a.grad_atom, a.grad_trans, a.grad_rot = _p(energy), _p(g_atom), _p(g_t), _p(g_r)
     a.B, a.L = B, L
     check(lib.abx_clash_grad(C.byref(a), _p(ws), _stream()), 'abx_clash_grad')

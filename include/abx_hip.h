@@ -284,16 +284,24 @@ int abx_reverse_step(const AbxReverseArgs* a, hipStream_t stream);
  * (its loop runs under no_grad): an opt-in extension built from the violation material the reference ships -
  * van-der-Waals radii / overlap tolerance (abx/common/residue_constants.py:381-386,483-525, config/config_model.json:116,213-214)
  * and the C-N peptide-bond term of eval/metric_scripts/cal_vio.py:29-74.  Per sample:
- *   energy[b] = { w_clash * sum_pairs w_ij relu(r_a + r_b - overlap_tolerance - d_ab),  w_bond * sum_i relu(|d(C_i,N_i+1) - l0| - tol * sigma) }
+ *   energy[b] = { w_clash * sum_pairs w_ij relu(r_a + r_b - overlap_tolerance - d_ab),
+ *                 w_bond  * sum_i relu(|d(C_i,N_i+1) - l0| - tol * sigma),
+ *                 w_angle * sum_i [ relu(|cos(CA_i,C_i,N_i+1) - c1| - tol * s1) + relu(|cos(C_i,N_i+1,CA_i+1) - c2| - tol * s2) ] }
+ *   (|.| smoothed as sqrt(1e-6 + .^2); l0 / sigma proline-aware; c1 = -0.4473 +- 0.0311, c2 = -0.5203 +- 0.0353: cal_vio.py:76-105,
+ *   abx/common/residue_constants.py:475-480)
  *   grad_atom = dE/dx (B,L,14,3);  grad_trans = sum_a g_a;  grad_rot = sum_a (x_a - frame_trans) x g_a   (B,L,3) each.
- * Pairs of one residue, the peptide bond C(i)-N(i+1) inside a chain and SG-SG pairs are excluded; w_ij = between_chain_factor for
- * atoms of different chains.  radius: [21][14] van-der-Waals radius of every atom14 slot (0 for empty slots).
+ * Pairs of one residue, the peptide bond C(i)-N(i+1) of linked neighbours and SG-SG pairs are excluded from the clash term; w_ij =
+ * between_chain_factor for atoms of different chains.  Residues i, i+1 are linked when they share a chain id and, if residx is
+ * given, residx[i+1] == residx[i] + 1 (residx == NULL: the chain-only rule of cal_vio.py:51).
+ * radius: [21][14] van-der-Waals radius of every atom14 slot (0 for empty slots).
  * The caller allocates the workspace (abx_clash_grad_workspace_bytes). */
 typedef struct AbxGuidanceArgs {
     const float* atom14; const unsigned char* atom_mask; const long long* aatype; const int* chain_id;
+    const int* residx;                              /* optional residue numbers (B,L) */
     const float* radius; const float* frame_trans;
-    float overlap_tolerance, between_chain_factor, bond_tolerance_factor, w_clash, w_bond;
-    float* energy; float* grad_atom; float* grad_trans; float* grad_rot;
+    float overlap_tolerance, between_chain_factor, bond_tolerance_factor, w_clash, w_bond, w_angle;
+    float* energy;                                  /* (B,3): clash, bond, angle */
+    float* grad_atom; float* grad_trans; float* grad_rot;
     int B, L;
 } AbxGuidanceArgs;
 long long abx_clash_grad_workspace_bytes(int B, int L);

@@ -951,9 +951,45 @@ def vdw_radius_table():
     return t
 
 
+def peptide_violation_terms(atom14, atom_mask, aatype, chain_id, residx=None, tolerance_factor=12.0):
+    """Restatement of eval/metric_scripts/cal_vio.py:29-110 (between_residue_bond_loss): per residue pair (i, i+1) the flat-bottom
+    violations of the C-N bond length and of cos(CA_i,C_i,N_i+1), cos(C_i,N_i+1,CA_i+1), their masks and hard-violation masks.
+    residx=None is the reference's rule (neighbours are linked when they share a chain id); with residue numbers a link also needs
+    residx[i+1] == residx[i] + 1 (the build's guidance default).  Pinned by tests/golden/vio_pdb.npz."""
+    x = atom14
+    dt = x.dtype
+    m = atom_mask.to(dt)
+    ca, c, n, ca2 = x[:, :-1, 1], x[:, :-1, 2], x[:, 1:, 0], x[:, 1:, 1]
+    m_ca, m_c, m_n, m_ca2 = m[:, :-1, 1], m[:, :-1, 2], m[:, 1:, 0], m[:, 1:, 1]
+    link = chain_id[:, 1:] == chain_id[:, :-1]
+    if residx is not None:
+        link = link & (residx[:, 1:] == residx[:, :-1] + 1)
+    link = link.to(dt)
+    pro = (aatype[:, 1:] == 14).to(dt)
+    l0 = (1 - pro) * 1.329 + pro * 1.341
+    sd = (1 - pro) * 0.014 + pro * 0.016
+    dist = torch.sqrt(1e-6 + ((c - n) ** 2).sum(-1))
+    err_b = torch.sqrt(1e-6 + (dist - l0) ** 2)
+    unit = lambda v: v / torch.sqrt(torch.clamp((v ** 2).sum(-1, keepdim=True), min=1e-12))      # abx/model/utils.py:12-14
+    c_ca, c_n, n_ca = unit(ca - c), unit(n - c), unit(ca2 - n)
+    err_a1 = torch.sqrt(1e-6 + ((c_ca * c_n).sum(-1) - (-0.4473)) ** 2)                           # residue_constants.py:480
+    err_a2 = torch.sqrt(1e-6 + (((-c_n) * n_ca).sum(-1) - (-0.5203)) ** 2)                        # residue_constants.py:479
+    t = tolerance_factor
+    return {
+        'c_n_loss_per_residue': torch.relu(err_b - t * sd), 'c_n_mask': m_c * m_n * link,
+        'ca_c_n_loss_per_residue': torch.relu(err_a1 - t * 0.0311), 'ca_c_n_mask': m_ca * m_c * m_n * link,
+        'c_n_ca_loss_per_residue': torch.relu(err_a2 - t * 0.0353), 'c_n_ca_mask': m_c * m_n * m_ca2 * link,
+        'c_n_violation_mask': m_c * m_n * link * (err_b > t * sd),
+        'ca_c_n_violation_mask': m_ca * m_c * m_n * link * (err_a1 > t * 0.0311),
+        'c_n_ca_violation_mask': m_c * m_n * m_ca2 * link * (err_a2 > t * 0.0353),
+        'has_no_gap_mask': link,
+    }
+
+
 def violation_energy(atom14, atom_mask, aatype, chain_id, overlap_tolerance=1.5, between_chain_factor=0.2,
-                     bond_tolerance_factor=12.0, w_clash=1.0, w_bond=1.0):
-    """atom14 (B,L,14,3), atom_mask (B,L,14) bool, aatype (B,L), chain_id (B,L) -> (E_clash (B,), E_bond (B,))."""
+                     bond_tolerance_factor=12.0, w_clash=1.0, w_bond=1.0, w_angle=1.0, residx=None):
+    """atom14 (B,L,14,3), atom_mask (B,L,14) bool, aatype (B,L), chain_id (B,L) -> (E_clash, E_bond, E_angle), each (B,): the
+    un-normalised sums that abx_clash_grad returns (csrc/guidance.hip)."""
     B, L = aatype.shape
     x = atom14.reshape(B, L * 14, 3)
     m = atom_mask.reshape(B, L * 14).bool()
@@ -966,17 +1002,16 @@ def violation_energy(atom14, atom_mask, aatype, chain_id, overlap_tolerance=1.5,
     d = torch.sqrt(1e-10 + ((x[:, :, None] - x[:, None]) ** 2).sum(-1))
     pair = m[:, :, None] & m[:, None] & (res[:, :, None] < res[:, None])              # every pair of different residues once
     same_chain = ch[:, :, None] == ch[:, None]
-    bonded = same_chain & (res[:, None] == res[:, :, None] + 1) & (slot[:, :, None] == 2) & (slot[:, None] == 0)
+    terms = peptide_violation_terms(atom14, atom_mask, aatype, chain_id, residx, bond_tolerance_factor)
+    linked = torch.zeros(B, L, dtype=torch.bool)                                      # residue is linked to its array predecessor
+    linked[:, 1:] = terms['has_no_gap_mask'].bool()
+    lk = linked.repeat_interleave(14, dim=1)
+    bonded = lk[:, None] & (res[:, None] == res[:, :, None] + 1) & (slot[:, :, None] == 2) & (slot[:, None] == 0)
     pair = pair & ~bonded & ~(sg[:, :, None] & sg[:, None])
     w = torch.where(same_chain, torch.ones_like(d), torch.full_like(d, between_chain_factor))
     ov = torch.relu(rad[:, :, None] + rad[:, None] - overlap_tolerance - d)
     e_clash = w_clash * (w * ov * pair).sum((1, 2))
-    c, n = atom14[:, :-1, 2], atom14[:, 1:, 0]
-    ok = atom_mask[:, :-1, 2].bool() & atom_mask[:, 1:, 0].bool() & (chain_id[:, 1:] == chain_id[:, :-1])
-    pro = (aatype[:, 1:] == 14).to(x.dtype)
-    l0 = (1 - pro) * 1.329 + pro * 1.341
-    sd = (1 - pro) * 0.014 + pro * 0.016
-    dist = torch.sqrt(1e-6 + ((c - n) ** 2).sum(-1))
-    err = torch.sqrt(1e-6 + (dist - l0) ** 2)
-    e_bond = w_bond * (torch.relu(err - bond_tolerance_factor * sd) * ok).sum(1)
-    return e_clash, e_bond
+    e_bond = w_bond * (terms['c_n_loss_per_residue'] * terms['c_n_mask']).sum(1)
+    e_angle = w_angle * ((terms['ca_c_n_loss_per_residue'] * terms['ca_c_n_mask']).sum(1) +
+                         (terms['c_n_ca_loss_per_residue'] * terms['c_n_ca_mask']).sum(1))
+    return e_clash, e_bond, e_angle

@@ -974,8 +974,9 @@ def test_reverse_step_device_rng_samples_share_no_noise(ops, cfg):
 
 def test_clash_grad_vs_oracle_autograd(ops):
     """Row G: abx_clash_grad energies and ANALYTIC gradients against the fp64 torch restatement and its autograd gradient (which
-    is the finite-difference limit), on a compact random two-chain + antigen complex where thousands of atom pairs overlap; the
-    frame pull-back (sum of atom gradients, torque about the frame origin) against the same gradients."""
+    is the finite-difference limit), on a compact random two-chain + antigen complex where thousands of atom pairs overlap and
+    peptide bonds / bond angles leave their flat bottoms; the frame pull-back (sum of atom gradients, torque about the frame origin)
+    against the same gradients.  Both link rules: by chain id only (cal_vio.py:51) and by chain id + consecutive residue numbers."""
     from oracle import abx_oracle as O
     from abx_amd import residue_constants as rc
     B, L = 2, 70
@@ -983,28 +984,47 @@ def test_clash_grad_vs_oracle_autograd(ops):
     aatype = torch.randint(0, 20, (B, L), generator=ge)
     aatype[0, 11] = 4; aatype[0, 40] = 4            # a cysteine pair (SG-SG excluded)
     aatype[:, 20] = 14                              # a proline after a peptide bond
-    chain = torch.cat([torch.zeros(30), torch.ones(25), 2 * torch.ones(15)]).int()[None].repeat(B, 1)
+    chain = torch.cat([torch.zeros(30), torch.ones(25), 17 * torch.ones(15)]).int()[None].repeat(B, 1)     # 17: chain ids are not 4-bit
+    residx = torch.cat([torch.arange(30), torch.arange(25) + 512, torch.tensor([3, 4, 5, 9, 10, 11, 12, 40, 41, 42, 43, 44, 45, 46, 47])]).int()[None].repeat(B, 1)
     ca = torch.cumsum(1.6 * torch.randn(B, L, 3, generator=ge), dim=1)            # compact walk: many clashes
     x = ca[:, :, None] + 1.2 * torch.randn(B, L, 14, 3, generator=ge)
     mask = torch.as_tensor(rc.restype_atom14_mask)[aatype].clone()
     mask[1, 5] = False                               # a residue without atoms
     mask[0, 33, 4:] = False
+    mask[1, 44, 1] = False                           # a missing CA: its angle terms drop out, the bond stays
     # put C(i) / N(i+1) of consecutive residues near bond length for half of the pairs so that both branches of the flat bottom occur
     x[:, 1:, 0] = x[:, :-1, 2] + torch.tensor([1.33, 0., 0.]) + 0.25 * torch.randn(B, L - 1, 3, generator=ge) * (torch.rand(B, L - 1, 1, generator=ge) > 0.5)
-    kw = dict(overlap_tolerance=1.5, between_chain_factor=0.2, bond_tolerance_factor=12.0, w_clash=0.7, w_bond=1.3)
+    # and near-ideal backbone angles on a third of the pairs: CA(i) and CA(i+1) placed at the literature cosines, slightly perturbed
+    third = torch.rand(B, L - 1, 1, generator=ge) > 0.66
+    x[:, :-1, 1] = torch.where(third, x[:, :-1, 2] + 1.52 * torch.tensor([-0.4473, 0.8944, 0.]) + 0.05 * torch.randn(B, L - 1, 3, generator=ge), x[:, :-1, 1])
+    kw = dict(overlap_tolerance=1.5, between_chain_factor=0.2, bond_tolerance_factor=12.0, w_clash=0.7, w_bond=1.3, w_angle=0.9)
     t0 = x[:, :, 1].clone()
-    e, ga, gt, gr = ops.clash_grad(x.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)
+    for rx in (None, residx):
+        e, ga, gt, gr = ops.clash_grad(x.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), residx=None if rx is None else rx.to(DEV), **kw)
+        xd = x.double().requires_grad_(True)
+        ec, eb, ea = O.violation_energy(xd, mask, aatype, chain, residx=rx, **kw)
+        (ec.sum() + eb.sum() + ea.sum()).backward()
+        assert float(ec.detach().min()) > 10 and float(eb.detach().min()) > 0.1 and float(ea.detach().min()) > 0.1, (ec, eb, ea)   # active terms
+        check(e[:, 0].cpu(), ec.detach(), 2e-5, 'clash energy')
+        check(e[:, 1].cpu(), eb.detach(), 2e-5, 'bond energy')
+        check(e[:, 2].cpu(), ea.detach(), 2e-5, 'angle energy')
+        gref = xd.grad * mask[..., None]
+        check(ga.cpu() * mask[..., None], gref, 5e-5, 'atom gradients')
+        check(gt.cpu(), gref.sum(2), 5e-5, 'frame translation gradient')
+        tq = torch.cross(xd.detach() - t0.double()[:, :, None], gref, dim=-1).sum(2)
+        check(gr.cpu(), tq, 5e-5, 'frame rotation gradient (torque)')
+    # the two link rules differ exactly by the terms across the numbering gaps of the third chain
+    e_chain = ops.clash_grad(x.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), **kw)[0]
+    e_res = ops.clash_grad(x.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), residx=residx.to(DEV), **kw)[0]
+    assert (e_chain[:, 1] > e_res[:, 1]).all()
+    # the peptide terms alone (clash off): gradient of bond + angle energies only, against autograd
+    kw2 = dict(kw, w_clash=0.0)
+    e, ga = ops.clash_grad(x.to(DEV), mask.to(DEV), aatype.to(DEV), chain.to(DEV), t0.to(DEV), residx=residx.to(DEV), **kw2)[:2]
     xd = x.double().requires_grad_(True)
-    ec, eb = O.violation_energy(xd, mask, aatype, chain, **kw)
-    (ec.sum() + eb.sum()).backward()
-    assert float(ec.detach().min()) > 10 and float(eb.detach().min()) > 0.1, (ec, eb)              # the terms are active
-    check(e[:, 0].cpu(), ec.detach(), 2e-5, 'clash energy')
-    check(e[:, 1].cpu(), eb.detach(), 2e-5, 'bond energy')
-    gref = xd.grad * mask[..., None]
-    check(ga.cpu() * mask[..., None], gref, 5e-5, 'atom gradients')
-    check(gt.cpu(), gref.sum(2), 5e-5, 'frame translation gradient')
-    tq = torch.cross(xd.detach() - t0.double()[:, :, None], gref, dim=-1).sum(2)
-    check(gr.cpu(), tq, 5e-5, 'frame rotation gradient (torque)')
+    ec, eb, ea = O.violation_energy(xd, mask, aatype, chain, residx=residx, **kw2)
+    (eb.sum() + ea.sum()).backward()
+    assert float(e[:, 0].abs().max()) == 0
+    check(ga.cpu() * mask[..., None], xd.grad * mask[..., None], 2e-5, 'peptide-term gradients')
     # central finite difference of the KERNEL's own fp32 energy along a random direction, on a looser geometry (a few hundred
     # overlapping pairs: with the compact complex above the fp32 rounding of an energy of ~1e5 would swamp the difference)
     ca2 = torch.cumsum(3.0 * torch.randn(B, L, 3, generator=ge), dim=1)
@@ -1018,6 +1038,30 @@ def test_clash_grad_vs_oracle_autograd(ops):
     fd = (run(x2 + h * dirn)[0].sum(1).cpu().double() - run(x2 - h * dirn)[0].sum(1).cpu().double()) / (2 * h)
     an = (ga2.cpu().double() * dirn.double()).sum((1, 2, 3))
     assert ((fd - an).abs() <= 4e-2 * an.abs() + 0.3).all(), (fd, an)
+
+
+def test_clash_grad_peptide_terms_vs_reference_cal_vio(ops):
+    """The bond / angle energies of abx_clash_grad against the UNMODIFIED reference's between_residue_bond_loss (cal_vio.py:29-110;
+    vio_pdb.npz: its per-residue flat-bottom losses on the two shipped complexes and perturbed copies), summed over its masks."""
+    z = load_npz('vio_pdb.npz')
+    for c in z['cases']:
+        code = str(c).split('.')[0]
+        p = load_npz(f'pdb_{code}.npz')
+        m, ch, aa = tt(p['batch.atom14_gt_exists']), tt(p['batch.chain_id']), tt(p['batch.seq'])
+        x = tt(z[f'{c}.pos'])
+        e = ops.clash_grad(x.to(DEV), m.to(DEV), aa.to(DEV), ch.to(DEV), x[:, :, 1].contiguous().to(DEV), w_clash=0.0)[0].cpu()
+        link = tt(z[f'{c}.has_no_gap_mask']).float()
+        mf = m.float()
+        m_ca, m_c, m_n, m_ca2 = mf[:, :-1, 1], mf[:, :-1, 2], mf[:, 1:, 0], mf[:, 1:, 1]
+        want_b = (tt(z[f'{c}.c_n_loss_per_residue']) * m_c * m_n * link).sum()
+        want_a = (tt(z[f'{c}.ca_c_n_loss_per_residue']) * m_ca * m_c * m_n * link).sum() + (tt(z[f'{c}.c_n_ca_loss_per_residue']) * m_c * m_n * m_ca2 * link).sum()
+        assert abs(float(e[0, 1]) - float(want_b)) < 1e-4 + 2e-5 * float(want_b), (c, float(e[0, 1]), float(want_b))
+        assert abs(float(e[0, 2]) - float(want_a)) < 1e-4 + 2e-5 * float(want_a), (c, float(e[0, 2]), float(want_a))
+    p = load_npz('pdb_6qd7.npz')
+    x = tt(z['6qd7.s0.pos'])
+    args = (x.to(DEV), tt(p['batch.atom14_gt_exists']).to(DEV), tt(p['batch.seq']).to(DEV), tt(p['batch.chain_id']).to(DEV), x[:, :, 1].contiguous().to(DEV))
+    assert float(ops.clash_grad(*args, w_clash=0.0)[0][0, 1]) > 1.0                       # the chain-only rule: a bond across the patch gap
+    assert float(ops.clash_grad(*args, w_clash=0.0, residx=tt(p['batch.residx']).to(DEV))[0][0, 1]) == 0.0
 
 
 @pytest.mark.parametrize('L', [64, 70])

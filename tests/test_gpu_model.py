@@ -60,7 +60,6 @@ def test_full_call_matches_reference_golden(gpu_model, cfg):
     for k in ('seq_t', 'rigids_t', 't', 'prev_pos', 'prev_seq', 'prev_pair', 'rot_score_scaling', 'trans_score_scaling'):
         b[k] = tt(m['in.' + k])
     b = to_dev(b)
-    model.invalidate_static()
     ret = model(b)
     torch.cuda.synchronize()
     f = ret['heads']['folding']
@@ -106,7 +105,6 @@ def test_warmup_call_fp32_t(gpu_model, cfg):
     ones = torch.ones(b['seq'].shape[0], device=DEV)
     b = sampler.set_t_feats(b, D, float(np.linspace(0.01, 1.0, 100)[::-1][0]), ones)
     assert b['t'].dtype == torch.float32
-    model.invalidate_static()
     ret = model(b)
     assert ret['heads']['folding']['trans_score'].dtype == torch.float32
     close(ret['heads']['folding']['rigids'], m['warm.rigids'], 1e-4, 1e-4, 'warm rigids')
@@ -188,7 +186,6 @@ def test_medium_complex_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
     b = sampler.set_t_feats(b, D, t_, torch.ones(3, device=DEV))
     cpu = {k: (v.cpu() if torch.is_tensor(v) else tuple(x.cpu() for x in v) if isinstance(v, tuple) else v) for k, v in b.items()}
     model.max_chunk = 2
-    model.invalidate_static()
     ret = model(b)
     model.max_chunk = None
     ref = O.score_network(params, cpu, cfg, oracle_diffuser)
@@ -223,7 +220,6 @@ def test_split_bf16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_di
         ops.GEMM_EXACT = exact
         try:
             model.max_chunk = None
-            model.invalidate_static()
             r = model(bb)
             torch.cuda.synchronize()
         finally:
@@ -422,7 +418,6 @@ def test_full_size_properties(gpu_model, cfg):
         if shared:
             bb['_shared_context'] = True
         model.max_chunk = chunk
-        model.invalidate_static()
         r = model(bb)
         torch.cuda.synchronize()
         return {'rigids': r['heads']['folding']['rigids'].clone(), 'logits': r['heads']['sequence_module']['logits'].clone(),
@@ -863,6 +858,143 @@ def test_graph_replay_equals_eager(gpu_model, cfg, w, B):
         assert torch.equal(e['seq'], g['seq']), f'step {k} tokens'
         assert torch.equal(e['rigids_t'].double(), g['rigids_t'].double()), f'step {k} rigids'
         assert torch.equal(e['atom14_results'], g['atom14_results']) and torch.equal(e['pLDDT'], g['pLDDT']), f'step {k} outputs'
+
+
+def test_graph_replay_with_guidance_equals_eager(gpu_model, cfg):
+    """the guided step inside hipGraph capture (no host-to-device copy, no allocation of host data on the step path):
+    bit-identical to the eager guided loop."""
+    from abx_amd import sampler
+    from abx_amd.guidance import ViolationGuidance
+    model, D = gpu_model
+    B = 2
+    b = _synthetic_batch(D, dict(L_heavy=30, L_light=26, L_antigen=16, cdr=(20, 27)), B=B)
+    b['_shared_context'] = True
+    sid = torch.arange(B, device=DEV) + 2
+    runs = []
+    for use_graph in (False, True):
+        D.seed = 8
+        runs.append(sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=6, sample_ids=sid, use_graph=use_graph,
+                                      guidance=ViolationGuidance(scale_trans=0.02, scale_rot=0.02)))
+    D.seed = 8
+    plain = sampler.sample_fn(b, cfg, D, model, mode='trajectory', num_t=6, sample_ids=sid)
+    for k, (e, g) in enumerate(zip(*runs)):
+        assert torch.equal(e['seq'], g['seq']) and torch.equal(e['rigids_t'].double(), g['rigids_t'].double()), f'step {k}'
+        assert torch.equal(e['atom14_results'], g['atom14_results'])
+    assert not torch.equal(runs[0][1]['rigids_t'], plain[1]['rigids_t'])             # and the guidance did act
+
+
+def _reference_style_loop(data_init, config, diffuser, model, mode, num_t, min_t=0.01):
+    """The CALL PATTERN of the reference's sample_fn (inference.py:180-273), written against the drop-in import paths: what a user who
+    switches packages executes.  deepcopy of the batch, dt as a 0-dim device tensor, t from a NumPy float64, diffuser.reverse with
+    the reference's keyword set only, per-step .to('cpu') of the outputs."""
+    import copy
+    from abx.model.abx import get_prev
+    batch = copy.deepcopy(data_init)
+    device = batch['rigids_t'].device
+    bb_mask = batch['atom14_gt_exists'][..., 0]
+    diffuse_mask = (1 - batch['fixed_mask']) * bb_mask
+    Lab = batch['anchor_flag'].shape[1]
+    n = batch['rigids_t'].shape[0]
+    t_placeholder = torch.ones(n, device=device, dtype=torch.float32)
+    grid = np.linspace(min_t, 1.0, num_t)[::-1]
+    dt = torch.tensor(1 / num_t, device=device)
+    if mode == 'optimize':
+        opt_step = batch['t'][0].cpu().numpy()
+        if opt_step < 1.0:
+            grid = grid[grid <= opt_step + 1e-8]
+
+    def set_t(feats, t):
+        feats['t'] = t * t_placeholder
+        rs, ts = diffuser.score_scaling(feats['t'])
+        feats['rot_score_scaling'] = rs * t_placeholder
+        feats['trans_score_scaling'] = ts * t_placeholder
+        return feats
+
+    traj = []
+    with torch.no_grad():
+        batch = set_t(batch, grid[0])
+        batch.update(get_prev(batch, model(batch), config.model))
+        for t in grid:
+            if t > min_t:
+                t_ = torch.tile(torch.tensor(t, device=device), (n,))
+                batch = set_t(batch, t_)
+                out = model(batch)
+                batch.update(get_prev(batch, out, config.model))
+                rigids_t, seq_t = diffuser.reverse(
+                    rigid_t=batch['rigids_t'], seq_t=batch['seq_t'], rot_score=out['heads']['folding']['rot_score'],
+                    trans_score=out['heads']['folding']['trans_score'], logits_t=out['heads']['sequence_module']['logits'],
+                    diffuse_mask=diffuse_mask, t=t_, dt=dt, center=True, noise_scale=1.0)
+            else:
+                out = model(batch)
+                rigids_t, seq_t = out['heads']['folding']['rigids'], out['heads']['sequence_module']['seq_0']
+            batch['rigids_t'], batch['seq_t'] = rigids_t, seq_t
+            pl = out['heads']['predicted_lddt']['pLDDT']
+            pl = torch.sum(pl * diffuse_mask, dim=1) / torch.sum(diffuse_mask, dim=1)
+            traj.append({'seq': torch.clamp(seq_t[:, :Lab], min=0, max=19).long().to('cpu').numpy(),
+                         'atom14_results': out['heads']['folding']['final_atom14_positions'][:, :Lab].to('cpu').numpy(),
+                         'pLDDT': torch.tile(pl[:, None], (1, Lab)).to('cpu').numpy(), 'time': t,
+                         'rigids_t': rigids_t.to('cpu').numpy()})
+    return traj if mode == 'trajectory' else traj[-1:]
+
+
+def test_reference_call_pattern_through_the_alias_packages(params, cfg, gpu_model, tmp_path, monkeypatch):
+    """VERDICT r2 weak #7a / INTEGRATION.md section A: `abx.model.abx` / `diffuser.full_diffuser` driven exactly the way the reference's
+    own loop drives them (see _reference_style_loop): singleton FullDiffuser.get(conf) that loads its IGSO(3) tables from the .npy
+    cache, no extension keyword anywhere; the recorded noise of traj_tiny.npz / optimize_tiny.npz reaches the kernel through a
+    monkey-patched reverse() only.  Tokens exact at every step, frames / atoms at the tolerance of the sampler tests."""
+    import copy
+    import abx.model.abx as ref_abx
+    import diffuser.full_diffuser as ref_fd
+    _, pinned = gpu_model
+    dc = copy.deepcopy(cfg.diffuser)
+    dc.so3.cache_dir = str(tmp_path / 'cache') + '/'
+    monkeypatch.setattr(ref_fd, 'diffuser_obj_dict', {})
+    D = ref_fd.FullDiffuser.get(dc)
+    assert ref_fd.FullDiffuser.get(dc) is D                                          # the reference's process-wide singleton
+    os.makedirs(D._cache_path(), exist_ok=True)                                      # so3_diffuser.py:131-174 cache contract
+    for name, tab in (('pdf_vals.npy', pinned._pdf), ('cdf_vals.npy', pinned._cdf), ('score_norms.npy', pinned.score_norms)):
+        np.save(os.path.join(D._cache_path(), name), tab.cpu().numpy())
+    model = ref_abx.ScoreNetwork(model_conf=cfg.model, diffuser=D)
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).eval()
+    orig_reverse = ref_fd.FullDiffuser.reverse
+    for fixture, mode, feat in (('traj_tiny.npz', 'trajectory', 'feat_tiny.npz'), ('optimize_tiny.npz', 'optimize', None)):
+        tj = load_npz(fixture)
+        if feat is not None:
+            b = to_dev(feat_batch_from_golden(load_npz(feat)))
+            num_t = 4
+        else:
+            b = feat_batch_from_golden(load_npz('feat_tiny.npz'))
+            for k in ('rigids_t', 'seq_t', 't', 'fixed_mask', 'rigids_0'):
+                b[k] = tt(tj['feat.' + k])
+            b = to_dev(b)
+            num_t = 100
+        calls = []
+
+        def patched(self, *a, **kw):
+            assert not a and set(kw) == {'rigid_t', 'seq_t', 'rot_score', 'trans_score', 'logits_t', 'diffuse_mask', 't', 'dt', 'center', 'noise_scale'}
+            k = len(calls)
+            calls.append(k)
+            return orig_reverse(self, noise=dict(z_rot=tt(tj[f'n{k}.z_rot']).to(DEV), z_trans=tt(tj[f'n{k}.z_trans']).to(DEV),
+                                                 jumps=tt(tj[f'n{k}.jumps']).to(DEV)), **kw)
+
+        monkeypatch.setattr(ref_fd.FullDiffuser, 'reverse', patched)
+        traj = _reference_style_loop(b, cfg, D, model, mode, num_t)
+        monkeypatch.setattr(ref_fd.FullDiffuser, 'reverse', orig_reverse)
+        if mode == 'trajectory':
+            assert len(traj) == 4 and len(calls) == 3
+            for k, d in enumerate(traj):
+                assert float(d['time']) == float(tj[f'k{k}.time'])
+                assert np.array_equal(d['seq'], tj[f'k{k}.seq']), f'step {k}: tokens differ'
+                close(d['atom14_results'], tj[f'k{k}.atom14'], 5e-3, 1e-4, f'step {k} atom14')
+                close(d['pLDDT'], tj[f'k{k}.pLDDT'], 1e-2, 1e-4, f'step {k} pLDDT')
+            close(traj[-1]['rigids_t'], tj['final.rigids_t'], 2e-3, 1e-4, 'final rigids')
+        else:
+            assert len(traj) == 1 and len(calls) == 3 and float(traj[0]['time']) == float(tj['last.time'])
+            assert np.array_equal(traj[0]['seq'], tj['last.seq'])
+            close(traj[0]['atom14_results'], tj['last.atom14'], 5e-3, 1e-4, 'optimize atom14')
+            close(traj[0]['pLDDT'], tj['last.pLDDT'], 1e-2, 1e-4, 'optimize pLDDT')
+            close(traj[0]['rigids_t'], tj['final.rigids_t'], 2e-3, 1e-4, 'optimize final rigids')
 
 
 def test_design_driver_two_ranks_shard_the_samples(tmp_path):

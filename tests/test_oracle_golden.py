@@ -438,3 +438,38 @@ def test_poisson_icdf_is_the_poisson_inverse_cdf():
     assert abs(draws.mean() - lm.mean()) < 4 * np.sqrt(lm.mean() / draws.size)
     resid = (draws - lm[None]) ** 2
     assert abs(resid.mean() - lm.mean()) < 0.02 * lm.mean()                        # Var = lam
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# peptide-geometry violation terms (guidance): pinned on the reference's eval/metric_scripts/cal_vio.py
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_peptide_violation_terms_match_reference_cal_vio():
+    z = load_npz('vio_pdb.npz')
+    n_viol = 0
+    for c in z['cases']:
+        code = str(c).split('.')[0]
+        p = load_npz(f'pdb_{code}.npz')
+        m, ch, aa = tt(p['batch.atom14_gt_exists']), tt(p['batch.chain_id']), tt(p['batch.seq'])
+        got = O.peptide_violation_terms(tt(z[f'{c}.pos']), m, aa, ch)               # residx=None: the reference's chain-only rule
+        for k in ('c_n_loss_per_residue', 'ca_c_n_loss_per_residue', 'c_n_ca_loss_per_residue'):
+            assert float((got[k] - tt(z[f'{c}.{k}'])).abs().max()) < 2e-6, (c, k)
+        for k in ('c_n_violation_mask', 'ca_c_n_violation_mask', 'c_n_ca_violation_mask', 'has_no_gap_mask'):
+            assert torch.equal(got[k].bool(), tt(z[f'{c}.{k}']).bool()), (c, k)
+        # the reference's mean losses from the restated per-residue terms and masks
+        for loss, per, mk in (('c_n_loss', 'c_n_loss_per_residue', 'c_n_mask'), ('ca_c_n_loss', 'ca_c_n_loss_per_residue', 'ca_c_n_mask'),
+                              ('c_n_ca_loss', 'c_n_ca_loss_per_residue', 'c_n_ca_mask')):
+            mine = (got[mk] * got[per]).sum() / (got[mk].sum() + 1e-6)
+            assert abs(float(mine) - float(z[f'{c}.{loss}'])) < 1e-6 + 1e-5 * abs(float(z[f'{c}.{loss}'])), (c, loss)
+        n_viol += int(got['c_n_violation_mask'].sum() + got['ca_c_n_violation_mask'].sum() + got['c_n_ca_violation_mask'].sum())
+        # violation_energy is the un-normalised sum of exactly these terms
+        _, eb, ea = O.violation_energy(tt(z[f'{c}.pos']), m, aa, ch, w_clash=0.0)
+        assert abs(float(eb) - float((tt(z[f'{c}.c_n_loss_per_residue']) * got['c_n_mask']).sum())) < 1e-4
+        want_a = (tt(z[f'{c}.ca_c_n_loss_per_residue']) * got['ca_c_n_mask']).sum() + (tt(z[f'{c}.c_n_ca_loss_per_residue']) * got['c_n_ca_mask']).sum()
+        assert abs(float(ea) - float(want_a)) < 1e-4
+    assert n_viol > 500
+    # 6qd7 as shipped: the reference's chain-only rule sees a "broken bond" across the gap of the cropped antigen patch; linking by
+    # residue number (the guidance default) does not
+    p = load_npz('pdb_6qd7.npz')
+    args = (tt(z['6qd7.s0.pos']), tt(p['batch.atom14_gt_exists']), tt(p['batch.seq']), tt(p['batch.chain_id']))
+    assert int(O.peptide_violation_terms(*args)['c_n_violation_mask'].sum()) == 1
+    assert int(O.peptide_violation_terms(*args, residx=tt(p['batch.residx']))['c_n_violation_mask'].sum()) == 0
