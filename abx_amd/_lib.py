@@ -41,9 +41,11 @@ class AbxGemm(C.Structure):
         ('A2', c_f), ('sA2b', LL), ('sA2m', LL), ('K2', I),
         ('B2_split', C.c_void_p), ('sB23p', LL), ('sB23n', LL), ('sB23k', LL),
         ('ln2_csum', c_f), ('bias2', c_f),
+        ('mlp', I), ('N2', I),
         ('out_ln_w', c_f), ('out_ln_b', c_f), ('out_ln_eps', F),
         ('exact', I),
         ('tune', I),
+        ('clock_probe', c_f),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
         ('c_vec_ok', I), ('g_vec_ok', I), ('r_vec_ok', I), ('rs_vec_ok', I),
     ]
@@ -59,6 +61,7 @@ class AbxTriAttn(C.Structure):
         ('B', I), ('S', I), ('L', I), ('H', I), ('D', I),
         ('scale', F),
         ('exact', I),
+        ('clock_probe', c_f),
     ]
 
 

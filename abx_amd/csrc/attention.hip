@@ -289,6 +289,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int bh = (slot / a.S) * 8 + xcd, s = slot % a.S;
     if (bh >= a.B * a.H) return;
+    const ClockProbe probe(a.clock_probe);
     const int b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, g = lane >> 4;
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             *reinterpret_cast<f32x4*>(op + dd) = v;
         }
     }
+    probe.finish();
 }
 
 // ---- sequence attention with pair bias (seqformer.py:314-356): 32 heads x 17 channels, bias (b, h, q, k) ---------------------------

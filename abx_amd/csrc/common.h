@@ -65,4 +65,19 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
+// Diagnostics (AbxGemm.clock_probe / AbxTriAttn.clock_probe): shader-clock and constant-100-MHz ticks a workgroup was resident for
+struct ClockProbe {
+    unsigned long long c0, r0;
+    unsigned long long* acc;
+    __device__ __forceinline__ explicit ClockProbe(unsigned long long* a) : c0(0), r0(0), acc(a) {
+        if (acc) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ __forceinline__ void finish() const {
+        if (acc && threadIdx.x == 0) {
+            atomicAdd(acc, (unsigned long long)__builtin_amdgcn_s_memtime() - c0);
+            atomicAdd(acc + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime() - r0);
+        }
+    }
+};
+
 #define ABX_NEG_MAX (-3.4028234663852886e38f)  // torch.finfo(float32).min

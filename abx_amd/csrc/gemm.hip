@@ -465,6 +465,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     ABX_REQUIRE(!g.glu, "abx_gemm: glu is served by the split-bf16 kernels only (large problems, K % 16 == 0)");
     ABX_REQUIRE(!g.A2, "abx_gemm: the dual GEMM is served by the split-bf16 kernels only");
     ABX_REQUIRE(!g.out_ln_w, "abx_gemm: out_ln is served by the split-bf16 kernels only");
+    ABX_REQUIRE(!g.mlp, "abx_gemm: the fused transition (mlp) is served by the split-bf16 kernels only (exact = 2, K % 16 == 0)");
     const long long mt128 = ((long long)g.M + 127) / 128;
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);

@@ -75,9 +75,13 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
 
 // Main loop of one output tile: acc += A' B for the operands of `g`; for the inline LayerNorm also the per-row partial sums
 // (ls, lq over this lane's k half, shifted by lshift).  Ends with all DMA drained and a block barrier (the LDS is free again).
-template <int BM, int BN, int WM, int WN, int AMODE>
+// SWAP: the MFMA operands trade places, acc[i][j] holds the TRANSPOSED 32 x 32 tile (rows = the tile's B rows / output columns, lane =
+// A row): the fused transition consumes it as the A operand of its second GEMM straight from the registers.
+// STATS: accumulate the inline LayerNorm partial sums and set lshift (the per-row shift of the operand, part of the statistics'
+// meaning); a caller that walks the same A rows again passes STATS = false and the lshift of its first walk.
+template <int BM, int BN, int WM, int WN, int AMODE, bool SWAP = false, bool STATS = true>
 __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, int mt, int nt, int b, f32x16 (&acc)[WM / 32][WN / 32],
-                                               float (&ls)[WM / 32], float (&lq)[WM / 32]) {
+                                               float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32]) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;                  // bytes per A stage
@@ -174,11 +178,11 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 
     const bool relu = g.a_relu != 0;
     const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
-    float lshift[TM];
     f32x2 ls2[TM], lq2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        ls[i] = lq[i] = lshift[i] = 0.f;
+        ls[i] = lq[i] = 0.f;
+        if constexpr (STATS) lshift[i] = 0.f;
         ls2[i] = lq2[i] = (f32x2){0.f, 0.f};
     }
 
@@ -243,14 +247,16 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                     // statistics of the row from this lane's 8 k (the other k half sits in lane ^ 32), shifted by the row's
                     // first element so that E[x^2] - mean^2 does not cancel when |mean| >> sigma.  Packed math: two elements
                     // per VALU instruction (even / odd partial sums, folded after the loop)
-                    if (t == 0) lshift[i] = __shfl(x[0], lane & 31, 64);
+                    if (STATS && t == 0) lshift[i] = __shfl(x[0], lane & 31, 64);
                     const f32x2 sh2 = {lshift[i], lshift[i]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         f32x2 xp = {x[2 * e], x[2 * e + 1]};
                         xp -= sh2;
-                        ls2[i] += xp;
-                        lq2[i] = __builtin_elementwise_fma(xp, xp, lq2[i]);
+                        if constexpr (STATS) {
+                            ls2[i] += xp;
+                            lq2[i] = __builtin_elementwise_fma(xp, xp, lq2[i]);
+                        }
                         x[2 * e] = xp[0];
                         x[2 * e + 1] = xp[1];
                     }
@@ -285,7 +291,8 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < JG; ++j)
-                        acc[i][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
+                        acc[i][j0 + j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[j][TB[term]], a[i][TA[term]], acc[i][j0 + j], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
         }
         wait_vm_and_barrier<0>();
     }
@@ -333,8 +340,8 @@ template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OL
 __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN];
-    float ls[TM], lq[TM];
-    gemm3_mainloop<BM, BN, WM, WN, AMODE>(g, smem, mt, nt, b, acc, ls, lq);
+    float ls[TM], lq[TM], lsh[TM];
+    gemm3_mainloop<BM, BN, WM, WN, AMODE>(g, smem, mt, nt, b, acc, ls, lq, lsh);
     float* st_lds = smem;                                   // [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     __syncthreads();
@@ -349,15 +356,15 @@ template <int BM, int BN, int WM, int WN, bool EDGE>
 __device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN], acc2[TM][TN];
-    float ls[TM], lq[TM], ls2[TM], lq2[TM];
+    float ls[TM], lq[TM], ls2[TM], lq2[TM], lsh[TM], lsh2[TM];
     AbxGemm g2 = g;                                          // operand view of the gate GEMM
     g2.A = g.A2; g2.sAb = g.sA2b; g2.sAm = g.sA2m; g2.sAk = 1; g2.K = g.K2;
     g2.A_split = nullptr; g2.a_relu = 0; g2.a_pair_transpose = 0; g2.a_pair = g.pair_Lp > 0 ? 1 : 0;
     g2.B_split = g.B2_split; g2.sB3p = g.sB23p; g2.sB3n = g.sB23n; g2.sB3k = g.sB23k; g2.sB3b = 0;
     g2.ln_csum = g.ln2_csum; g2.ln_stats = nullptr; g2.batch_inner = 0;
-    if (g.sAk == 1) gemm3_mainloop<BM, BN, WM, WN, 0>(g, smem, mt, nt, b, acc, ls, lq);
-    else gemm3_mainloop<BM, BN, WM, WN, 1>(g, smem, mt, nt, b, acc, ls, lq);
-    gemm3_mainloop<BM, BN, WM, WN, 0>(g2, smem, mt, nt, b, acc2, ls2, lq2);
+    if (g.sAk == 1) gemm3_mainloop<BM, BN, WM, WN, 0>(g, smem, mt, nt, b, acc, ls, lq, lsh);
+    else gemm3_mainloop<BM, BN, WM, WN, 1>(g, smem, mt, nt, b, acc, ls, lq, lsh);
+    gemm3_mainloop<BM, BN, WM, WN, 0>(g2, smem, mt, nt, b, acc2, ls2, lq2, lsh2);
     float* st_lds = smem;                                   // [BM][2] + [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     gemm3_row_stats<BM, BN, WM, WN, EDGE>(g2, st_lds + 2 * BM, mt, b, ls2, lq2);
@@ -391,8 +398,10 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     const int rem = (int)(wgid - (long long)b * per_batch);
     const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
+    const ClockProbe probe(g.clock_probe);
     if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS>(g, smem, mt, nt, b);
     else gemm3_block<BM, BN, WM, WN, AMODE, true, TS>(g, smem, mt, nt, b);
+    probe.finish();
 }
 
 // Linear -> LayerNorm over the output row (out_ln): k-contiguous fp32 A, one n-tile, plain store
@@ -430,6 +439,149 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     if (interior) gemm3_dual_block<BM, BN, WM, WN, false>(g, smem, mt, nt, b);
     else gemm3_dual_block<BM, BN, WM, WN, true>(g, smem, mt, nt, b);
+}
+
+// Fused two-layer transition (seqformer.py:358-376: LayerNorm -> Linear(4x) -> ReLU -> Linear, + residual) for 128 rows per block:
+//     out = relu(LN(A) W1 + b1) W2 + b2 (+ resid)          A: k-contiguous fp32 rows (K = g.K), hidden width g.N, output width g.N2
+// The hidden activations never exist in memory.  The hidden dimension is walked in chunks of 128:
+//   GEMM 1 of a chunk is the ordinary main loop with the MFMA operands SWAPPED, so a wave's accumulators hold the TRANSPOSED tiles
+//   H^T[hidden][row]: lane = row, registers = 16 hidden channels.  Folded LayerNorm (the row statistics are lane-local in this
+//   orientation), bias and ReLU are applied to the registers, which are then split into bf16 pieces and ARE the A operand of GEMM 2
+//   (lane = row, 8 k values per k-step): a 32 x 32 tile feeds two k-steps whose k slots (lane half h, slot i) hold the hidden
+//   channel 8 (i >> 2) + 4 h + (i & 3) of a 16-channel k-tile.  The W2 planes are stored with exactly that order inside every
+//   k-tile (AbxGemm.B2_split of an mlp descriptor; abx_amd.ops.permute_k16), so its fragments are the usual 16-byte reads.
+//   GEMM 2 streams the chunk's 8 k-tiles of W2 (all N2 <= 192 columns) through a double-buffered LDS stage of its own; its first
+//   tile is requested before GEMM 1 of the chunk starts.
+// A is read from HBM once (the 6 chunk walks of a block hit the L2 / MALL), the hidden never leaves the CU, the output rows are
+// written once: 2 x 192 floats of HBM traffic per pair row instead of 2 x 192 + 2 x 768.
+template <bool EDGE>
+__device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, int mt, int b) {
+    constexpr int BM = 128, BN = 128, WM = 32, WN = 128, BN2 = 192, TN2 = BN2 / 32;
+    constexpr int G1_BYTES = 2 * BM * 64 + 2 * 3 * BN * 32;                  // stages of GEMM 1 (A fp32 + W1 planes)
+    constexpr int B2_IMG = 3 * BN2 * 32;                                     // one k-tile of W2: [3][192][16] bf16
+    constexpr int NL2 = (B2_IMG + 4095) / 4096;
+    char* W2s = reinterpret_cast<char*>(smem) + G1_BYTES;                    // 2 stages
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    f32x16 acc2[1][TN2];
+#pragma unroll
+    for (int t = 0; t < TN2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[0][t][r] = 0.f;
+    // DMA sources of the W2 k-tiles (all N2 columns)
+    unsigned offs2[NL2];
+    plane_sources<BN2, NL2>(g.sB23p, g.sB23n, 0, g.N2, offs2);
+    const char* base2 = reinterpret_cast<const char*>(g.B2_split);
+    const long long step2 = g.sB23k * 2;
+    auto issue_w2 = [&](int ktile, int stage) {
+        char* dst = W2s + stage * B2_IMG + wave * NL2 * 1024;
+        const char* src = base2 + ktile * step2;
+#pragma unroll
+        for (int i = 0; i < NL2; ++i)
+            if (B2_IMG % 4096 == 0 || (wave * NL2 + i) * 1024 < B2_IMG) glds16(src + offs2[i], dst + i * 1024);
+    };
+    // fragment of n-tile t: + t * 1024 bytes (32 rows of 32 bytes; the half swap of plane_off depends on (row >> 3) & 1 only)
+    const int offB2 = plane_off<BN2>(0, lane & 31, h);
+    constexpr int TG2 = 2;                                                   // n-tiles per fragment group (register budget)
+    const bool rows_live = mt * BM + wave * WM < g.M;
+
+    float ls[1], lq[1], lsh[1] = {0.f};
+    float rstd = 0.f, dmean = 0.f;
+    const int nchunk = (g.N + BN - 1) / BN;
+    constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
+    for (int c = 0; c < nchunk; ++c) {
+        issue_w2(c * (BN / 16), 0);                                          // first W2 k-tile of the chunk: lands under GEMM 1
+        f32x16 acc1[1][BN / 32];
+        if (c == 0) {
+            gemm3_mainloop<BM, BN, WM, WN, 0, true, true>(g, smem, mt, c, b, acc1, ls, lq, lsh);
+            // row statistics of this lane's row (the two lane halves hold the two k halves)
+            const float invK = 1.0f / (float)g.K;
+            const float sm = ls[0] + __shfl_xor(ls[0], 32, 64), sq = lq[0] + __shfl_xor(lq[0], 32, 64);
+            dmean = sm * invK;
+            rstd = 1.0f / sqrtf(fmaxf(sq * invK - dmean * dmean, 0.f) + g.ln_eps);
+        } else {
+            gemm3_mainloop<BM, BN, WM, WN, 0, true, false>(g, smem, mt, c, b, acc1, ls, lq, lsh);
+        }
+        // (the main loop ended with every DMA drained - the W2 tile included - and a block barrier)
+        const int hid0 = c * BN;
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) {
+            // ---- H^T tile j: folded LayerNorm, bias, ReLU, split -> A fragments of two k-steps (one k-step = 8 registers of the tile),
+            // each followed by its k-tile of GEMM 2
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 hf[3];
+                {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int hc = hid0 + j * 32 + 8 * (2 * s2 + q) + 4 * h;    // 4 consecutive hidden channels
+                        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+                        if (hc + 4 <= g.N) {
+                            cs = *reinterpret_cast<const f32x4*>(g.ln_csum + hc);
+                            if (g.bias) bi = *reinterpret_cast<const f32x4*>(g.bias + hc);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (hc + e < g.N) { cs[e] = g.ln_csum[hc + e]; bi[e] = g.bias ? g.bias[hc + e] : 0.f; }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = rstd * (acc1[0][j][8 * s2 + 4 * q + e] - dmean * cs[e]) + bi[e];
+                            x = fmaxf(x, 0.f);
+                            v[4 * q + e] = (hc + e < g.N) ? x : 0.f;
+                        }
+                    }
+                    unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], q0[e], q1[e], q2[e]);
+                    hf[0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
+                    hf[1] = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
+                    hf[2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                }
+                const int kl = 2 * j + s2;                                   // k-tile of the chunk, stage kl & 1
+                const int knext = c * (BN / 16) + kl + 1;
+                if (kl + 1 < BN / 16 && knext * 16 < g.N) issue_w2(knext, (kl + 1) & 1);
+                const char* ws = W2s + (kl & 1) * B2_IMG + offB2;
+                if (rows_live && (c * (BN / 16) + kl) * 16 < g.N) {
+#pragma unroll
+                    for (int t0 = 0; t0 < TN2; t0 += TG2) {
+                        bf16x8 wb[TG2][3];
+#pragma unroll
+                        for (int t = 0; t < TG2; ++t)
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) wb[t][p] = *reinterpret_cast<const bf16x8*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
+#pragma unroll
+                        for (int term = 0; term < 6; ++term)
+#pragma unroll
+                            for (int t = 0; t < TG2; ++t)
+                                acc2[0][t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[TA[term]], wb[t][TB[term]], acc2[0][t0 + t], 0, 0, 0);
+                    }
+                }
+                wait_vm_and_barrier<0>();
+            }
+        }
+    }
+    // ---- epilogue: + bias2 (+ resid), plain store.  A view of the descriptor whose "GEMM" is the second layer.
+    AbxGemm g2 = g;
+    g2.N = g.N2; g2.bias = g.bias2; g2.ln_csum = nullptr; g2.ln_stats = nullptr; g2.act = 0; g2.alpha = 1.0f;
+    __syncthreads();
+    gemm_epilogue<BM, BN2, WM, BN2, EDGE, false>(g2, smem, smem + 2 * BM, acc2, mt * BM, 0, b, false);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm3_mlp_kernel(const AbxGemm g) {
+    constexpr int OPER = (2 * 128 * 64 + 2 * 3 * 128 * 32 + 2 * 3 * 192 * 32) / 4;           // floats
+    constexpr int EPI = 2 * 128 + 4 * 32 * (3 * 32 + 4);
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntm = (g.M + 127) / 128;
+    const long long nwg = gridDim.x, bid = blockIdx.x;
+    const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const long long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / ntm), mt = (int)(wgid - (long long)b * ntm);
+    const ClockProbe probe(g.clock_probe);
+    if ((mt + 1) * 128 <= g.M && g.N2 == 192) gemm3_mlp_block<false>(g, smem, mt, b);
+    else gemm3_mlp_block<true>(g, smem, mt, b);
+    probe.finish();
 }
 
 template <int BM, int BN, int WM, int WN, int MINW>
@@ -505,6 +657,22 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         const long long mt = ((long long)g.M + 127) / 128;
         hipLaunchKernelGGL((gemm3_oln_kernel<128, 128, 32, 128, 3>), dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(out_ln)");
+        return 0;
+    }
+    if (g.mlp) {
+        // fused two-layer transition: hidden = relu(LN(A) B + bias) never stored, out = hidden B2 + bias2 (+ resid)
+        if (g.A_split || g.sAk != 1 || g.c_transposed || g.C_split || g.glu || g.A2 || g.out_ln_w || !g.B2_split || g.N2 <= 0 || g.N2 > 192 ||
+            g.N % 16 != 0 || g.act != 1 || g.alpha != 1.0f || g.rowscale || g.gate || !g.ln_csum || g.ln_stats || g.a_relu ||
+            g.a_pair_transpose > 0 || g.pair_Lp > 0 || !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 ||
+            (long long)(g.N / 16) * g.sB23k >= (1LL << 31) || !al16(g.ln_csum) || (g.bias && !al16(g.bias))) {
+            abx_set_error("abx_gemm: mlp needs a k-contiguous fp32 A with folded LayerNorm, relu, N % 16 == 0, N2 <= 192, plain store, "
+                          "B2_split planes in the permuted k order");
+            *rc = ABX_ERR_ARG;
+            return 0;
+        }
+        const long long mt = ((long long)g.M + 127) / 128;
+        hipLaunchKernelGGL(gemm3_mlp_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
+        *rc = abx_check_launch("abx_gemm(mlp)");
         return 0;
     }
     if (g.A2) {

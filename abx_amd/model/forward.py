@@ -104,6 +104,13 @@ class Packed:
             self._split_cache[key] = self._split(self.wt[key])
         return self._split_cache[key]
 
+    def mlp_second(self, key):
+        """(planes, bias) of the second layer of a fused transition (AbxGemm.mlp): k order permuted inside every 16-tile."""
+        ck = ('mlp2', key)
+        if ck not in self._split_cache:
+            self._split_cache[ck] = ops.split_weights(ops.permute_k16(self.wt[key]))
+        return self._split_cache[ck], self.b.get(key)
+
     def split_narrow(self, wt, key):
         """bf16x3 image of a skinny (N <= 32) weight matrix: the pair-stack bias projections stream their 9.5 GB A operand
         through the 128 x 32 tile of the split-bf16 GEMM (DMA pipeline) instead of the exact kernel's register-staged loads."""
@@ -384,8 +391,12 @@ class Engine:
             _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'
-        _ln_lin(P, pre + '1', pre + '0', None, z2, w768, act=1)
-        _lin(P, pre + '3', w768, z2, resid=z2)
+        if P.gemm_mode == 2:
+            # LayerNorm -> Linear -> ReLU -> Linear + residual in ONE kernel: the 768-wide hidden never travels through HBM
+            _ln_lin(P, pre + '1', pre + '0', None, z2, z2, act=1, resid=z2, mlp=P.mlp_second(pre + '3'))
+        else:
+            _ln_lin(P, pre + '1', pre + '0', None, z2, w768, act=1)
+            _lin(P, pre + '3', w768, z2, resid=z2)
 
         # ================= IpaScore (score_network.py:83-196)
         ic = cfg.heads.diffusion_module.IPA

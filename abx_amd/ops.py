@@ -93,6 +93,18 @@ def pack_glu_weights(Wv, Wg, bv=None, bg=None):
     return W, b
 
 
+_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def permute_k16(Wt):
+    """Wt (K, N), K % 16 == 0 -> rows reordered inside every block of 16 as 0-3, 8-11, 4-7, 12-15: the k order in which the fused
+    transition (AbxGemm.mlp) feeds its second GEMM from the accumulator registers of the first (csrc/gemm3.hip)."""
+    K, N = Wt.shape
+    assert K % 16 == 0
+    idx = torch.tensor(_PERM16, device=Wt.device)
+    return Wt.reshape(K // 16, 16, N)[:, idx, :].reshape(K, N).contiguous()
+
+
 def split_weights(Wt):
     """Wt (K, N) packed weight (n-contiguous) -> int16 tensor [Kp/16][3][N][16] of k-tiled bf16 planes with
     W = p0 + p1 + p2 exactly (operand image of the split-bf16 GEMM kernels); Kp = K rounded up to 16."""
@@ -105,7 +117,7 @@ def split_weights(Wt):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -119,7 +131,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     tensor; c_pair: Cout / gate / resid are UNpadded (b, L*L, N) pair tensors (pad rows dropped).  rowscale is indexed by GEMM row.
     dual=(A2, B3_2, csum2, bias2): Cout = epi(A' B) * sigmoid(LN(A2) @ W2 + bias2) (+ resid): A2 (b, rows, K2) k-contiguous fp32 (the
     UNpadded pair tensor when pair is given), B3_2 = split_weights of the gamma-scaled gate weights (K2, N), csum2 their column sums.
-    out_ln=(gamma, beta[, eps]): LayerNorm over the N output columns right after bias / alpha / act (split-bf16 path only, N <= 128)."""
+    out_ln=(gamma, beta[, eps]): LayerNorm over the N output columns right after bias / alpha / act (split-bf16 path only, N <= 128).
+    mlp=(B3_2, bias2): fused two-layer transition Cout = relu(LN(A) @ B + bias) @ W2 + bias2 (+ resid); B (K, N) is the first layer
+    (N = hidden width, act must be 1, ln given), B3_2 = split_weights(permute_k16(W2t)) of the second layer W2t (N, N2), Cout / resid
+    have N2 <= 192 columns and may alias A."""
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
@@ -161,6 +176,14 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         _f32(B)
         g.B, g.sBb, g.sBk, g.sBn = _p(B), (B.stride(0) if B.shape[0] > 1 else 0), B.stride(1), B.stride(2)
     No = N // 2 if glu else N
+    if mlp is not None:
+        B32m, bias2m = mlp
+        assert B32m.dtype == torch.int16 and B32m.is_contiguous() and B32m.dim() == 4 and B32m.shape[0] * 16 == N and B32m.shape[1] == 3 and B32m.shape[3] == 16
+        No = B32m.shape[2]
+        g.mlp, g.N2 = 1, No
+        g.B2_split, g.sB23k, g.sB23p, g.sB23n = _p(B32m), B32m.stride(0), B32m.stride(1), B32m.stride(2)
+        g.bias2 = _p(bias2m)
+        assert act == 1 and ln is not None and ln[0] is None
     if c_planes:
         L = Cout.shape[4]
         Lp = pair[1] if pair is not None else L
@@ -217,6 +240,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         assert out_ln[0].numel() == N and out_ln[1].numel() == N
         g.out_ln_w, g.out_ln_b = _p(_f32(out_ln[0])), _p(_f32(out_ln[1]))
         g.out_ln_eps = float(out_ln[2]) if len(out_ln) > 2 else 1e-5
+    if clock_probe is not None:       # diagnostics: uint64[2] device accumulators (shader ticks, 100 MHz ticks)
+        assert clock_probe.dtype == torch.int64 and clock_probe.numel() >= 2
+        g.clock_probe = _p(clock_probe)
     g.bias = _p(bias)
     g.alpha = float(alpha)
     g.act = int(act)
@@ -233,7 +259,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         if resid.dim() == 2:
             resid = resid.unsqueeze(0)
         cd, sd = (1, 2) if g.c_transposed else (2, 1)
-        assert resid.shape == (nb, M if c_planes else Cout.shape[1], N) and resid.stride(cd) == 1, 'resid must be laid out like Cout'
+        assert resid.shape == (nb, M if c_planes else Cout.shape[1], No if mlp is not None else N) and resid.stride(cd) == 1, 'resid must be laid out like Cout'
         g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(sd)
     check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
     return Cout
@@ -292,7 +318,7 @@ def tri_attn_kernel_name(L, exact=None):
     return f'tri_attn4_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}, 128, true>'
 
 
-def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None):
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None):
     """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
     already laid out [b,h,q,k] for this orientation (bias_is_qk=True; then (B,H,L,Lp) with rows padded to Lp % 4 == 0 floats gives
     the kernel 16-byte bias loads for any L); out (B*L*L, H*D)."""
@@ -318,6 +344,9 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.B, a.S, a.L, a.H, a.D = B, L, L, H, D
     a.scale = float(D ** (-0.5))
     a.exact = int(GEMM_EXACT if exact is None else exact)
+    if clock_probe is not None:
+        assert clock_probe.dtype == torch.int64 and clock_probe.numel() >= 2
+        a.clock_probe = _p(clock_probe)
     check(lib.abx_tri_attn_fwd(C.byref(a), _stream()), 'abx_tri_attn_fwd')
     return out
 

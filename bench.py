@@ -86,6 +86,9 @@ class OpTimer:
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
             c_planes = C.dtype == torch.int16
+            if kw.get('mlp') is not None:       # fused transition: both layers' flops, rows in + rows out of HBM
+                N2 = kw['mlp'][0].shape[2]
+                return 'gemm3_mlp_kernel', 2.0 * nb * M * N * (K + N2), 4.0 * nb * M * (K + 2 * N2) + 6.0 * N * (K + N2)
             kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
                                              split=kw.get('B3') is not None, exact=kw.get('exact'), dual=kw.get('dual') is not None,
                                              out_ln=kw.get('out_ln') is not None)
@@ -107,7 +110,7 @@ class OpTimer:
         return name, 0.0, 0.0
 
     def __enter__(self):
-        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel')
+        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table')
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
             if callable(fn) and not name.startswith('_') and name not in skip and getattr(fn, '__module__', '') == self.ops.__name__:

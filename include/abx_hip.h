@@ -95,6 +95,13 @@ typedef struct AbxGemm {
     const float* A2; long long sA2b, sA2m; int K2;
     const unsigned short* B2_split; long long sB23p, sB23n, sB23k;   /* gate weights as k-tiled planes (abx_split_weights) */
     const float* ln2_csum; const float* bias2;     /* [N] column sums of the gamma-scaled gate weights, folded bias */
+    /* Fused two-layer transition (split-bf16 path, plain store; seqformer.py:358-376 LayerNorm -> Linear -> ReLU -> Linear + residual):
+     * mlp != 0:  C = relu(LN(A) B + bias) B2 + bias2 (+ resid), the N-wide hidden activations never leave the CU.  A k-contiguous
+     * fp32 with inline LayerNorm (ln_csum, ln_stats NULL), act = 1; N % 16 == 0 = hidden width; C / resid have N2 <= 192 columns;
+     * B2_split = planes of the second layer's weights [N/16][3][N2][16] (strides sB23k / sB23p / sB23n) whose 16 k of every k-tile
+     * are stored in the order 0-3, 8-11, 4-7, 12-15 (the accumulator layout of the first GEMM feeds the second one from
+     * registers); C may alias resid and A (a block reads its rows before it writes them). */
+    int mlp, N2;
     /* LayerNorm over the N OUTPUT columns (gamma, beta; eps), applied right after bias / alpha / act and before rowscale / gate /
      * resid: Linear -> LayerNorm without a round trip of the rows through HBM (score_network.py:117-120).  Needs a kernel whose
      * wave tile holds whole rows: split-bf16 path only (its own 128x128-tile instantiation), N <= 128, k-contiguous fp32 A, plain store */
@@ -106,6 +113,10 @@ typedef struct AbxGemm {
                                                       kernel only on shape / alignment grounds): callers that need results
                                                       independent of the batch size fix the arithmetic per op with 1 or 2 */
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
+    unsigned long long* clock_probe;               /* diagnostics, optional DEVICE [2]: every workgroup of the split-bf16 kernels adds
+                                                      its elapsed shader-clock ticks (s_memtime) to [0] and its elapsed constant
+                                                      100 MHz ticks (s_memrealtime) to [1]: 100 MHz * [0] / [1] = the shader clock
+                                                      the kernel actually ran at (tools/probes/clock_probe.py) */
     int a_vec_ok, b_vec_ok, fast_ok;               /* filled by the library */
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
@@ -141,6 +152,7 @@ typedef struct AbxTriAttn {
     float scale;
     int exact;                                      /* 0: split-bf16 matrix-core kernel (fp32-accurate, any L <= 1536);
                                                        1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
+    unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-bf16 kernel) */
 } AbxTriAttn;
 int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);
 

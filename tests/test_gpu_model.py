@@ -948,7 +948,7 @@ def test_reference_call_pattern_through_the_alias_packages(params, cfg, gpu_mode
     _, pinned = gpu_model
     dc = copy.deepcopy(cfg.diffuser)
     dc.so3.cache_dir = str(tmp_path / 'cache') + '/'
-    monkeypatch.setattr(ref_fd, 'diffuser_obj_dict', {})
+    monkeypatch.delitem(ref_fd.diffuser_obj_dict, 'diffuser', raising=False)      # a fresh process-wide singleton for this test
     D = ref_fd.FullDiffuser.get(dc)
     assert ref_fd.FullDiffuser.get(dc) is D                                          # the reference's process-wide singleton
     os.makedirs(D._cache_path(), exist_ok=True)                                      # so3_diffuser.py:131-174 cache contract

@@ -1,0 +1,23 @@
+import sys, torch
+sys.path.insert(0, '/root/repo')
+from abx_amd import ops
+from tools.kbench import timeit
+DEV='cuda:0'
+Bc, L = int(sys.argv[1]) if len(sys.argv) > 1 else 20, 352
+M2 = Bc * L * L
+r = lambda *s: torch.randn(*s, device=DEV)
+z = r(M2, 192)
+W1, W2 = r(192, 768) / 14, r(768, 192) / 28
+b1, cs1, b2 = r(768), r(768), r(192)
+W13, W23, W23p = ops.split_weights(W1), ops.split_weights(W2), ops.split_weights(ops.permute_k16(W2))
+hid = torch.empty(M2, 768, device=DEV)
+out = torch.empty(M2, 192, device=DEV)
+def two():
+    ops.gemm(z, W1, hid, bias=b1, ln=(None, cs1), B3=W13, act=1, exact=2)
+    ops.gemm(hid, W2, out, bias=b2, B3=W23, resid=z, exact=2)
+def fused():
+    ops.gemm(z, W1, out, bias=b1, ln=(None, cs1), B3=W13, act=1, resid=z, exact=2, mlp=(W23p, b2))
+fl = 2.0 * M2 * 768 * 384
+for name, fn in (('two launches', two), ('fused mlp', fused), ('two launches', two), ('fused mlp', fused)):
+    ms = timeit(fn, reps=7)
+    print(f'{name:14s} Bc={Bc} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
