@@ -258,15 +258,43 @@ def collate_single(ret):
     return out
 
 
+NPZ_KEYS = ('antibody_str_seq', 'antibody_coords', 'antibody_coord_mask', 'antibody_chain_ids', 'antibody_residx', 'antibody_cdr_def',
+            'antigen_str_seq', 'antigen_coords', 'antigen_coord_mask', 'antigen_chain_ids', 'antigen_residx', 'antigen_cdr_def')
+
+
+def save_struc_npz(struc, path):
+    """Write the chain features in the schema of the reference's preprocessed data set (`make_pdb_npz`,
+    abx/preprocess/make_ab_data_from_mmcif.py:145-191: one <name>.npz per complex under --data_dir)."""
+    np.savez(path, **{k: np.asarray(struc[k]) for k in NPZ_KEYS if k in struc})
+
+
+def _finish(struc, name, max_antigen_seq_len, seed, source):
+    ret = patch_around_anchor(structure_labels(struc, name))
+    if ret is None:
+        raise ValueError(f'{source}: no antigen residue within 16 A of a CDR anchor')
+    ret = crop_antigen(ret, max_antigen_seq_len, random.Random(seed))
+    return collate_single(ret)
+
+
+def load_complex_npz(data_dir, name, max_antigen_seq_len=32, seed=0):
+    """`dataset.load` for ONE entry of a --name_idx list (abx/data/dataset.py:90-214,554-571): <data_dir>/<name>.npz in the
+    reference's `make_pdb_npz` schema -> the collated batch (B = 1), through the same centring / antigen patch / window crop /
+    collate as load_complex.  BASELINE configs 3 / 4 (diffab_test.idx, the RAbD list) are lists of such entries."""
+    path = os.path.join(data_dir, name + '.npz')
+    with np.load(path) as z:
+        struc = {k: z[k] for k in z.files}
+    missing = [k for k in ('antibody_str_seq', 'antibody_coords', 'antibody_coord_mask', 'antibody_chain_ids', 'antibody_residx',
+                           'antibody_cdr_def') if k not in struc]
+    if missing:
+        raise ValueError(f'{path}: not a make_pdb_npz file (missing {missing})')
+    return _finish(struc, name, max_antigen_seq_len, seed, path)
+
+
 def load_complex(pdb_file, max_antigen_seq_len=32, seed=0):
     """`dataset.load_single` for one PDB file named <code>_<H>_<L>_<antigen chains>.pdb -> the collated batch (B = 1) that
     abx_amd.features.build_features consumes, plus `meta` for the PDB writer."""
     name, code, heavy, light, antigens = parse_pdb_name(pdb_file)
     struc = make_pdb_features(pdb_file, heavy, light, antigens)
-    ret = patch_around_anchor(structure_labels(struc, name))
-    if ret is None:
-        raise ValueError(f'{pdb_file}: no antigen residue within 16 A of a CDR anchor')
-    ret = crop_antigen(ret, max_antigen_seq_len, random.Random(seed))
-    batch = collate_single(ret)
+    batch = _finish(struc, name, max_antigen_seq_len, seed, pdb_file)
     batch['cdrs'] = struc['cdrs']
     return batch

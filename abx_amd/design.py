@@ -8,6 +8,18 @@ and write the PDB files (per step in trajectory mode, asynchronously).
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m abx_amd.design \
         --pdb_list diffab_test.txt --pdb_dir pdbs/ --num_samples 100 --output_dir out/                        (a test set on 8 GPUs)
 
+    python -m abx_amd.design --name_idx diffab_test.idx --data_dir npz/ --model_features config_data_feature.json \
+        --model abx_diffab.ckpt --model_config config_model.json --gpu_list 0 1 2 3 4 5 6 7 --num_samples 100 --output_dir out/
+                                                                     (inference.py's own command line: BASELINE configs 3 / 4)
+
+--name_idx / --data_dir / --model_features / --gpu_list / --batch_size are the arguments of the reference's inference.py
+(inference.py:398-416): one complex name per line, <data_dir>/<name>.npz in the `make_pdb_npz` schema (abx_amd.data.antibody.
+load_complex_npz), the feature-pipeline JSON (its make_diffuser_features entry supplies generate_area and, in optimize mode, the
+list of optimize_steps that is looped over like inference.py:310-345), and the output layout of inference.py:
+<output_dir>/<mode>[/OPT-<step>]/reference/<name>.pdb (the ground truth) and .../<k:04d>/<name>.pdb for sample k.  --gpu_list with
+more than one entry starts one rank per listed GPU through torch.distributed.run (the reference spawns one worker per GPU that all
+repeat the same work, inference.py:376-381; here the samples are sharded).  --batch_size (complexes per DataLoader batch upstream) is
+accepted and ignored: complexes run one after the other with all local samples of a complex in one batch.
 --pdb_file follows the reference's naming contract <code>_<heavy>_<light>_<antigen chains joined by |>.pdb (dataset.py:290-293);
 it is read by abx_amd.data.antibody (plain-text parser, landmark IMGT locator, 16 A antigen patch, 32-residue window).
 Several files (or --pdb_list, one name per line, relative to --pdb_dir) are processed one after the other.
@@ -50,6 +62,31 @@ def sample_names(name, ids, num_samples):
     return [f'{head}-{i:03d}_{tail}' for i in ids]
 
 
+def read_model_features(path):
+    """The make_diffuser_features entry of a feature-pipeline JSON (config/config_data_feature.json): (generate_area, optimize_steps)."""
+    import json
+    with open(path, encoding='utf-8') as f:
+        feats = json.load(f)
+    for name, opts in feats:
+        if 'diffuse' in name:
+            return opts.get('generate_area', 'H3'), list(opts.get('optimize_steps', []))
+    return 'H3', []
+
+
+def _relaunch_on_gpus(gpu_list, argv):
+    """--gpu_list a b c ... outside torch.distributed.run: one rank per listed GPU on 127.0.0.1."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES=','.join(str(g) for g in gpu_list), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={len(gpu_list)}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), '-m', 'abx_amd.design'] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--pdb_file', nargs='*', default=None, help='antibody-antigen complex(es), <code>_<H>_<L>_<antigen chains>.pdb')
@@ -70,10 +107,36 @@ def main(argv=None):
     ap.add_argument('--guidance_scale', type=float, nargs=2, default=[1.0, 1.0], metavar=('TRANS', 'ROT'),
                     help='step scales of the guidance gradients on the translation / rotation scores')
     ap.add_argument('--debug_one_gpu', action='store_true', help='debugging on a 1-GPU box: every rank uses cuda:0 and the gloo backend')
+    # the reference's inference.py arguments (inference.py:398-416)
+    ap.add_argument('--name_idx', default=None, help='text file with one complex name per line (entries of --data_dir)')
+    ap.add_argument('--data_dir', default=None, help='directory of <name>.npz files in the make_pdb_npz schema')
+    ap.add_argument('--model_features', default=None, help='feature-pipeline JSON (config/config_data_feature.json): generate_area, optimize_steps')
+    ap.add_argument('--gpu_list', type=int, nargs='+', default=None, help='GPUs to use, one rank each (default: the launcher\'s ranks / GPU 0)')
+    ap.add_argument('--batch_size', type=int, default=1, help='accepted for compatibility (complexes per batch upstream); ignored')
+    ap.add_argument('--verbose', action='store_true')
     a = ap.parse_args(argv)
+    if a.gpu_list and len(a.gpu_list) > 1 and 'WORLD_SIZE' not in os.environ:
+        import sys
+        rc_ = _relaunch_on_gpus(a.gpu_list, sys.argv[1:] if argv is None else argv)
+        if rc_ != 0:
+            raise SystemExit(rc_)
+        return []
+    if a.name_idx and not a.data_dir:
+        ap.error('--name_idx needs --data_dir')
+    opt_steps = [a.optimize_steps]
+    if a.model_features:
+        a.generate_area, steps = read_model_features(a.model_features)
+        if a.mode == 'optimize' and steps:
+            opt_steps = steps
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpu_list and len(a.gpu_list) == 1 and not a.device and 'WORLD_SIZE' not in os.environ:
+        a.device = f'cuda:{a.gpu_list[0]}'
+    if a.device in ('gpu', 'cpu'):                      # the reference's --device choices
+        if a.device == 'cpu':
+            raise SystemExit('abx_amd runs on an MI355X only: there is no CPU path (the oracle under oracle/ is test infrastructure)')
+        a.device = None
     dev = torch.device(a.device if a.device else ('cuda:0' if a.debug_one_gpu else f'cuda:{local_rank}'))
     torch.cuda.set_device(dev)
     group = None
@@ -99,18 +162,41 @@ def main(argv=None):
     N = a.num_samples
     ids = sampler.shard_sample_ids(N, rank, world)             # the global sample ids this rank runs, for every complex
     n = len(ids)
-    complexes = complex_list(a.pdb_file, a.pdb_list, a.pdb_dir) or [None]
+    # jobs: (kind, reference to the complex, output directory, optimize step, inference.py layout?)
+    jobs = []
+    if a.name_idx:
+        with open(a.name_idx) as f:
+            names = [x.strip() for x in f if x.strip()]
+        root = os.path.join(a.output_dir, a.mode)
+        for step in (opt_steps if a.mode == 'optimize' else [None]):
+            out = os.path.join(root, f'OPT-{step}') if a.mode == 'optimize' else root
+            jobs += [('npz', nm, out, step, True) for nm in names]
+    else:
+        for step in (opt_steps if a.mode == 'optimize' else [None]):
+            out = os.path.join(a.output_dir, f'OPT-{step}') if (a.mode == 'optimize' and len(opt_steps) > 1) else a.output_dir
+            jobs += [('pdb' if path is not None else 'synthetic', path, out, step, False)
+                     for path in (complex_list(a.pdb_file, a.pdb_list, a.pdb_dir) or [None])]
     os.makedirs(a.output_dir, exist_ok=True)
     files = []
-    for path in complexes:
-        if path is not None:
-            from .data.antibody import load_complex
-            cb = load_complex(path, seed=a.seed)
+    for kind, path, out_dir, opt_step, ref_layout in jobs:
+        os.makedirs(out_dir, exist_ok=True)
+        if kind in ('pdb', 'npz'):
+            from .data.antibody import load_complex, load_complex_npz
+            cb = load_complex(path, seed=a.seed) if kind == 'pdb' else load_complex_npz(a.data_dir, path, seed=a.seed)
             one = {k: v.to(dev) for k, v in cb.items() if torch.is_tensor(v)}
             cname = cb['name'][0]
             meta = {k: list(cb[k]) * n for k in ('str_heavy_seq', 'str_light_seq', 'antigen_origin_str_seq',
                                                  'antigen_origin_atom14_gt_positions', 'antigen_origin_atom14_gt_exists',
                                                  'antigen_origin_chain_ids')}
+            if ref_layout and rank == 0:
+                # inference.py:346-361: the "reference batch" = the ground-truth antibody with pLDDT 100, written once per complex
+                from .io import postprocess_trajectory
+                Lab0 = one['anchor_flag'].shape[1]
+                ref_meta = {k: list(cb[k]) for k in meta}
+                ref_meta['name'] = [cname]
+                files += postprocess_trajectory(ref_meta, [{'seq': one['seq'][:, :Lab0], 'atom14_results': one['atom14_gt_positions'][:, :Lab0],
+                                                            'pLDDT': torch.full((1, Lab0), 100.0), 'time': 0.0}],
+                                                os.path.join(out_dir, 'reference'))
         else:
             w = synthetic.WORKLOADS[a.workload]
             cx = synthetic.make_complex(seed=a.seed + 1, **w)
@@ -119,16 +205,20 @@ def main(argv=None):
             seq = cx['seq'].tolist()
             cname = f'{a.workload}_H_L_A'
             meta = dict(str_heavy_seq=[index_to_str_seq(seq[:nh])] * n, str_light_seq=[index_to_str_seq(seq[nh:nh + nl])] * n)
-        meta['name'] = sample_names(cname, ids, N)
+        if ref_layout:                                      # inference.py:363-367: <k:04d>/<name>.pdb
+            meta['name'] = [cname] * n
+            meta['subdir'] = [f'{i:04d}' for i in ids]
+        else:
+            meta['name'] = sample_names(cname, ids, N)
         L, Lab = one['seq'].shape[1], one['anchor_flag'].shape[1]
         if n > 0:
             raw = {k: v.expand(n, *v.shape[1:]).contiguous() for k, v in one.items()}
             batch = features.build_features(raw, diffuser, generate_area=a.generate_area,
-                                            opt_step=a.optimize_steps if a.mode == 'optimize' else None,
+                                            opt_step=opt_step if a.mode == 'optimize' else None,
                                             noise=features.per_sample_init_noise(ids, L, a.seed, dev))
             batch['_shared_context'] = True
             diffuser.seed = a.seed
-            writer = TrajectoryWriter(meta, a.output_dir, multi=a.mode == 'trajectory')
+            writer = TrajectoryWriter(meta, out_dir, multi=a.mode == 'trajectory')
             traj = sampler.sample_fn(batch, cfg, diffuser, model, mode=a.mode, num_t=a.num_t,
                                      sample_ids=torch.tensor(ids, device=dev, dtype=torch.int64), on_record=writer.submit, guidance=guide)
             torch.cuda.synchronize()
@@ -140,7 +230,7 @@ def main(argv=None):
             local = {k: v.cpu() for k, v in local.items()}
         res = sampler.gather_results(local, N, rank, world, group)
         if rank == 0:
-            tsv = os.path.join(a.output_dir, f'{cname}_designs.tsv')
+            tsv = os.path.join(out_dir, f'{cname}_designs.tsv')
             with open(tsv, 'w') as f:
                 f.write('sample\tmean_pLDDT\tantibody_sequence\n')
                 for i in range(N):

@@ -5,8 +5,9 @@ writer so that a per-step trajectory dump (BASELINE config 5) never stalls the G
 The reference builds Bio.PDB Atom/Residue/Chain objects and calls `PDBIO.save`; Biopython is not available in this image, so
 the record layout below restates PDBIO's ATOM / TER / END format (Bio/PDB/PDBIO.py `_ATOM_FORMAT_STRING`,
 `_TER_FORMAT_STRING`: atoms renumbered from 1, the TER record takes the next serial WITHOUT consuming it, element = first
-letter of the atom name, occupancy 1.00, B-factor = pLDDT).  PARITY UNPINNED: no golden output of the reference exists for it
-(its own writer cannot run here); tests check the format rules and the round trip of coordinates / sequences.
+letter of the atom name, occupancy 1.00, B-factor = pLDDT).  PINNED on the two example complexes the reference ships
+(test_data/*.pdb, themselves written by PDBIO: tests/golden/pdb/): every ATOM / TER / END record of those files is reproduced
+character for character from its parsed fields (tests/test_pdb_writer.py::test_record_layout_matches_the_shipped_pdbio_files).
 
 This is host-side I/O: plain Python / numpy, no kernel involved."""
 import os
@@ -19,7 +20,7 @@ import torch
 from .. import residue_constants as rc
 
 _ATOM_FMT = "%s%5i %-4s%c%3s %c%4i%c   %8.3f%8.3f%8.3f%s%6.2f      %4s%2s%2s\n"
-_TER_FMT = "TER   %5i      %3s %c%4i%c" + " " * 53 + "\n"          # 80 columns
+_TER_FMT = "TER   %5i      %3s %c%4i%c" + " " * 54 + "\n"          # PDBIO's TER record is 81 columns wide (pinned on test_data/*.pdb)
 
 
 def index_to_str_seq(idx):
@@ -102,7 +103,11 @@ def _one_record_files(meta, rec, output_dir, multi):
                        'antigen_chain_ids': meta['antigen_origin_chain_ids'][i],
                        # design.py:152 splits the antigen chain ids on '|' ('6qd7_X_Z_F|E'); inference.py:149 takes the characters
                        'antigen_chains': parts[-1].split('|') if '|' in parts[-1] else list(parts[-1])}
-        path = f'{output_dir}/{name}@{time:.4f}.pdb' if time else f'{output_dir}/{name}.pdb'
+        out_i = output_dir
+        if meta.get('subdir') is not None:              # inference.py's layout: one directory per sample (<k:04d>/<name>.pdb)
+            out_i = os.path.join(output_dir, meta['subdir'][i])
+            os.makedirs(out_i, exist_ok=True)
+        path = f'{out_i}/{name}@{time:.4f}.pdb' if time else f'{out_i}/{name}.pdb'
         save_pdb(index_to_str_seq(seq[:nh]), parts[1], index_to_str_seq(seq[nh:nh + nl]), parts[2],
                  rec['atom14_results'][i, :nh + nl], path, rec['pLDDT'][i], antigen)
         files.append(path)

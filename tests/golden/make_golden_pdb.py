@@ -58,6 +58,10 @@ for fname in ('6ct7_H_L_S.pdb', '6qd7_X_Z_F|E.pdb'):
     name, code, heavy, light, antigens = A.parse_pdb_name(path)
     struc = A.make_pdb_features(path, heavy, light, antigens)
     cdrs = struc.pop('cdrs')
+    # the same chain features in the schema of the reference's preprocessed data set (make_pdb_npz): the inputs of its --name_idx /
+    # --data_dir path (abx/data/dataset.py:90-214), used by tests/test_pdb_features.py::test_npz_entry_*
+    os.makedirs(os.path.join(HERE, 'npz'), exist_ok=True)
+    A.save_struc_npz(struc, os.path.join(HERE, 'npz', name + '.npz'))
     ds = object.__new__(ref_dataset.IgStructureData)               # the reference class without its Biopython-based __init__
     ds.ret, ds.pdb_name, ds.is_training, ds.max_antigen_seq_len = copy.deepcopy(struc), name, False, 32
     random.seed(SEED)                                              # the reference's window crop uses the global `random`

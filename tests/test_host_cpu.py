@@ -249,3 +249,20 @@ def test_design_driver_complex_list_and_sample_names(tmp_path):
     ids = sampler.shard_sample_ids(100, 7, 8)
     assert ids == list(range(88, 100))
     assert design.sample_names('6qd7_X_Z_F|E', ids, 100)[:2] == ['6qd7-088_X_Z_F|E', '6qd7-089_X_Z_F|E']
+
+
+def test_metrics_match_reference_calc_ab_metrics():
+    """VERDICT r2 missing #5: abx_amd.metrics.calc_ab_metrics against the UNMODIFIED reference's abx.common.ab_utils.calc_ab_metrics
+    (tests/golden/make_golden_metrics.py: the 6qd7 antibody vs perturbed / rigidly moved / mutated copies): same keys in the same
+    order, RMSD to 1e-9, AAR exact."""
+    from abx_amd import metrics
+    from conftest import load_npz
+    z = load_npz('metrics_6qd7.npz')
+    gt, cdr, gs = z['gt_coord'], z['cdr_def'], str(z['gt_str_seq'])
+    for c in z['cases']:
+        m = metrics.calc_ab_metrics(gt, z[f'{c}.pred_coord'], cdr, gs, str(z[f'{c}.pred_str_seq']))
+        assert list(m.keys()) == [str(k) for k in z[f'{c}.names']]
+        ref = z[f'{c}.values']
+        for (k, v), r in zip(m.items(), ref):
+            assert abs(v - r) <= (0.0 if k.endswith('AAR') else 1e-9 * max(1.0, abs(r))), (c, k, v, r)
+    assert float(z['c3.values'].max()) > 5.0 and float(z['c0.values'].min()) < 1e-12

@@ -116,3 +116,40 @@ def test_ab_metrics_rmsd_and_aar():
     m2 = metrics.calc_ab_metrics(ca, pert, cdr, seq, ''.join(mut))
     assert m2['heavy_cdr3_AAR'] == pytest.approx(1 - 2 / len(h3)) and m2['heavy_cdr3_Loop_AAR'] == pytest.approx(1 - 1 / (len(h3) - 6))
     assert 0.5 < m2['heavy_cdr3_RMSD'] < 1.0 and m2['light_cdr3_RMSD'] < 0.1 and m2['heavy_cdr1_AAR'] == 1.0
+
+
+@pytest.mark.parametrize('code', ['6ct7', '6qd7'])
+def test_npz_entry_of_a_name_idx_list_matches_reference(code):
+    """The --name_idx / --data_dir path of the reference's inference.py (abx/data/dataset.py:90-214): <data_dir>/<name>.npz in the
+    make_pdb_npz schema -> the collated batch.  Against the reference's own get_structure_label_npz / Patch_Around_Anchor / collate_fn
+    outputs on the same arrays (pdb_<code>.npz 'batch.*') and against the raw-PDB route."""
+    from abx_amd.data import antibody as A
+    g = load_npz(f'pdb_{code}.npz')
+    name = os.path.basename(PDB[code])[:-4]
+    data_dir = os.path.join(GOLDEN, 'npz')
+    with np.load(os.path.join(data_dir, name + '.npz')) as z:
+        assert set(z.files) == set(A.NPZ_KEYS)                                     # the schema of make_pdb_npz
+        for k in A.NPZ_KEYS:
+            assert np.array_equal(z[k], g['struc.' + k]), k
+    b = A.load_complex_npz(data_dir, name, seed=int(g['seed']))
+    for k in ('seq', 'mask', 'atom14_gt_exists', 'cdr_def', 'chain_id', 'residx', 'anchor_flag', 'atom14_gt_positions'):
+        assert np.array_equal(b[k].numpy(), g['batch.' + k]), k
+    assert b['name'] == (name,) and b['str_heavy_seq'][0] == str(g['batch.str_heavy_seq'])
+    assert b['antigen_origin_str_seq'][0] == str(g['batch.antigen_origin_str_seq'])
+    p = A.load_complex(PDB[code], seed=int(g['seed']))
+    for k, v in b.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, p[k]), k
+    with pytest.raises(ValueError, match='make_pdb_npz'):
+        np.savez(os.path.join('/tmp', 'abx_bad_entry.npz'), foo=np.zeros(3))
+        A.load_complex_npz('/tmp', 'abx_bad_entry')
+
+
+def test_model_features_json():
+    """read_model_features: generate_area / optimize_steps of the reference's feature-pipeline JSON (config_data_feature.json layout)."""
+    import json
+    from abx_amd import design
+    path = '/tmp/abx_feats.json'
+    json.dump([["make_to_device", {"fields": ["seq"], "device": "%(device)s"}], ["make_gt_frames", {}],
+               ["make_diffuser_features", {"generate_area": "H3", "optimize_steps": [4, 8]}]], open(path, 'w'))
+    assert design.read_model_features(path) == ('H3', [4, 8])
