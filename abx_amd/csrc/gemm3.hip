@@ -569,7 +569,8 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
     gemm_epilogue<BM, BN2, WM, BN2, EDGE, false>(g2, smem, smem + 2 * BM, acc2, mt * BM, 0, b, false);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm3_mlp_kernel(const AbxGemm g) {
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
     constexpr int OPER = (2 * 128 * 64 + 2 * 3 * 128 * 32 + 2 * 3 * 192 * 32) / 4;           // floats
     constexpr int EPI = 2 * 128 + 4 * 32 * (3 * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
@@ -671,7 +672,8 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
             return 0;
         }
         const long long mt = ((long long)g.M + 127) / 128;
-        hipLaunchKernelGGL(gemm3_mlp_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
+        if ((g.tune >> 4) & 1) hipLaunchKernelGGL(gemm3_mlp_kernel<1>, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);       // benchmarking
+        else hipLaunchKernelGGL(gemm3_mlp_kernel<2>, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(mlp)");
         return 0;
     }

@@ -62,6 +62,9 @@ def sample_names(name, ids, num_samples):
     return [f'{head}-{i:03d}_{tail}' for i in ids]
 
 
+TIMINGS = []      # one dict per complex of the last main() call: seconds spent reading / featurising, sampling, waiting for the writer
+
+
 def read_model_features(path):
     """The make_diffuser_features entry of a feature-pipeline JSON (config/config_data_feature.json): (generate_area, optimize_steps)."""
     import json
@@ -178,7 +181,10 @@ def main(argv=None):
                      for path in (complex_list(a.pdb_file, a.pdb_list, a.pdb_dir) or [None])]
     os.makedirs(a.output_dir, exist_ok=True)
     files = []
+    import time
+    del TIMINGS[:]
     for kind, path, out_dir, opt_step, ref_layout in jobs:
+        t_job = time.perf_counter()
         os.makedirs(out_dir, exist_ok=True)
         if kind in ('pdb', 'npz'):
             from .data.antibody import load_complex, load_complex_npz
@@ -219,10 +225,17 @@ def main(argv=None):
             batch['_shared_context'] = True
             diffuser.seed = a.seed
             writer = TrajectoryWriter(meta, out_dir, multi=a.mode == 'trajectory')
+            torch.cuda.synchronize()
+            t_feat = time.perf_counter()
             traj = sampler.sample_fn(batch, cfg, diffuser, model, mode=a.mode, num_t=a.num_t,
                                      sample_ids=torch.tensor(ids, device=dev, dtype=torch.int64), on_record=writer.submit, guidance=guide)
             torch.cuda.synchronize()
-            files += writer.close()
+            t_samp = time.perf_counter()
+            new_files = writer.close()
+            files += new_files
+            t_done = time.perf_counter()
+            TIMINGS.append(dict(complex=cname, L=int(L), samples=n, mode=a.mode, opt_step=opt_step, read_and_featurise_s=t_feat - t_job,
+                                sampling_s=t_samp - t_feat, writer_tail_s=t_done - t_samp, files=len(new_files)))
             local = {'seq': traj[-1]['seq'], 'pLDDT': traj[-1]['pLDDT']}
         else:                                                   # more ranks than samples: join the gather with zero-row blocks
             local = {'seq': torch.zeros(0, Lab, dtype=torch.int64, device=dev), 'pLDDT': torch.zeros(0, Lab, device=dev)}
