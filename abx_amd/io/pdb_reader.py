@@ -19,12 +19,17 @@ _THREE_TO_ONE = {v: k for k, v in rc.restype_1to3.items()}
 
 
 class Residue:
-    __slots__ = ('resname', 'resseq', 'icode', 'het', 'atoms', '_occ')
+    __slots__ = ('resname', 'resseq', 'icode', 'het', 'atoms', '_occ', '_alt')
 
     def __init__(self, resname, resseq, icode, het):
         self.resname, self.resseq, self.icode, self.het = resname, resseq, icode, het
         self.atoms = OrderedDict()          # name -> xyz
         self._occ = {}                      # name -> occupancy of the selected alternate location
+        self._alt = None                    # other residue NAMES at this position (point-mutation disorder): name -> Residue
+
+
+class PdbFormatError(ValueError):
+    pass
 
 
 def read_pdb(path):
@@ -32,19 +37,22 @@ def read_pdb(path):
     chains = OrderedDict()
     index = {}
     with open(path) as f:
-        for line in f:
+        for lineno, line in enumerate(f, 1):
             rec = line[:6]
             if rec == 'ENDMDL':
                 break
             if rec not in ('ATOM  ', 'HETATM'):
                 continue
-            name = line[12:16].strip()
-            altloc = line[16]
-            resname = line[17:20].strip()
-            chain_id = line[21]
-            resseq = int(line[22:26])
-            icode = line[26]
-            xyz = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
+            try:
+                name = line[12:16].strip()
+                altloc = line[16]
+                resname = line[17:20].strip()
+                chain_id = line[21]
+                resseq = int(line[22:26])
+                icode = line[26]
+                xyz = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
+            except (ValueError, IndexError) as e:
+                raise PdbFormatError(f'{path}:{lineno}: malformed {rec.strip()} record ({e}): {line.rstrip()!r}') from None
             try:
                 occ = float(line[54:60])
             except ValueError:
@@ -56,6 +64,16 @@ def read_pdb(path):
                 res = Residue(resname, resseq, icode, het)
                 index[key] = res
                 chains.setdefault(chain_id, []).append(res)
+            elif resname != res.resname:
+                # point-mutation microheterogeneity: two residue NAMES share (het, number, insertion code).  Biopython keeps both in a
+                # DisorderedResidue and selects the one whose atoms were added last ... of the highest occupancy; here the alternative
+                # is collected on the side and _resolve_disorder() keeps the name with the higher total occupancy
+                if res._alt is None:
+                    res._alt = OrderedDict()
+                alt = res._alt.get(resname)
+                if alt is None:
+                    alt = res._alt[resname] = Residue(resname, resseq, icode, het)
+                res = alt
             if name in res.atoms:
                 # alternate location of a known atom: keep the higher occupancy; a plain duplicate keeps the first
                 if altloc != ' ' and occ > res._occ[name]:
@@ -64,6 +82,12 @@ def read_pdb(path):
                 continue
             res.atoms[name] = xyz
             res._occ[name] = occ
+    for cid, residues in chains.items():
+        for i, r in enumerate(residues):
+            if r._alt:
+                best = max([r] + list(r._alt.values()), key=lambda x: sum(x._occ.values()) / max(len(x._occ), 1))
+                best._alt = None
+                residues[i] = best
     return chains
 
 

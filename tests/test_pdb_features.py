@@ -153,3 +153,20 @@ def test_model_features_json():
     json.dump([["make_to_device", {"fields": ["seq"], "device": "%(device)s"}], ["make_gt_frames", {}],
                ["make_diffuser_features", {"generate_area": "H3", "optimize_steps": [4, 8]}]], open(path, 'w'))
     assert design.read_model_features(path) == ('H3', [4, 8])
+
+
+def test_pdb_reader_error_context_and_resname_disorder(tmp_path):
+    """malformed records name the file and line; two residue names at one position (point-mutation disorder) keep the
+    one with the higher occupancy instead of merging their atoms."""
+    from abx_amd.io.pdb_reader import read_pdb, chain_feature, PdbFormatError
+    fmt = lambda i, name, resn, alt, x, occ: f"ATOM  {i:5d}  {name:<3s}{alt}{resn} A   5    {x:8.3f}{0.0:8.3f}{0.0:8.3f}{occ:6.2f}{10.0:6.2f}           {name[0]:>2s}  \n"
+    p = tmp_path / 'dis.pdb'
+    p.write_text(fmt(1, 'N', 'SER', 'A', 1.0, 0.3) + fmt(2, 'CA', 'SER', 'A', 2.0, 0.3) + fmt(3, 'OG', 'SER', 'A', 3.0, 0.3) +
+                 fmt(4, 'N', 'ALA', 'B', 1.1, 0.7) + fmt(5, 'CA', 'ALA', 'B', 2.1, 0.7) + fmt(6, 'CB', 'ALA', 'B', 3.1, 0.7))
+    ch = read_pdb(str(p))
+    f = chain_feature(ch['A'])
+    assert f['str_seq'] == 'A' and abs(float(f['coords'][0, 1, 0]) - 2.1) < 1e-6 and int(f['coord_mask'].sum()) == 3
+    bad = tmp_path / 'bad.pdb'
+    bad.write_text(fmt(1, 'N', 'SER', ' ', 1.0, 1.0) + 'ATOM      2  CA  SER A   x       1.000\n')
+    with pytest.raises(PdbFormatError, match=r'bad\.pdb:2'):
+        read_pdb(str(bad))
