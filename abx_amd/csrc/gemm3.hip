@@ -707,7 +707,13 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     const bool wide = g.glu ? false : force ? force == 2 : (g.A_split ? pad192 <= pad128 : (pad192 <= pad128 && g.N % 128 != 0));
     // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
     // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
-    if (wide) *rc = launch3<128, 192, 32, 192, 3>(g, st);
+    // Small problems (the per-residue GEMMs of the IPA loop / sequence track at a dozen samples per GPU: 4 224 rows x 256 columns = 66
+    // tiles of 128 x 128 on 256 CUs): 64 x 128 tiles, 2 x 2 waves, twice the workgroups.  Every output element still accumulates its k
+    // in the same order (same MFMA, same term order, same row statistics), so the tile choice does not change a single bit and
+    // results stay independent of how many samples share a launch.
+    const long long ntn128 = ((long long)g.N + 127) / 128;
+    if (!wide && !g.glu && !force && mt128 * ntn128 * g.batch < 384 && g.M > 64) *rc = launch3<64, 128, 32, 64, 4>(g, st);
+    else if (wide) *rc = launch3<128, 192, 32, 192, 3>(g, st);
     else *rc = launch3<128, 128, 32, 128, 4>(g, st);
     return 0;
 }

@@ -49,6 +49,8 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
         pad128, pad192 = ((N + 127) // 128) * 128, ((N + 191) // 192) * 192
         wide = pad192 <= pad128 if a_split else (wide192 and N % 128 != 0)
         cfg = (128, 192, 32, 192, 3) if wide else (128, 128, 32, 128, 4)
+        if not wide and blocks128 < 384 and M > 64:
+            cfg = (64, 128, 32, 64, 4)
         return f'gemm3_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, {amode}, {b(transposed)}, {cfg[4]}>'
     if N <= 32:
         cfg = (128, 32, 32, 32, 3)
