@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libabx_hip.so')
+# ABX_HIP_LIB: an alternative build of the same C ABI (kernel experiments under tools/probes/); the default is the in-tree library
+LIB_PATH = os.environ.get('ABX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libabx_hip.so')
 
 c_f = C.c_void_p          # device pointers travel as integers
 LL = C.c_longlong
@@ -44,6 +45,7 @@ class AbxGemm(C.Structure):
         ('mlp', I), ('N2', I),
         ('out_ln_w', c_f), ('out_ln_b', c_f), ('out_ln_eps', F),
         ('exact', I),
+        ('b_f16', I), ('b_exp', I), ('b2_exp', I),
         ('tune', I),
         ('clock_probe', c_f),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
@@ -116,6 +118,7 @@ _PROTOS = {
     'abx_init': (I, [I]),
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
     'abx_split_weights': (I, [c_f, LL, LL, I, I, C.c_void_p, _S]),
+    'abx_split_weights_f16': (I, [c_f, LL, LL, I, I, I, C.c_void_p, _S]),
     'abx_gemm3_occupancy': (I, [I]),
     'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),
     'abx_layernorm': (I, [c_f, LL, LL, I, c_f, c_f, F, c_f, LL, c_f, LL, _S]),

@@ -44,6 +44,27 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& p0, unsigned&
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
+// Split-f16 weight GEMMs (AbxGemm.b_f16): an activation pair scaled by 2^ABX_F16_A_EXP -> two packed f16 pairs with
+// x' = p0 + p1 * 2^-11 (+ <= 2^-23 |x'|: 23 significant bits): round-to-nearest pieces (v_cvt_pk_f16_f32), exact subtraction, the remainder scaled by
+// 2^11 so that it never becomes a float16 subnormal before |x'| < 2^-22.  |x'| >= 65520 gives p0 = inf, p1 = -inf: NaN downstream.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define ABX_F16_A_EXP (-4)
+__device__ __forceinline__ void split2h(float a, float b, unsigned& p0, unsigned& p1) {
+    f32x2 x = {a, b};
+    x *= (f32x2){0.0625f, 0.0625f};
+    const f16x2 h0 = __builtin_convertvector(x, f16x2);
+    const f32x2 r = (x - __builtin_convertvector(h0, f32x2)) * (f32x2){2048.0f, 2048.0f};
+    p0 = __builtin_bit_cast(unsigned, h0);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+// one product term of the split GEMMs on 8-element fragments held as raw 16 bytes
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_split(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -73,6 +73,12 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
     }
 }
 
+// Product terms of one fp32 product, smallest first.  bf16 (both operands three pieces x = p0 + p1 + p2): the six terms with
+// piece indices summing to <= 2.  f16 (activation a0 + a1 2^-11, weight planes p0, p1, p2 = p0 2^-11): a1 p2 + a0 p1 + a0 p0.
+template <bool F16> struct SplitTerms;
+template <> struct SplitTerms<false> { static constexpr int N = 6; static constexpr int A[6] = {0, 1, 2, 0, 1, 0}; static constexpr int B[6] = {2, 1, 0, 1, 0, 0}; };
+template <> struct SplitTerms<true> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {2, 1, 0}; };
+
 // Main loop of one output tile: acc += A' B for the operands of `g`; for the inline LayerNorm also the per-row partial sums
 // (ls, lq over this lane's k half, shifted by lshift).  Ends with all DMA drained and a block barrier (the LDS is free again).
 // SWAP: the MFMA operands trade places, acc[i][j] holds the TRANSPOSED 32 x 32 tile (rows = the tile's B rows / output columns, lane =
@@ -84,6 +90,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                                                float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32]) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
+    constexpr bool F16 = AMODE != 2;                                            // fp32 A x weight planes: split-f16, 3 products
     constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;                  // bytes per A stage
     constexpr int NLA = (A_IMG + 4095) / 4096;                                  // DMA instructions per wave per A tile
     constexpr int A_STAGE = A_IMG;
@@ -226,12 +233,12 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         issue_a(min(t + RING - 1, nk - 1));
         const char* as = As + (t % RING) * A_STAGE;
         const char* bs = Bs + (t & 1) * B_STAGE;
-        bf16x8 a[TM][3];
+        u32x4 a[TM][F16 ? 2 : 3];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if constexpr (AMODE == 2) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(as + offA[i][0] + p * (BM * 32));
+                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const u32x4*>(as + offA[i][0] + p * (BM * 32));
             } else {
                 float x[8];
                 if constexpr (AMODE == 0) {
@@ -265,36 +272,42 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
                 }
-                unsigned q0[4], q1[4], q2[4];
+                unsigned q0[4], q1[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], q0[e], q1[e], q2[e]);
-                a[i][0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
-                a[i][1] = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
-                a[i][2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                for (int e = 0; e < 4; ++e) split2h(x[2 * e], x[2 * e + 1], q0[e], q1[e]);
+                a[i][0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                a[i][1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
             }
         }
-        // six product terms, smallest first; the B fragments are fetched per group of JG sub-tiles (register budget);
+        // product terms, smallest first (SplitTerms); the B fragments are fetched per group of JG sub-tiles (register budget);
         // consecutive MFMAs hit different accumulators
-        constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
-        constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
+        using T = SplitTerms<F16>;
         constexpr int JG = TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN;
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += JG) {
-            bf16x8 bb[JG][3];
+            u32x4 bb[JG][3];
 #pragma unroll
             for (int j = 0; j < JG; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bb[j][p] = *reinterpret_cast<const bf16x8*>(bs + offB[j0 + j] + p * (BN * 32));
+                for (int p = 0; p < 3; ++p) bb[j][p] = *reinterpret_cast<const u32x4*>(bs + offB[j0 + j] + p * (BN * 32));
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < T::N; ++term)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < JG; ++j)
-                        acc[i][j0 + j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[j][TB[term]], a[i][TA[term]], acc[i][j0 + j], 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[term]], bb[j][TB[term]], acc[i][j0 + j], 0, 0, 0);
+                        acc[i][j0 + j] = SWAP ? mfma_split<F16>(bb[j][T::B[term]], a[i][T::A[term]], acc[i][j0 + j])
+                                              : mfma_split<F16>(a[i][T::A[term]], bb[j][T::B[term]], acc[i][j0 + j]);
         }
         wait_vm_and_barrier<0>();
+    }
+    if constexpr (F16) {
+        // the planes hold w * 2^b_exp, the activations went in as x * 2^ABX_F16_A_EXP: exact power-of-two rescale
+        const float cs = __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - g.b_exp);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= cs;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -361,7 +374,7 @@ __device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, 
     g2.A = g.A2; g2.sAb = g.sA2b; g2.sAm = g.sA2m; g2.sAk = 1; g2.K = g.K2;
     g2.A_split = nullptr; g2.a_relu = 0; g2.a_pair_transpose = 0; g2.a_pair = g.pair_Lp > 0 ? 1 : 0;
     g2.B_split = g.B2_split; g2.sB3p = g.sB23p; g2.sB3n = g.sB23n; g2.sB3k = g.sB23k; g2.sB3b = 0;
-    g2.ln_csum = g.ln2_csum; g2.ln_stats = nullptr; g2.batch_inner = 0;
+    g2.ln_csum = g.ln2_csum; g2.ln_stats = nullptr; g2.batch_inner = 0; g2.b_exp = g.b2_exp;
     if (g.sAk == 1) gemm3_mainloop<BM, BN, WM, WN, 0>(g, smem, mt, nt, b, acc, ls, lq, lsh);
     else gemm3_mainloop<BM, BN, WM, WN, 1>(g, smem, mt, nt, b, acc, ls, lq, lsh);
     gemm3_mainloop<BM, BN, WM, WN, 0>(g2, smem, mt, nt, b, acc2, ls2, lq2, lsh2);
@@ -487,8 +500,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
     float ls[1], lq[1], lsh[1] = {0.f};
     float rstd = 0.f, dmean = 0.f;
     const int nchunk = (g.N + BN - 1) / BN;
-    constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
-    constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
+    using T = SplitTerms<true>;
     for (int c = 0; c < nchunk; ++c) {
         issue_w2(c * (BN / 16), 0);                                          // first W2 k-tile of the chunk: lands under GEMM 1
         f32x16 acc1[1][BN / 32];
@@ -510,7 +522,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
             // each followed by its k-tile of GEMM 2
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 hf[3];
+                u32x4 hf[2];
                 {
                     float v[8];
 #pragma unroll
@@ -532,12 +544,11 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
                             v[4 * q + e] = (hc + e < g.N) ? x : 0.f;
                         }
                     }
-                    unsigned q0[4], q1[4], q2[4];
+                    unsigned q0[4], q1[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split2(v[2 * e], v[2 * e + 1], q0[e], q1[e], q2[e]);
-                    hf[0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
-                    hf[1] = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
-                    hf[2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                    for (int e = 0; e < 4; ++e) split2h(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+                    hf[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                    hf[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
                 }
                 const int kl = 2 * j + s2;                                   // k-tile of the chunk, stage kl & 1
                 const int knext = c * (BN / 16) + kl + 1;
@@ -546,21 +557,26 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
                 if (rows_live && (c * (BN / 16) + kl) * 16 < g.N) {
 #pragma unroll
                     for (int t0 = 0; t0 < TN2; t0 += TG2) {
-                        bf16x8 wb[TG2][3];
+                        u32x4 wb[TG2][3];
 #pragma unroll
                         for (int t = 0; t < TG2; ++t)
 #pragma unroll
-                            for (int p = 0; p < 3; ++p) wb[t][p] = *reinterpret_cast<const bf16x8*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
+                            for (int p = 0; p < 3; ++p) wb[t][p] = *reinterpret_cast<const u32x4*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
 #pragma unroll
-                        for (int term = 0; term < 6; ++term)
+                        for (int term = 0; term < T::N; ++term)
 #pragma unroll
                             for (int t = 0; t < TG2; ++t)
-                                acc2[0][t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[TA[term]], wb[t][TB[term]], acc2[0][t0 + t], 0, 0, 0);
+                                acc2[0][t0 + t] = mfma_split<true>(hf[T::A[term]], wb[t][T::B[term]], acc2[0][t0 + t]);
                     }
                 }
                 wait_vm_and_barrier<0>();
             }
         }
+    }
+    {
+        const float cs2 = __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - g.b2_exp);
+#pragma unroll
+        for (int t = 0; t < TN2; ++t) acc2[0][t] *= cs2;
     }
     // ---- epilogue: + bias2 (+ resid), plain store.  A view of the descriptor whose "GEMM" is the second layer.
     AbxGemm g2 = g;
@@ -614,6 +630,22 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     out[o + 2LL * N * 16] = (unsigned short)(p2 & 0xffffu);
 }
 
+// fp32 weights -> k-tiled float16 planes of w' = w * scale: p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 / 2048) (AbxGemm.b_f16)
+__global__ __launch_bounds__(256) void split_weights_f16_kernel(const float* __restrict__ w, long long s_n, long long s_k, int N, int K,
+                                                                int Kp, float scale, unsigned short* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * Kp) return;
+    const int n = (int)(idx / Kp), k = (int)(idx % Kp);
+    const float x = k < K ? w[n * s_n + k * s_k] * scale : 0.f;
+    const _Float16 h0 = (_Float16)x;
+    const _Float16 h1 = (_Float16)(x - (float)h0);
+    const _Float16 h2 = (_Float16)((float)h0 * (1.0f / 2048.0f));
+    const long long o = ((long long)(k >> 4) * 3 * N + n) * 16 + (k & 15);
+    out[o] = __builtin_bit_cast(unsigned short, h0);
+    out[o + (long long)N * 16] = __builtin_bit_cast(unsigned short, h1);
+    out[o + 2LL * N * 16] = __builtin_bit_cast(unsigned short, h2);
+}
+
 }  // namespace
 
 // Called by abx_gemm (gemm.hip) once the descriptor has been validated and the vector flags filled.
@@ -625,6 +657,12 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     const bool narrow = g.B_split && g.N <= 32 && !g.A_split && g.sAk == 1 && !g.glu && !g.C_split && !g.A2 && !g.out_ln_w &&
                         g.a_pair_transpose <= 0 && g.pair_Lp == 0;
     if (!g.B_split || g.K % 16 != 0 || (g.N <= 64 && !narrow)) return 1;
+    if ((g.A_split != nullptr) == (g.b_f16 != 0) || g.b_exp < -100 || g.b_exp > 100 || g.b2_exp < -100 || g.b2_exp > 100) {
+        abx_set_error("abx_gemm: B_split must be float16 weight planes (abx_split_weights_f16, b_f16 = 1, |b_exp| <= 100) with an fp32 A "
+                      "and bf16 planes (b_f16 = 0) with A_split");
+        *rc = ABX_ERR_ARG;
+        return 0;
+    }
     const long long mt128 = ((long long)g.M + 127) / 128;
     // exact == 2: the caller fixed the arithmetic class of this op (results must not depend on how many samples share a launch)
     if (g.exact != 2 && mt128 * (((long long)g.N + 127) / 128) * g.batch < ABX_SPLIT_MIN_TILES) return 1;
@@ -735,4 +773,14 @@ extern "C" int abx_split_weights(const float* w, long long s_n, long long s_k, i
     const long long total = (long long)N * Kp;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, s_n, s_k, N, K, Kp, out);
     return abx_check_launch("abx_split_weights");
+}
+
+extern "C" int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out,
+                                     hipStream_t st) {
+    ABX_REQUIRE(w && out && N > 0 && K > 0 && scale_exp >= -100 && scale_exp <= 100, "abx_split_weights_f16: bad args");
+    const int Kp = (K + 15) / 16 * 16;
+    const long long total = (long long)N * Kp;
+    hipLaunchKernelGGL(split_weights_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, s_n, s_k, N, K, Kp,
+                       ldexpf(1.0f, scale_exp), out);
+    return abx_check_launch("abx_split_weights_f16");
 }

@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (abx_amd/_lib.py).  torch is used for device memory and the current
 stream only; every function launches HIP kernels from libabx_hip.so and raises if the library is unavailable."""
 import ctypes as C
+import math
 
 import torch
 
@@ -107,15 +108,55 @@ def permute_k16(Wt):
     return Wt.reshape(K // 16, 16, N)[:, idx, :].reshape(K, N).contiguous()
 
 
-def split_weights(Wt):
-    """Wt (K, N) packed weight (n-contiguous) -> int16 tensor [Kp/16][3][N][16] of k-tiled bf16 planes with
-    W = p0 + p1 + p2 exactly (operand image of the split-bf16 GEMM kernels); Kp = K rounded up to 16."""
+def split_planes_bf16(Wt):
+    """Wt (K, N) fp32 (n-contiguous) -> int16 tensor [Kp/16][3][N][16] of k-tiled bf16 planes with W = p0 + p1 + p2 exactly: the
+    operand image of the plane x plane contraction (both operands activations; in the network these planes are written by the
+    epilogue of the projection GEMMs, this entry point serves tests and tools); Kp = K rounded up to 16."""
     K, N = Wt.shape
     _f32(Wt)
     Kp = (K + 15) // 16 * 16
     out = torch.empty(Kp // 16, 3, N, 16, device=Wt.device, dtype=torch.int16)
     check(_lib.load().abx_split_weights(_p(Wt), Wt.stride(1), Wt.stride(0), N, K, _p(out), _stream()), 'abx_split_weights')
     return out
+
+
+class WeightPlanes(torch.Tensor):
+    """float16 tensor [Kp/16][3][N][16] of split weight planes + the power-of-two exponent they were scaled with (`w_exp`)."""
+    w_exp = 0
+    __torch_function__ = torch._C._disabled_torch_function_impl     # a plain data carrier: no dispatch overhead on .stride() / .shape
+
+
+def split_weights(Wt):
+    """Wt (K, N) packed weight (n-contiguous) -> WeightPlanes [Kp/16][3][N][16] float16: the k-tiled operand image of the split-f16
+    weight GEMMs (AbxGemm.b_f16, include/abx_hip.h): with w' = w * 2^w_exp, max|w'| in [2^13, 2^14):
+    p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 * 2^-11);  w' = p0 + p1 up to 2^-23 |w'| (+ 2^-25 absolute).  One host sync (the
+    maximum) per call: weights are packed once, outside any graph capture.  Kp = K rounded up to 16."""
+    K, N = Wt.shape
+    _f32(Wt)
+    Kp = (K + 15) // 16 * 16
+    amax = float(Wt.abs().max())
+    if not math.isfinite(amax):
+        raise ValueError('split_weights: non-finite weight')
+    w_exp = 14 - math.frexp(amax)[1] if amax > 0 else 0
+    w_exp = max(-100, min(100, w_exp))
+    out = torch.empty(Kp // 16, 3, N, 16, device=Wt.device, dtype=torch.float16)
+    check(_lib.load().abx_split_weights_f16(_p(Wt), Wt.stride(1), Wt.stride(0), N, K, w_exp, _p(out), _stream()), 'abx_split_weights_f16')
+    out = out.as_subclass(WeightPlanes)
+    out.w_exp = w_exp
+    return out
+
+
+def weights_to_float(w3):
+    """WeightPlanes -> fp32 (Kp, N) value the kernels multiply with: (p0 + p1) * 2^-w_exp."""
+    v = (w3[:, 0].float() + w3[:, 1].float()) * 2.0 ** (-w3.w_exp)
+    return v.permute(0, 2, 1).reshape(-1, w3.shape[2])
+
+
+def _weight_planes(w3, N, K=None, what='B3'):
+    assert isinstance(w3, WeightPlanes) and w3.dtype == torch.float16 and w3.is_contiguous() and w3.shape[1:] == (3, N, 16), \
+        f'{what}: WeightPlanes (ops.split_weights) of N = {N} expected'
+    assert K is None or w3.shape[0] * 16 >= K
+    return w3
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
@@ -180,9 +221,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     No = N // 2 if glu else N
     if mlp is not None:
         B32m, bias2m = mlp
-        assert B32m.dtype == torch.int16 and B32m.is_contiguous() and B32m.dim() == 4 and B32m.shape[0] * 16 == N and B32m.shape[1] == 3 and B32m.shape[3] == 16
         No = B32m.shape[2]
-        g.mlp, g.N2 = 1, No
+        _weight_planes(B32m, No, what='mlp B3_2')
+        assert B32m.shape[0] * 16 == N
+        g.mlp, g.N2, g.b2_exp = 1, No, B32m.w_exp
         g.B2_split, g.sB23k, g.sB23p, g.sB23n = _p(B32m), B32m.stride(0), B32m.stride(1), B32m.stride(2)
         g.bias2 = _p(bias2m)
         assert act == 1 and ln is not None and ln[0] is None
@@ -222,8 +264,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     g.a_relu = 1 if a_relu else 0
     g.exact = 1 if GEMM_EXACT else int(exact or 0)        # 0 by problem size, 1 exact fp32 MFMA, 2 split-bf16 whenever the shape allows
     if B3 is not None:
-        assert B3.dtype == torch.int16 and B3.is_contiguous() and B3.shape[1:] == (3, N, 16) and B3.shape[0] * 16 >= K
+        _weight_planes(B3, N, K)
+        assert not a_planes, 'weight planes go with an fp32 A (the plane x plane contraction takes bf16 planes on both sides)'
         g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
+        g.b_f16, g.b_exp = 1, B3.w_exp
     g.tune = GEMM_TUNE if tune is None else tune
     if dual is not None:
         A2, B32, csum2, bias2 = dual
@@ -232,7 +276,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         _f32(A2)
         assert A2.stride(2) == 1 and A2.shape[0] == nb and A2.shape[1] == (pair[0] * pair[0] if pair is not None else M)
         K2 = A2.shape[2]
-        assert B32.dtype == torch.int16 and B32.is_contiguous() and B32.shape[1:] == (3, N, 16) and B32.shape[0] * 16 == K2 and csum2.numel() == N
+        _weight_planes(B32, N, what='dual B3_2')
+        assert B32.shape[0] * 16 == K2 and csum2.numel() == N
+        g.b2_exp = B32.w_exp
         g.A2, g.sA2b, g.sA2m, g.K2 = _p(A2), (A2.stride(0) if nb > 1 else 0), A2.stride(1), K2
         g.B2_split, g.sB23k, g.sB23p, g.sB23n = _p(B32), B32.stride(0), B32.stride(1), B32.stride(2)
         g.ln2_csum, g.bias2 = _p(_f32(csum2)), _p(bias2)

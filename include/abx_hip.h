@@ -112,6 +112,17 @@ typedef struct AbxGemm {
                                                       2: the split-bf16 kernels whatever the problem size (falls back to the exact
                                                       kernel only on shape / alignment grounds): callers that need results
                                                       independent of the batch size fix the arithmetic per op with 1 or 2 */
+    /* Split-f16 WEIGHT operands (round 3; csrc/gemm3.hip): when A is an fp32 operand (A_split NULL), B_split / B2_split hold the
+     * weights as three k-tiled FLOAT16 planes written by abx_split_weights_f16: with w' = w * 2^b_exp (|w'| < 2^14),
+     * p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 * 2^-11).  The kernels scale an activation by 2^-4, split it into
+     * a0 = f16(x'), a1 = f16((x' - a0) * 2^11) and accumulate a1 p2 + a0 p1 + a0 p0 in fp32 (3 MFMA products per fp32 product,
+     * every term exact; a piece pair carries 23 significant bits
+     * (|x' - a0 - a1 2^-11| <= 2^-23 |x'| worst case, 2^-25 on average) and the dropped term is <= 2^-22 |x w|, mean zero: measured as
+     * accurate as the exact fp32 MFMA kernel, tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy_vs_exact); the accumulators are multiplied by 2^(4 - b_exp) before the epilogue.
+     * Activation range: |x| < 2^20 (beyond: inf - inf = NaN in the output, never a silently wrong number); full relative
+     * precision down to |x| = 2^-10, absolute error < 2^-32 below.  b_f16 must be 1 with an fp32 A and 0 with A_split (the
+     * plane x plane contraction keeps three bf16 planes per operand: both sides are activations of unknown range). */
+    int b_f16, b_exp, b2_exp;
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
     unsigned long long* clock_probe;               /* diagnostics, optional DEVICE [2]: every workgroup of the split-bf16 kernels adds
                                                       its elapsed shader-clock ticks (s_memtime) to [0] and its elapsed constant
@@ -124,6 +135,9 @@ int abx_gemm(const AbxGemm* desc, hipStream_t stream);
 /* fp32 weights W[n][k] (element strides s_n, s_k) -> out[Kp/16][3][N][16] bf16 planes with w = p0 + p1 + p2 exactly,
  * Kp = (K+15)/16*16 (zero padded) */
 int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t stream);
+/* fp32 weights W[n][k] -> out[Kp/16][3][N][16] float16 planes of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
+ * scale_exp = 14 - e with max|w| = m * 2^e, 0.5 <= m < 1 (so that max|w| * 2^scale_exp is in [2^13, 2^14)) */
+int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out, hipStream_t stream);
 /* diagnostics: resident workgroups per CU of the main split-bf16 GEMM instantiations (0: 128x192, 1: 128x128,
  * 2: 128x128 transposed store, 3: 128x192 plane operands); negative on error */
 int abx_gemm3_occupancy(int which);

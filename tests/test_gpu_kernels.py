@@ -130,11 +130,77 @@ def _planes_to_f64(pl):
     return f.movedim(-3, -2).reshape(*f.shape[:-3], f.shape[-2], -1)
 
 
+def test_gemm_split_f16_weight_image(ops):
+    """abx_split_weights_f16 (the operand image of the split-f16 weight GEMMs): with w' = w 2^w_exp, max|w'| in [2^13, 2^14):
+    p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 2^-11), bit for bit the host's round-to-nearest conversions; p0 + p1 = w' to
+    2^-23 |w'| + 2^-25 (two 11-bit pieces and a sign: 23 significant bits, worst case); k-tiled, zero padded rows."""
+    for K, N, scale in ((192, 768, 1.0), (52, 70, 1e-3), (128, 192, 300.0)):
+        Wt = (scale * torch.randn(K, N, generator=g(200)) * torch.logspace(-6, 0, N)[None]).to(DEV)
+        w3 = ops.split_weights(Wt)
+        Kp = (K + 15) // 16 * 16
+        assert w3.shape == (Kp // 16, 3, N, 16) and w3.dtype == torch.float16
+        wp = torch.zeros(N, Kp); wp[:, :K] = Wt.cpu().t() * 2.0 ** w3.w_exp
+        assert 2.0 ** 13 <= float(wp.abs().max()) < 2.0 ** 14
+        p0 = wp.half(); p1 = (wp - p0.float()).half(); p2 = (p0.float() / 2048).half()
+        host = torch.stack([p0, p1, p2], 0).reshape(3, N, Kp // 16, 16).permute(2, 0, 1, 3)
+        assert torch.equal(torch.Tensor(w3.cpu()).view(torch.int16), host.contiguous().view(torch.int16))
+        back = p0.double() + p1.double()
+        assert ((back - wp.double()).abs() <= 2.0 ** -23 * wp.double().abs() + 2.0 ** -25).all()
+        assert torch.equal(ops.weights_to_float(w3).cpu(), ((p0.float() + p1.float()) * 2.0 ** -w3.w_exp).t())
+
+
+def test_gemm_split_f16_activation_range(ops):
+    """Range contract of the split-f16 weight GEMMs (include/abx_hip.h, AbxGemm.b_f16): rows of magnitude 1e-6 ... 1e5 - with and
+    without the folded LayerNorm - are as accurate as the exact fp32 MFMA kernel (elements below 2^-9: to 2^-32 absolute, which the LayerNorm's eps = 1e-5 amplifies to
+    at most 7e-8); an activation beyond 2^20 gives NaN in its output
+    row (never a silently wrong number) and leaves the other rows alone."""
+    M, N, K = 40000, 192, 128
+    A = torch.randn(M, K, generator=g(211)) + 0.3
+    mag = 10.0 ** (torch.rand(M, generator=g(212)) * 11.0 - 6.0)                     # 1e-6 ... 1e5 per row (|x| < 6e5)
+    A = A * mag[:, None]
+    W = torch.randn(N, K, generator=g(213)) / K ** 0.5
+    b = torch.randn(N, generator=g(214))
+    Ad, Wt, bd = A.to(DEV), W.t().contiguous().to(DEV), b.to(DEV)
+    w3 = ops.split_weights(Wt)
+    # plain Linear: error relative to the row's own scale
+    ref = A.double() @ W.double().t()
+    o_x = torch.empty(M, N, device=DEV); o_s = torch.empty(M, N, device=DEV)
+    ops.gemm(Ad, Wt, o_x, exact=True)
+    ops.gemm(Ad, Wt, o_s, B3=w3, exact=2)
+    den = (A.double().abs() @ W.double().abs().t())
+    e_x = ((o_x.cpu().double() - ref).abs() / den); e_s = ((o_s.cpu().double() - ref).abs() / den)
+    full = mag >= 1e-2                                      # |x| >= 2^-9: full relative precision; below: 2^-32 absolute per element
+    assert float(e_s[full].max()) <= 1.5 * float(e_x[full].max()) and float(e_s[full].mean()) <= 1.2 * float(e_x[full].mean()), \
+        (e_x[full].max(), e_s[full].max(), e_x[full].mean(), e_s[full].mean())
+    floor = 2.0 ** -31 * W.double().abs().sum(1)[None]      # (2^-32 per element of the row, twice for slack)
+    assert ((o_s.cpu().double() - ref).abs() <= 1.5 * float(e_x.max()) * den + floor).all()
+    # folded LayerNorm: rows of any magnitude normalise to O(1)
+    csum = Wt.sum(0).contiguous()
+    refn = torch.nn.functional.layer_norm(A.double(), (K,)) @ W.double().t() + b.double()
+    ops.gemm(Ad, Wt, o_x, bias=bd, ln=(None, csum), exact=True)
+    ops.gemm(Ad, Wt, o_s, bias=bd, ln=(None, csum), B3=w3, exact=2)
+    big = mag > 1e-2                                                                  # (below, eps = 1e-5 of the LayerNorm matters: compare kernels only)
+    ex, es = (o_x.cpu().double() - refn).abs()[big], (o_s.cpu().double() - refn).abs()[big]
+    assert float(es.max()) <= 1.5 * float(ex.max()) + 1e-7 and float(es.mean()) <= 1.2 * float(ex.mean()) + 1e-9, (ex.max(), es.max(), ex.mean(), es.mean())
+    assert float((o_s - o_x).abs().max()) < 2e-5
+    # overflow is loud
+    A2 = Ad[:512].clone(); A2[7, 5] = 2.0 ** 20 * 1.01; A2[9, 100] = -3e7
+    o2 = torch.empty(512, N, device=DEV)
+    ops.gemm(A2, Wt, o2, B3=w3, exact=2)
+    bad = ~torch.isfinite(o2).all(1)
+    assert bad[7] and bad[9] and int(bad.sum()) == 2
+    A2[7, 5] = 2.0 ** 20 * 0.99; A2[9, 100] = -1e6
+    ops.gemm(A2, Wt, o2, B3=w3, exact=2)
+    assert torch.isfinite(o2).all()
+    ref2 = A2.cpu().double() @ W.double().t()
+    assert float((o2.cpu().double() - ref2).abs()[7].max()) < 1e-6 * 2.0 ** 20
+
+
 def test_gemm_split_bf16_weight_image(ops):
     """abx_split_weights: W = p0 + p1 + p2 EXACTLY (three round-to-nearest bf16 pieces), k-tiled, zero padded rows."""
     for K, N in ((192, 768), (52, 70), (128, 192)):
         Wt = (torch.randn(K, N, generator=g(200)) * torch.logspace(-6, 3, N)[None]).to(DEV)
-        w3 = ops.split_weights(Wt)
+        w3 = ops.split_planes_bf16(Wt)
         Kp = (K + 15) // 16 * 16
         assert w3.shape == (Kp // 16, 3, N, 16)
         back = _planes_to_f64(w3.cpu())                                                              # (N, Kp)
