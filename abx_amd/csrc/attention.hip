@@ -299,7 +299,8 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
     const int nqt = (L + 15) / 16;
     const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
     const int bias_row = (int)a.bias_sq;                        // readable floats per bias row when bias_sk == 1
-    const float qscale = a.scale * LOG2E;
+    // split-f16 scales: keys / values are staged as 16 x, queries and softmax weights enter as x / 16, so the products need no rescale
+    const float qscale = a.scale * LOG2E * 0.0625f;
     // wave-uniform: does this sample mask any key?  (12 waves x 64 lanes cover L <= 768 in one pass of the ballot loop)
     bool any_masked = false;
     if (km) {
@@ -340,14 +341,14 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
         if (it == 0 && tid < KC4) Msb[buf * KC4 + tid] = (c0 + tid < L) ? ((!km || km[c0 + tid] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
         if (kk >= KC4) return;
         unsigned a0, a1, a2, b0, b1, b2;
-        split2(kreg[0], kreg[1], a0, a1, a2);
-        split2(kreg[2], kreg[3], b0, b1, b2);
+        split2w(kreg[0], kreg[1], a0, a1, a2);
+        split2w(kreg[2], kreg[3], b0, b1, b2);
         char* kd = Kp + kk * RST + c4 * 8;
         *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
         *reinterpret_cast<u32x2*>(kd + 2 * PLN) = u32x2{a2, b2};
-        split2(vreg[0], vreg[1], a0, a1, a2);
-        split2(vreg[2], vreg[3], b0, b1, b2);
+        split2w(vreg[0], vreg[1], a0, a1, a2);
+        split2w(vreg[2], vreg[3], b0, b1, b2);
         char* vd = Vp + kk * RST + c4 * 8;
         *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             // ---- Q fragments (B operand of the swapped product), pre-scaled, split: lane holds Q[q][dbase + 8g .. +7]
             const int qrow = qt * 16 + lq;
             const bool qok = qrow < L;
-            bf16x8 qf[2][3];
+            f16x8 qf[2][2];
             {
                 const float* qp = a.q + base + (long long)(qok ? qrow : 0) * a.sl;
 #pragma unroll
@@ -400,19 +401,17 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                     const f32x4 hi = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { x[e] = lo[e] * qscale; x[4 + e] = hi[e] * qscale; }
-                    unsigned q0[4], q1[4], q2[4];
+                    unsigned q0[4], q1[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split2(x[2 * e], x[2 * e + 1], q0[e], q1[e], q2[e]);
-                    qf[hh][0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
-                    qf[hh][1] = __builtin_bit_cast(bf16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
-                    qf[hh][2] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], q2[2], q2[3]});
+                    for (int e = 0; e < 4; ++e) split2h_raw(x[2 * e], x[2 * e + 1], q0[e], q1[e]);
+                    qf[hh][0] = __builtin_bit_cast(f16x8, u32x4{q0[0], q0[1], q0[2], q0[3]});
+                    qf[hh][1] = __builtin_bit_cast(f16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
                 }
             }
             const float* brow = biasb ? biasb + (long long)(qok ? qrow : 0) * a.bias_sq + (long long)c0 * a.bias_sk : nullptr;
             float mr = m_run[sl], lr = l_run[sl];
             f32x4 oo[3] = {o[sl][0], o[sl][1], o[sl][2]};
-            constexpr int TA[6] = {0, 1, 2, 0, 1, 0};
-            constexpr int TB[6] = {2, 1, 0, 1, 0, 0};
+            using T = SplitTerms<true>;                         // A: the two-piece operand (Q, P), B: the plane operand (K, V)
 
             for (int kt = 0; kt < nkt; ++kt) {
                 const int k0 = kt * 64;
@@ -436,19 +435,19 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
                     const char* kr = Kp + (k0 + sub * 16 + lq) * RST + g * 16;
-                    bf16x8 ka[2][3];
+                    f16x8 ka[2][3];
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
-                        ka[0][p] = *reinterpret_cast<const bf16x8*>(kr + p * PLN);
+                        ka[0][p] = *reinterpret_cast<const f16x8*>(kr + p * PLN);
                         // d 32..47: lane groups 0, 1 read d 32 + 8g; groups 2, 3 re-read a valid address and are multiplied by Q = 0
-                        ka[1][p] = *reinterpret_cast<const bf16x8*>(kr + p * PLN + 64 - (g >> 1) * 32);
+                        ka[1][p] = *reinterpret_cast<const f16x8*>(kr + p * PLN + 64 - (g >> 1) * 32);
                     }
                     f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < T::N; ++term)
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh)
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[hh][TA[term]], qf[hh][TB[term]], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka[hh][T::B[term]], qf[hh][T::A[term]], c, 0, 0, 0);
                     sc[sub] = c;
                 }
                 // ---- bias, mask, online softmax (base 2) of this lane's query column
@@ -477,12 +476,13 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                 mx = quad_max(mx);
                 const float m_new = vmax(mr, mx);
                 const float alpha = __builtin_amdgcn_exp2f(mr - m_new);
+                const float m_sh = m_new + 4.0f;
                 float rs4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(sc[sub][r] - m_new);
+                        const float p = __builtin_amdgcn_exp2f(sc[sub][r] - m_sh);     // P / 16
                         sc[sub][r] = p;
                         rs4[r] += p;
                     }
@@ -499,29 +499,28 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                 // V planes: lane d receives 8 keys of its column), B = P (registers)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    bf16x8 pa[3];
-                    unsigned p0[4], p1[4], p2[4];
-                    split2(sc[2 * m][0], sc[2 * m][1], p0[0], p1[0], p2[0]);
-                    split2(sc[2 * m][2], sc[2 * m][3], p0[1], p1[1], p2[1]);
-                    split2(sc[2 * m + 1][0], sc[2 * m + 1][1], p0[2], p1[2], p2[2]);
-                    split2(sc[2 * m + 1][2], sc[2 * m + 1][3], p0[3], p1[3], p2[3]);
-                    pa[0] = __builtin_bit_cast(bf16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
-                    pa[1] = __builtin_bit_cast(bf16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
-                    pa[2] = __builtin_bit_cast(bf16x8, u32x4{p2[0], p2[1], p2[2], p2[3]});
+                    f16x8 pa[2];
+                    unsigned p0[4], p1[4];
+                    split2h_raw(sc[2 * m][0], sc[2 * m][1], p0[0], p1[0]);
+                    split2h_raw(sc[2 * m][2], sc[2 * m][3], p0[1], p1[1]);
+                    split2h_raw(sc[2 * m + 1][0], sc[2 * m + 1][1], p0[2], p1[2]);
+                    split2h_raw(sc[2 * m + 1][2], sc[2 * m + 1][3], p0[3], p1[3]);
+                    pa[0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+                    pa[1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
                     // lane i of a 16-lane group supplies row (4g + i/4) of the sub-block, 4 channels (i%4)*4.. of the 16-channel block
                     const char* vr = Vp + (k0 + m * 32 + 4 * g + (lq >> 2)) * RST + (lq & 3) * 8;
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
-                        bf16x8 vb[3];
+                        f16x8 vb[3];
 #pragma unroll
                         for (int p = 0; p < 3; ++p) {
                             const s16x4 lo = lds_tr16(vr + p * PLN + d * 32);
                             const s16x4 hi = lds_tr16(vr + p * PLN + d * 32 + 16 * RST);
-                            vb[p] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                            vb[p] = __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
                         }
 #pragma unroll
-                        for (int term = 0; term < 6; ++term)
-                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[TA[term]], pa[TB[term]], oo[d], 0, 0, 0);
+                        for (int term = 0; term < T::N; ++term)
+                            oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[T::B[term]], pa[T::A[term]], oo[d], 0, 0, 0);
                     }
                 }
             }
@@ -539,7 +538,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
         const int qt = wave + sl * (TRI_THREADS / 64);
         const int qrow = qt * 16 + lq;
         if (qt >= nqt || qrow >= L) continue;
-        const float inv = 1.0f / l_run[sl];
+        const float inv = 0.0625f / l_run[sl];                  // l_run accumulated P / 16
         const long long go = base + (long long)qrow * a.sl;
         float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
 #pragma unroll

@@ -50,14 +50,33 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& p0, unsigned&
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define ABX_F16_A_EXP (-4)
-__device__ __forceinline__ void split2h(float a, float b, unsigned& p0, unsigned& p1) {
-    f32x2 x = {a, b};
-    x *= (f32x2){0.0625f, 0.0625f};
+// (raw: the caller has applied the scale)
+__device__ __forceinline__ void split2h_raw(float a, float b, unsigned& p0, unsigned& p1) {
+    const f32x2 x = {a, b};
     const f16x2 h0 = __builtin_convertvector(x, f16x2);
     const f32x2 r = (x - __builtin_convertvector(h0, f32x2)) * (f32x2){2048.0f, 2048.0f};
     p0 = __builtin_bit_cast(unsigned, h0);
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
+__device__ __forceinline__ void split2h(float a, float b, unsigned& p0, unsigned& p1) {
+    split2h_raw(a * 0.0625f, b * 0.0625f, p0, p1);
+}
+// The partner operand of a split-f16 product when it is an ACTIVATION too (keys / values of the triangle attention): scaled by
+// 2^4, three packed f16 planes p0 = f16(x'), p1 = f16(x' - p0), p2 = p0 * 2^-11 - what abx_split_weights_f16 writes for weights,
+// with a fixed scale.  |x| < 4095 (beyond: NaN downstream); 23 significant bits from |x| = 2^-6, 2^-29 absolute below.
+__device__ __forceinline__ void split2w(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const f32x2 x = (f32x2){a, b} * (f32x2){16.0f, 16.0f};
+    const f16x2 h0 = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h0, f32x2);
+    p0 = __builtin_bit_cast(unsigned, h0);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    p2 = __builtin_bit_cast(unsigned, h0 * (f16x2){(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f});
+}
+// Product terms of one fp32 product, smallest first.  bf16 (both operands three pieces x = p0 + p1 + p2): the six terms with
+// piece indices summing to <= 2.  f16 (A: activation pieces a0 + a1 2^-11; B: planes p0, p1, p2 = p0 2^-11): a1 p2 + a0 p1 + a0 p0.
+template <bool F16> struct SplitTerms;
+template <> struct SplitTerms<false> { static constexpr int N = 6; static constexpr int A[6] = {0, 1, 2, 0, 1, 0}; static constexpr int B[6] = {2, 1, 0, 1, 0, 0}; };
+template <> struct SplitTerms<true> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {2, 1, 0}; };
 // one product term of the split GEMMs on 8-element fragments held as raw 16 bytes
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma_split(u32x4 a, u32x4 b, f32x16 c) {

@@ -73,12 +73,6 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
     }
 }
 
-// Product terms of one fp32 product, smallest first.  bf16 (both operands three pieces x = p0 + p1 + p2): the six terms with
-// piece indices summing to <= 2.  f16 (activation a0 + a1 2^-11, weight planes p0, p1, p2 = p0 2^-11): a1 p2 + a0 p1 + a0 p0.
-template <bool F16> struct SplitTerms;
-template <> struct SplitTerms<false> { static constexpr int N = 6; static constexpr int A[6] = {0, 1, 2, 0, 1, 0}; static constexpr int B[6] = {2, 1, 0, 1, 0, 0}; };
-template <> struct SplitTerms<true> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {2, 1, 0}; };
-
 // Main loop of one output tile: acc += A' B for the operands of `g`; for the inline LayerNorm also the per-row partial sums
 // (ls, lq over this lane's k half, shifted by lshift).  Ends with all DMA drained and a block barrier (the LDS is free again).
 // SWAP: the MFMA operands trade places, acc[i][j] holds the TRANSPOSED 32 x 32 tile (rows = the tile's B rows / output columns, lane =
