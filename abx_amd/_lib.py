@@ -35,6 +35,7 @@ class AbxGemm(C.Structure):
         ('B_split', C.c_void_p), ('sB3p', LL), ('sB3n', LL), ('sB3k', LL), ('sB3b', LL),
         ('A_split', C.c_void_p), ('sA3p', LL), ('sA3m', LL), ('sA3k', LL), ('sA3b', LL),
         ('batch_inner', I), ('sA3i', LL), ('sB3i', LL),
+        ('c_split_nA', I),
         ('C_split', C.c_void_p), ('sCp', LL), ('sCk', LL), ('c_split_L', I),
         ('glu', I),
         ('a_pair_transpose', I),
@@ -117,7 +118,6 @@ _PROTOS = {
     'abx_last_error_string': (C.c_char_p, []),
     'abx_init': (I, [I]),
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
-    'abx_split_weights': (I, [c_f, LL, LL, I, I, C.c_void_p, _S]),
     'abx_split_weights_f16': (I, [c_f, LL, LL, I, I, I, C.c_void_p, _S]),
     'abx_gemm3_occupancy': (I, [I]),
     'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),

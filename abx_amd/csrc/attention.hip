@@ -411,7 +411,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             const float* brow = biasb ? biasb + (long long)(qok ? qrow : 0) * a.bias_sq + (long long)c0 * a.bias_sk : nullptr;
             float mr = m_run[sl], lr = l_run[sl];
             f32x4 oo[3] = {o[sl][0], o[sl][1], o[sl][2]};
-            using T = SplitTerms<true>;                         // A: the two-piece operand (Q, P), B: the plane operand (K, V)
+            using T = SplitTerms;                         // A: the two-piece operand (Q, P), B: the plane operand (K, V)
 
             for (int kt = 0; kt < nkt; ++kt) {
                 const int k0 = kt * 64;

@@ -25,24 +25,9 @@ int abx_ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// two fp32 -> three packed bf16 pairs (lo half = first element) with a + b = p0 + p1 + p2 exactly: round-to-nearest-even
-// pieces (v_cvt_pk_bf16_f32), the subtractions are exact.  The operand image of the split-bf16 GEMM kernels (gemm3.hip).
-__device__ __forceinline__ void split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-    f32x2 x = {a, b};
-    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-    f32x2 x0 = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
-    f32x2 r = x - x0;
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
-    f32x2 x1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-    f32x2 r2 = r - x1;
-    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-}
 
 // Split-f16 weight GEMMs (AbxGemm.b_f16): an activation pair scaled by 2^ABX_F16_A_EXP -> two packed f16 pairs with
 // x' = p0 + p1 * 2^-11 (+ <= 2^-23 |x'|: 23 significant bits): round-to-nearest pieces (v_cvt_pk_f16_f32), exact subtraction, the remainder scaled by
@@ -72,16 +57,12 @@ __device__ __forceinline__ void split2w(float a, float b, unsigned& p0, unsigned
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     p2 = __builtin_bit_cast(unsigned, h0 * (f16x2){(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f});
 }
-// Product terms of one fp32 product, smallest first.  bf16 (both operands three pieces x = p0 + p1 + p2): the six terms with
-// piece indices summing to <= 2.  f16 (A: activation pieces a0 + a1 2^-11; B: planes p0, p1, p2 = p0 2^-11): a1 p2 + a0 p1 + a0 p0.
-template <bool F16> struct SplitTerms;
-template <> struct SplitTerms<false> { static constexpr int N = 6; static constexpr int A[6] = {0, 1, 2, 0, 1, 0}; static constexpr int B[6] = {2, 1, 0, 1, 0, 0}; };
-template <> struct SplitTerms<true> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {2, 1, 0}; };
+// Product terms of one fp32 product, smallest first.  A: the two-piece operand a0 + a1 2^-11; B: planes p0, p1, p2 = p0 2^-11:
+// a1 p2 + a0 p1 + a0 p0 (every f16 x f16 product is exact in fp32; dropped: a1 p1 2^-11 <= 2^-22 |a b|).
+struct SplitTerms { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {2, 1, 0}; };
 // one product term of the split GEMMs on 8-element fragments held as raw 16 bytes
-template <bool F16>
 __device__ __forceinline__ f32x16 mfma_split(u32x4 a, u32x4 b, f32x16 c) {
-    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

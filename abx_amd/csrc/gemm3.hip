@@ -57,14 +57,14 @@ __device__ __forceinline__ int plane_off(int plane, int row, int half) {
 // DMA source byte offsets (from the operand's batch base) of one wave for a [3][ROWS][16] bf16 plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
 // Surplus chunks (image not a multiple of 4 KB) and rows past the matrix re-read a valid row; their LDS bytes are never used
 // for valid outputs.
-template <int ROWS, int NL>
+template <int ROWS, int NL, int NPL = 3>
 __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row, int r0, int R, unsigned (&off)[NL]) {
     // (the k-tile stride is applied by the caller: one k-tile = 16 consecutive k of every row)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         int o = (wave * NL + i) * 1024 + lane * 16;                 // byte offset in the stage
-        if (o >= 3 * ROWS * 32) o -= 3 * ROWS * 32;                 // surplus chunk: duplicate of the image start
+        if (o >= NPL * ROWS * 32) o -= NPL * ROWS * 32;             // surplus chunk: duplicate of the image start
         const int plane = o / (ROWS * 32), rem = o % (ROWS * 32);
         const int row = rem >> 5, hp = (rem >> 4) & 1;
         const int half = hp ^ ((row >> 3) & 1);
@@ -84,8 +84,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                                                float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32]) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr bool F16 = AMODE != 2;                                            // fp32 A x weight planes: split-f16, 3 products
-    constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;                  // bytes per A stage
+    constexpr int A_IMG = AMODE == 2 ? 2 * BM * 32 : BM * 64;                  // bytes per A stage (planes: the two pieces a0, a1)
     constexpr int NLA = (A_IMG + 4095) / 4096;                                  // DMA instructions per wave per A tile
     constexpr int A_STAGE = A_IMG;
     constexpr int B_IMG = 3 * BN * 32;
@@ -145,7 +144,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     } else {
         baseA = reinterpret_cast<const char*>(g.A_split + (g.batch_inner > 0 ? (long long)(b / g.batch_inner) * g.sA3b + (long long)(b % g.batch_inner) * g.sA3i
                                                                                   : (long long)b * g.sA3b));
-        plane_sources<BM, NLA>(g.sA3p, g.sA3m, m0, g.M, offsA);
+        plane_sources<BM, NLA, 2>(g.sA3p, g.sA3m, m0, g.M, offsA);
         a_step = g.sA3k * 2;
     }
     const char* baseB = reinterpret_cast<const char*>(
@@ -227,12 +226,12 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         issue_a(min(t + RING - 1, nk - 1));
         const char* as = As + (t % RING) * A_STAGE;
         const char* bs = Bs + (t & 1) * B_STAGE;
-        u32x4 a[TM][F16 ? 2 : 3];
+        u32x4 a[TM][2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if constexpr (AMODE == 2) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const u32x4*>(as + offA[i][0] + p * (BM * 32));
+                for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const u32x4*>(as + offA[i][0] + p * (BM * 32));
             } else {
                 float x[8];
                 if constexpr (AMODE == 0) {
@@ -275,7 +274,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         }
         // product terms, smallest first (SplitTerms); the B fragments are fetched per group of JG sub-tiles (register budget);
         // consecutive MFMAs hit different accumulators
-        using T = SplitTerms<F16>;
+        using T = SplitTerms;
         constexpr int JG = TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN;
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += JG) {
@@ -290,13 +289,14 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < JG; ++j)
-                        acc[i][j0 + j] = SWAP ? mfma_split<F16>(bb[j][T::B[term]], a[i][T::A[term]], acc[i][j0 + j])
-                                              : mfma_split<F16>(a[i][T::A[term]], bb[j][T::B[term]], acc[i][j0 + j]);
+                        acc[i][j0 + j] = SWAP ? mfma_split(bb[j][T::B[term]], a[i][T::A[term]], acc[i][j0 + j])
+                                              : mfma_split(a[i][T::A[term]], bb[j][T::B[term]], acc[i][j0 + j]);
         }
         wait_vm_and_barrier<0>();
     }
-    if constexpr (F16) {
+    if constexpr (AMODE != 2) {
         // the planes hold w * 2^b_exp, the activations went in as x * 2^ABX_F16_A_EXP: exact power-of-two rescale
+        // (plane x plane: the images were written as x 2^-4 and y 2^4, nothing to undo)
         const float cs = __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - g.b_exp);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -381,7 +381,7 @@ __device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, 
 
 template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
-    constexpr int A_IMG = AMODE == 2 ? 3 * BM * 32 : BM * 64;
+    constexpr int A_IMG = AMODE == 2 ? 2 * BM * 32 : BM * 64;
     constexpr int A_STAGE = A_IMG;
     constexpr int B_STAGE = 3 * BN * 32;
     constexpr int RING = 2;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
     float ls[1], lq[1], lsh[1] = {0.f};
     float rstd = 0.f, dmean = 0.f;
     const int nchunk = (g.N + BN - 1) / BN;
-    using T = SplitTerms<true>;
+    using T = SplitTerms;
     for (int c = 0; c < nchunk; ++c) {
         issue_w2(c * (BN / 16), 0);                                          // first W2 k-tile of the chunk: lands under GEMM 1
         f32x16 acc1[1][BN / 32];
@@ -560,7 +560,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
                         for (int term = 0; term < T::N; ++term)
 #pragma unroll
                             for (int t = 0; t < TG2; ++t)
-                                acc2[0][t0 + t] = mfma_split<true>(hf[T::A[term]], wb[t][T::B[term]], acc2[0][t0 + t]);
+                                acc2[0][t0 + t] = mfma_split(hf[T::A[term]], wb[t][T::B[term]], acc2[0][t0 + t]);
                     }
                 }
                 wait_vm_and_barrier<0>();
@@ -607,21 +607,6 @@ int launch3(const AbxGemm& g, hipStream_t st) {
     else if (amode == 1) hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, 1, false, MINW>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM, WN, 2, false, MINW>), grid, block, 0, st, g);
     return abx_check_launch("abx_gemm");
-}
-
-// fp32 weights W[n][k] (element strides s_n, s_k) -> k-tiled bf16 planes [Kp/16][3][N][16], zero padded to Kp
-__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, long long s_n, long long s_k, int N, int K,
-                                                            int Kp, unsigned short* __restrict__ out) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)N * Kp) return;
-    const int n = (int)(idx / Kp), k = (int)(idx % Kp);
-    const float x = k < K ? w[n * s_n + k * s_k] : 0.f;
-    unsigned p0, p1, p2;
-    split2(x, 0.f, p0, p1, p2);
-    const long long o = ((long long)(k >> 4) * 3 * N + n) * 16 + (k & 15);
-    out[o] = (unsigned short)(p0 & 0xffffu);
-    out[o + (long long)N * 16] = (unsigned short)(p1 & 0xffffu);
-    out[o + 2LL * N * 16] = (unsigned short)(p2 & 0xffffu);
 }
 
 // fp32 weights -> k-tiled float16 planes of w' = w * scale: p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 / 2048) (AbxGemm.b_f16)
@@ -759,14 +744,6 @@ extern "C" int abx_gemm3_occupancy(int which) {
     else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 128, 32, 128, 0, true, 4>), 256, 0);
     else if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&gemm3_kernel<128, 192, 32, 192, 2, false, 3>), 256, 0);
     return e == hipSuccess ? n : -(int)e - 1000;
-}
-
-extern "C" int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t st) {
-    ABX_REQUIRE(w && out && N > 0 && K > 0, "abx_split_weights: bad args");
-    const int Kp = (K + 15) / 16 * 16;
-    const long long total = (long long)N * Kp;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, s_n, s_k, N, K, Kp, out);
-    return abx_check_launch("abx_split_weights");
 }
 
 extern "C" int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out,

@@ -64,21 +64,29 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             for (int c = 0; c < 4; ++c) v[c] += rv[c];
         }
         if (g.C_split) {
-            // output as three bf16 planes (v = p0 + p1 + p2 exactly): the pre-split operand image of the next contraction
-            unsigned a0, a1, a2, b0, b1, b2;
-            split2(v[0], v[1], a0, a1, a2);
-            split2(v[2], v[3], b0, b1, b2);
+            // output as the pre-split f16 operand image of the next contraction: channels below c_split_nA are its A side (two
+            // pieces of v 2^-4: a0, a1 = (v' - a0) 2^11; plane 2 is not written), the others its B side (three planes of v 2^4:
+            // p0, p1 = v' - p0, p2 = p0 2^-11) - common.h split2h / split2w
+            unsigned a0, a1, a2 = 0, b0, b1, b2 = 0;
+            const bool a_side = n_idx < g.c_split_nA;
+            if (a_side) {
+                split2h(v[0], v[1], a0, a1);
+                split2h(v[2], v[3], b0, b1);
+            } else {
+                split2w(v[0], v[1], a0, a1, a2);
+                split2w(v[2], v[3], b0, b1, b2);
+            }
             // m = i * L + k: the planes are the k-tiled operand image [k/16][plane][i][16] of the following contraction
             const int ii = m_idx / g.c_split_L, kk = m_idx - ii * g.c_split_L;
             unsigned short* cs = g.C_split + (long long)b * g.sCb + (long long)n_idx * g.sCm + (kk >> 4) * g.sCk + ii * 16 + (kk & 15);
             if (c_vec && cnt == 4) {
                 *reinterpret_cast<u32x2*>(cs) = u32x2{a0, b0};
                 *reinterpret_cast<u32x2*>(cs + g.sCp) = u32x2{a1, b1};
-                *reinterpret_cast<u32x2*>(cs + 2 * g.sCp) = u32x2{a2, b2};
+                if (!a_side) *reinterpret_cast<u32x2*>(cs + 2 * g.sCp) = u32x2{a2, b2};
             } else {
                 const unsigned pa[3] = {a0, a1, a2}, pb[3] = {b0, b1, b2};
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < (a_side ? 2 : 3); ++p) {
                     unsigned short* o = cs + p * g.sCp;
                     if (cnt > 0) o[0] = (unsigned short)(pa[p] & 0xffffu);
                     if (cnt > 1) o[1] = (unsigned short)(pa[p] >> 16);

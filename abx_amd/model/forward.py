@@ -96,7 +96,7 @@ class Packed:
 
     @staticmethod
     def _split(wt):
-        # bf16x3 operand image for the split-bf16 GEMM kernels (only problems with N > 64 ever take that path)
+        # float16 weight planes for the split-f16 GEMM kernels (only problems with N > 64 ever take that path)
         return ops.split_weights(wt) if (wt.shape[1] > 64 and wt.is_cuda) else None
 
     def split(self, key):
@@ -112,8 +112,8 @@ class Packed:
         return self._split_cache[ck], self.b.get(key)
 
     def split_narrow(self, wt, key):
-        """bf16x3 image of a skinny (N <= 32) weight matrix: the pair-stack bias projections stream their 9.5 GB A operand
-        through the 128 x 32 tile of the split-bf16 GEMM (DMA pipeline) instead of the exact kernel's register-staged loads."""
+        """float16 weight planes of a skinny (N <= 32) weight matrix: the pair-stack bias projections stream their 9.5 GB A operand
+        through the 128 x 32 tile of the split-f16 GEMM (DMA pipeline) instead of the exact kernel's register-staged loads."""
         ck = ('narrow', key)
         if ck not in self._split_cache:
             self._split_cache[ck] = ops.split_weights(wt) if (wt.is_cuda and wt.shape[0] % 16 == 0) else None
@@ -313,8 +313,8 @@ class Engine:
         ops.opm_features(lr, feat, Bc, L, 64)
         _lin(P, pre + 'out_proj', feat, z2, resid=z2)
         # ---------------- triangle multiplication (seqformer.py:443-504)
-        # Large problems run the contraction on the split-bf16 kernels: the projections write left/right directly as the
-        # k-tiled bf16 plane operands of the contraction (C_split), and the incoming variant reads z pair-transposed
+        # Large problems run the contraction on the split-f16 kernels: the projections write left/right directly as the
+        # k-tiled f16 operand images of the contraction (C_split), and the incoming variant reads z pair-transposed
         # (a_pair_transpose) so that both einsums become the same row-major 'ik,jk->ij' product.
         # Any residue count: inside the triangle multiplication the pair positions are indexed with a row stride Lp = L rounded
         # up to 4 (m' = i*Lp + j), so that plane rows, float4 stores and the channel-major product stay 16-byte aligned; the
@@ -343,7 +343,7 @@ class Engine:
                 else:
                     pm = ws.get('pmask_p', (Bc * LLp,))
                     ops.pair_mask(mask_f, pm, Bc, L, Lp)
-                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, zin, lrp, rowscale=pm, glu=True,
+                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, zin, lrp, rowscale=pm, glu=True, c_split_nA=128,
                         a_pair_transpose=0 if outgoing else L, pair=pad, a_pair=pad is not None)
                 tt = w384[:Bc * 128 * LLp].view(Bc, 128, LLp)      # channel-major product, padded pair rows (pads: never stored)
                 tz = tt.as_strided((Bc * 128, L, L), (LLp, Lp, 1))
@@ -409,7 +409,7 @@ class Engine:
         _lin(P, P_IPA + 'proj_seq', s0, s)
         zi = w384[:M2 * 128].view(M2, 128)
         if P.gemm_mode == 2:
-            # Linear -> LayerNorm in one kernel (the 128 output channels of a row sit in one wave tile of the split-bf16 GEMM)
+            # Linear -> LayerNorm in one kernel (the 128 output channels of a row sit in one wave tile of the split-f16 GEMM)
             _lin(P, P_IPA + 'proj_init_pair_act', z2, zi, out_ln=P.ln(P_IPA + 'init_pair_layer_norm'))
         else:
             _lin(P, P_IPA + 'proj_init_pair_act', z2, zi)

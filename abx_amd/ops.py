@@ -29,7 +29,7 @@ GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 
 
 GEMM_EXACT = False   # True: every GEMM on the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32); default: large problems on the
-                     # split-bf16 kernels of csrc/gemm3.hip (fp32-accurate)
+                     # split-f16 kernels of csrc/gemm3.hip (fp32-accurate)
 
 
 def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=False, split=False, exact=None, a_split=False, dual=False, out_ln=False):
@@ -71,13 +71,13 @@ SPLIT_MIN_L = 64
 
 def gemm_mode(L):
     """Arithmetic class of the GEMMs of a network pass, fixed by the complex (residue count L) and NOT by how many samples share a
-    launch: 2 (split-bf16 kernels) from L = 64, 1 (exact fp32 MFMA) below.  Chunking a batch, sharding it over GPUs or running
+    launch: 2 (split-f16 kernels) from L = 64, 1 (exact fp32 MFMA) below.  Chunking a batch, sharding it over GPUs or running
     one sample alone therefore gives bit-identical results."""
     return 1 if (GEMM_EXACT or L < SPLIT_MIN_L) else 2
 
 
 def gemm_split_eligible(M, N, K, batch=1):
-    """True when abx_gemm serves an (aligned) problem of this size on the split-bf16 kernels (mirror of
+    """True when abx_gemm serves an (aligned) problem of this size on the split-f16 kernels (mirror of
     abx_gemm3_dispatch in csrc/gemm3.hip)."""
     return (not GEMM_EXACT) and N > 64 and K % 16 == 0 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= 256
 
@@ -106,18 +106,6 @@ def permute_k16(Wt):
     assert K % 16 == 0
     idx = torch.tensor(_PERM16, device=Wt.device)
     return Wt.reshape(K // 16, 16, N)[:, idx, :].reshape(K, N).contiguous()
-
-
-def split_planes_bf16(Wt):
-    """Wt (K, N) fp32 (n-contiguous) -> int16 tensor [Kp/16][3][N][16] of k-tiled bf16 planes with W = p0 + p1 + p2 exactly: the
-    operand image of the plane x plane contraction (both operands activations; in the network these planes are written by the
-    epilogue of the projection GEMMs, this entry point serves tests and tools); Kp = K rounded up to 16."""
-    K, N = Wt.shape
-    _f32(Wt)
-    Kp = (K + 15) // 16 * 16
-    out = torch.empty(Kp // 16, 3, N, 16, device=Wt.device, dtype=torch.int16)
-    check(_lib.load().abx_split_weights(_p(Wt), Wt.stride(1), Wt.stride(0), N, K, _p(out), _stream()), 'abx_split_weights')
-    return out
 
 
 class WeightPlanes(torch.Tensor):
@@ -160,21 +148,22 @@ def _weight_planes(w3, N, K=None, what='B3'):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
     tensors laid out like Cout (n-contiguous, or m-contiguous when Cout is stored transposed).
-    Split-bf16 operands (int16 tensors of k-tiled bf16 planes, x = p0 + p1 + p2): B3 (K/16,3,N,16) = split_weights(B);
-    A (b,K/16,3,M,16) and B (b,K/16,3,N,16) both as planes: the TriangleMultiplication contraction; Cout (b,N,L/16,3,L,16)
-    int16 (M = L*L pair rows, m = i*L + k): the output is written as the plane operand [n][k/16][plane][i][16] of that
-    contraction (transposed store).  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i.
+    Split-f16 operands (include/abx_hip.h, "Split-f16 operands"): B3 (K/16,3,N,16) = split_weights(B), float16 weight planes;
+    A (b,K/16,3,M,16) and B (b,K/16,3,N,16) both int16 tensors of activation images: the TriangleMultiplication contraction (A: the
+    two pieces in planes 0, 1; B: three planes); Cout (b,N,L/16,3,L,16) int16 (M = L*L pair rows, m = i*L + k): the output is written
+    as the operand image [n][k/16][plane][i][16] of that contraction (transposed store), channels n < c_split_nA as its A side, the
+    others as its B side.  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i.
     glu=True: B holds (value, gate) column pairs (pack_glu_weights); Cout has N/2 channels = value * sigmoid(gate).
     pair=(L, Lp): the M rows are padded pair positions i*Lp + j (Lp % 4 == 0, any L); a_pair: A is the UNpadded (b, L*L, K) pair
     tensor; c_pair: Cout / gate / resid are UNpadded (b, L*L, N) pair tensors (pad rows dropped).  rowscale is indexed by GEMM row.
     dual=(A2, B3_2, csum2, bias2): Cout = epi(A' B) * sigmoid(LN(A2) @ W2 + bias2) (+ resid): A2 (b, rows, K2) k-contiguous fp32 (the
     UNpadded pair tensor when pair is given), B3_2 = split_weights of the gamma-scaled gate weights (K2, N), csum2 their column sums.
-    out_ln=(gamma, beta[, eps]): LayerNorm over the N output columns right after bias / alpha / act (split-bf16 path only, N <= 128).
+    out_ln=(gamma, beta[, eps]): LayerNorm over the N output columns right after bias / alpha / act (split-f16 path only, N <= 128).
     mlp=(B3_2, bias2): fused two-layer transition Cout = relu(LN(A) @ B + bias) @ W2 + bias2 (+ resid); B (K, N) is the first layer
     (N = hidden width, act must be 1, ln given), B3_2 = split_weights(permute_k16(W2t)) of the second layer W2t (N, N2), Cout / resid
     have N2 <= 192 columns and may alias A."""
@@ -234,7 +223,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         assert Cout.dim() == 6 and Cout.shape == (nb, No, (Lp + 15) // 16, 3, L, 16) and M == L * Lp, (Cout.shape, nb, M, N)
         assert Cout.stride(5) == 1 and Cout.stride(4) == 16
         g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), Lp
-        g.c_transposed = 1
+        g.c_transposed, g.c_split_nA = 1, int(c_split_nA)
     else:
         if Cout.dim() == 2:
             Cout = Cout.unsqueeze(0)
@@ -262,10 +251,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             assert stats.numel() == 2 * nb * M, (stats.shape, nb, M)
             g.ln_stats, g.sSb = _p(_f32(stats)), M
     g.a_relu = 1 if a_relu else 0
-    g.exact = 1 if GEMM_EXACT else int(exact or 0)        # 0 by problem size, 1 exact fp32 MFMA, 2 split-bf16 whenever the shape allows
+    g.exact = 1 if GEMM_EXACT else int(exact or 0)        # 0 by problem size, 1 exact fp32 MFMA, 2 split-f16 whenever the shape allows
     if B3 is not None:
         _weight_planes(B3, N, K)
-        assert not a_planes, 'weight planes go with an fp32 A (the plane x plane contraction takes bf16 planes on both sides)'
+        assert not a_planes, 'weight planes go with an fp32 A (the plane x plane contraction takes activation images on both sides)'
         g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
         g.b_f16, g.b_exp = 1, B3.w_exp
     g.tune = GEMM_TUNE if tune is None else tune
@@ -313,9 +302,12 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     return Cout
 
 
-def planes_to_float(p, dim=0):
-    """int16 bf16 planes (size 3 along `dim`) -> float32 sum (exact when the planes came from one fp32 value)."""
-    return (p.to(torch.int32) << 16).view(torch.float32).sum(dim)
+def planes_to_float(p, a_side, dim=0):
+    """int16 activation images (size 3 along `dim`) of the contraction -> the float32 value they stand for: A side (p0 + p1 2^-11) 2^4,
+    B side (p0 + p1) 2^-4."""
+    h = p.view(torch.float16).float()
+    p0, p1 = h.select(dim, 0), h.select(dim, 1)
+    return (p0 + p1 / 2048.0) * 16.0 if a_side else (p0 + p1) / 16.0
 
 
 def row_stats(x, out=None, eps=1e-5):

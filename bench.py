@@ -43,8 +43,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK_TF = 2516.6     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz)
-MFMA_SPLIT_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0   # fp32-accurate product = 6 bf16 MFMA products (csrc/gemm3.hip)
+MFMA_F16_PEAK_TF = 2516.6      # dense f16 MFMA peak (v_mfma_f32_32x32x16_f16: 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+MFMA_SPLIT_PEAK_TF = MFMA_F16_PEAK_TF / 3.0    # one fp32 product = 3 f16 MFMA products (split-f16, csrc/gemm3.hip)
 WEIGHT_SEED = 7
 
 
@@ -75,7 +75,7 @@ class OpTimer:
     def _sig(self, name, args, kw):
         if name == 'gemm':
             A, B, C = args[0], args[1], args[2]
-            if A.dtype == torch.int16:          # k-tiled bf16 planes (b, K/16, 3, rows, 16): the tri-mul contraction
+            if A.dtype == torch.int16:          # k-tiled f16 operand images (b, K/16, 3, rows, 16): the tri-mul contraction
                 if A.dim() == 6:        # two-level batch (channel slices)
                     nb, M, K, N = A.shape[0] * A.shape[1], A.shape[4], A.shape[2] * 16, B.shape[4]
                 else:
@@ -492,7 +492,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'dtype_note': 'fp32 storage and accumulation everywhere; the large pair-stack GEMMs evaluate each fp32 product from '
-                      '3-way bf16 operand splits (6 MFMA products, fp32 accumulate: as accurate as the native fp32 MFMA, '
+                      'split float16 operands (3 exact MFMA products, 23-bit operand images, fp32 accumulate: measured as accurate as the native fp32 MFMA, '
                       'tests/test_gpu_kernels.py), everything else is native fp32 / fp64',
         'config': {'workload': f'{args.workload}: L={L} (Lab {w["L_heavy"] + w["L_light"]} + antigen {w["L_antigen"]}), '
                                f'{total} samples of one complex over {world} GPU(s), 1 step = ScoreNetwork (3 passes) + get_prev '
@@ -517,10 +517,10 @@ def main():
         if name.startswith('ipa_'):
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
         elif name.startswith('gemm3_') or name.startswith('tri_attn3') or name.startswith('tri_attn4'):
-            # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs six bf16 MFMA
-            # products, so the ceiling is the dense bf16 peak / 6
+            # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs three f16 MFMA
+            # products, so the ceiling is the dense f16 peak / 3
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_SPLIT_PEAK_TF, 'unit': 'TFLOP/s',
-                    'peak_note': 'dense bf16 MFMA peak 2516.6 TF / 6 products per fp32-accurate product; '
+                    'peak_note': 'dense f16 MFMA peak 2516.6 TF / 3 products per fp32 product (split-f16); '
                                  f'{fl / dur / 1e12 / MFMA_F32_PEAK_TF:.2f} of the native fp32 MFMA peak 157.3 TF'}
         else:
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s'}

@@ -61,15 +61,30 @@ typedef struct AbxGemm {
     const float* rowscale; long long sRSb;         /* [b*sRSb + m] or NULL */
     const float* gate; long long sGb, sGm; int gate_sigmoid;   /* addressed like C: (m,n) at gate + b*sGb + m*sGm + n, or */
     const float* resid; long long sRb, sRm;        /* + n*sGm + m when c_transposed; resid likewise and may alias C */
-    /* Split-bf16 operands and output (csrc/gemm3.hip).  A value x is held as three bf16 planes with x = p0 + p1 + p2 exactly;
-     * the planes are k-TILED: element (row, k) of plane p at base + batch*sXb + (k/16)*sXk + p*sXp + row*sXr + k%16, i.e. the
-     * 16 k of one k-tile are contiguous (abx_split_weights writes [Kp/16][3][N][16]: sB3k = 3*N*16, sB3p = N*16, sB3n = 16). */
+    /* Split-f16 operands and output (csrc/gemm3.hip): every fp32 product of the large contractions is evaluated on the float16
+     * matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate) from 3 exact partial products:
+     *     x y  ~  a1 p2 + a0 p1 + a0 p0      A side (two pieces):  x' = x 2^-4,  a0 = f16(x'),  a1 = f16((x' - a0) 2^11)
+     *                                        B side (three planes): y' = y 2^e,   p0 = f16(y'),  p1 = f16(y' - p0),  p2 = f16(p0 2^-11)
+     * A piece pair carries 23 significant bits (|x' - a0 - a1 2^-11| <= 2^-23 |x'| worst case, 2^-25 on average), the dropped term
+     * a1 p1 2^-11 is <= 2^-22 |x y| with mean zero: measured as accurate as the exact fp32 MFMA kernel
+     * (tests/test_gpu_kernels.py::test_gemm_split_accuracy_vs_exact).  A-side range: |x| < 2^20, full relative precision from
+     * |x| = 2^-9, 2^-32 absolute below; an operand beyond the range becomes inf - inf = NaN in its output row, never a silently wrong
+     * number (remedy: exact = 1).  fp32 A operands are split in registers by the kernels.
+     *   Weights (B of an fp32-A GEMM): abx_split_weights_f16 planes with a per-tensor e = b_exp (max |y'| in [2^13, 2^14)): b_f16 = 1;
+     *     the accumulators are multiplied by 2^(4 - b_exp) before the epilogue.
+     *   Activations on both sides (A_split and B_split: the TriangleMultiplication contraction): images written by the C_split
+     *     epilogue of the projection GEMM, B side with the fixed e = 4 (|y| < 4095; 2^-29 absolute below 2^-6); b_f16 = 0.
+     * The planes are k-TILED: element (row, k) of plane p at base + batch*sXb + (k/16)*sXk + p*sXp + row*sXr + k%16 (16-bit units),
+     * i.e. the 16 k of one k-tile are contiguous (abx_split_weights_f16 writes [Kp/16][3][N][16]: sB3k = 3*N*16, sB3p = N*16,
+     * sB3n = 16). */
     const unsigned short* B_split; long long sB3p, sB3n, sB3k, sB3b;   /* B as planes (sB3b = 0: shared weights); used instead of B */
-    const unsigned short* A_split; long long sA3p, sA3m, sA3k, sA3b;   /* A as planes, used instead of A: the TriangleMultiplication
-                                                      contraction takes both operands this way (K % 16 == 0) */
+    const unsigned short* A_split; long long sA3p, sA3m, sA3k, sA3b;   /* A as planes (pieces a0, a1 in planes 0, 1), used instead of A:
+                                                      the TriangleMultiplication contraction takes both operands this way (K % 16 == 0) */
     int batch_inner; long long sA3i, sB3i;         /* batch_inner > 0: two-level batch of the plane operands, entry b sits at
                                                       (b / batch_inner) * sX3b + (b % batch_inner) * sX3i (left / right channels of
                                                       one sample inside a wider channel tensor) */
+    int c_split_nA;                                /* with C_split: output channels n < c_split_nA are written as the A side of the
+                                                      following contraction (two pieces), the others as its B side (three planes) */
     unsigned short* C_split; long long sCp, sCk; int c_split_L;   /* write the output as planes instead of C, laid out as the
                                                       k-tiled OPERAND of the following contraction: with m = i*L + k (L =
                                                       c_split_L, M % L == 0, transposed store only), element (m, n) of plane p goes to
@@ -77,25 +92,25 @@ typedef struct AbxGemm {
     int glu;                                       /* transposed store only: the N columns are (value, gate) pairs of 32-column blocks
                                                       [v0 | g0 | v1 | g1 | ...] of the same N/2 output channels (weights packed that
                                                       way); out = epi(value) * sigmoid(epi(gate)), C / C_split have N/2 channels.
-                                                      Needs a kernel whose wave tile holds both blocks (split-bf16 128x128 tiles) */
+                                                      Needs a kernel whose wave tile holds both blocks (split-f16 128x128 tiles) */
     int a_pair_transpose;                          /* L > 0: M == L*L rows per batch are pair positions (i,k); row i*L + k of
-                                                      the GEMM reads source row k*L + i (k-contiguous A, split-bf16 path only) */
+                                                      the GEMM reads source row k*L + i (k-contiguous A, split-f16 path only) */
     int pair_L, pair_Lp;                           /* pair_Lp > 0: the M rows of the GEMM are PADDED pair positions m = i*pair_Lp + j
                                                       (i < pair_L, j < pair_Lp, pair_Lp % 4 == 0, M == pair_L*pair_Lp): any residue
                                                       count L keeps 16-byte aligned pair rows inside the triangle multiplication
-                                                      (split-bf16 path only).  With C_split, c_split_L == pair_Lp */
+                                                      (split-f16 path only).  With C_split, c_split_L == pair_Lp */
     int a_pair;                                    /* A rows live in the UNpadded pair tensor: GEMM row (i,j) reads source row
                                                       i*pair_L + min(j, pair_L-1), or min(j, pair_L-1)*pair_L + i when
                                                       a_pair_transpose != 0 (k-contiguous fp32 A) */
     int c_pair;                                    /* C / gate / resid rows live in the UNpadded pair tensor: GEMM row (i,j) is
                                                       stored at row i*pair_L + j, rows with j >= pair_L are dropped (plain store) */
-    /* Dual GEMM (split-bf16 path, plain store): out = epi(A' B) * sigmoid(LN(A2) B2 + bias2) (+ resid) - the tail of the
+    /* Dual GEMM (split-f16 path, plain store): out = epi(A' B) * sigmoid(LN(A2) B2 + bias2) (+ resid) - the tail of the
      * TriangleMultiplication (seqformer.py:496-503: proj_out(final_norm(x)) * sigmoid(final_gate(norm(z)))) in one kernel.
      * A2: k-contiguous fp32 rows (K2 % 16 == 0), statistics inline; with pair_Lp > 0 its rows live in the UNpadded pair tensor. */
     const float* A2; long long sA2b, sA2m; int K2;
-    const unsigned short* B2_split; long long sB23p, sB23n, sB23k;   /* gate weights as k-tiled planes (abx_split_weights) */
+    const unsigned short* B2_split; long long sB23p, sB23n, sB23k;   /* gate weights as k-tiled planes (abx_split_weights_f16, b2_exp) */
     const float* ln2_csum; const float* bias2;     /* [N] column sums of the gamma-scaled gate weights, folded bias */
-    /* Fused two-layer transition (split-bf16 path, plain store; seqformer.py:358-376 LayerNorm -> Linear -> ReLU -> Linear + residual):
+    /* Fused two-layer transition (split-f16 path, plain store; seqformer.py:358-376 LayerNorm -> Linear -> ReLU -> Linear + residual):
      * mlp != 0:  C = relu(LN(A) B + bias) B2 + bias2 (+ resid), the N-wide hidden activations never leave the CU.  A k-contiguous
      * fp32 with inline LayerNorm (ln_csum, ln_stats NULL), act = 1; N % 16 == 0 = hidden width; C / resid have N2 <= 192 columns;
      * B2_split = planes of the second layer's weights [N/16][3][N2][16] (strides sB23k / sB23p / sB23n) whose 16 k of every k-tile
@@ -104,27 +119,18 @@ typedef struct AbxGemm {
     int mlp, N2;
     /* LayerNorm over the N OUTPUT columns (gamma, beta; eps), applied right after bias / alpha / act and before rowscale / gate /
      * resid: Linear -> LayerNorm without a round trip of the rows through HBM (score_network.py:117-120).  Needs a kernel whose
-     * wave tile holds whole rows: split-bf16 path only (its own 128x128-tile instantiation), N <= 128, k-contiguous fp32 A, plain store */
+     * wave tile holds whole rows: split-f16 path only (its own 128x128-tile instantiation), N <= 128, k-contiguous fp32 A, plain store */
     const float* out_ln_w; const float* out_ln_b; float out_ln_eps;
-    int exact;                                     /* 0: large problems run fp32-accurate on the bf16 matrix cores (operands split
-                                                      into 3 bf16 pieces, 6 products, fp32 accumulate - csrc/gemm3.hip);
+    int exact;                                     /* 0: large problems run on the float16 matrix cores from split operands
+                                                      (3 exact products per fp32 product, fp32 accumulate - csrc/gemm3.hip);
                                                       1: always the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32);
-                                                      2: the split-bf16 kernels whatever the problem size (falls back to the exact
+                                                      2: the split-f16 kernels whatever the problem size (falls back to the exact
                                                       kernel only on shape / alignment grounds): callers that need results
                                                       independent of the batch size fix the arithmetic per op with 1 or 2 */
-    /* Split-f16 WEIGHT operands (round 3; csrc/gemm3.hip): when A is an fp32 operand (A_split NULL), B_split / B2_split hold the
-     * weights as three k-tiled FLOAT16 planes written by abx_split_weights_f16: with w' = w * 2^b_exp (|w'| < 2^14),
-     * p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 * 2^-11).  The kernels scale an activation by 2^-4, split it into
-     * a0 = f16(x'), a1 = f16((x' - a0) * 2^11) and accumulate a1 p2 + a0 p1 + a0 p0 in fp32 (3 MFMA products per fp32 product,
-     * every term exact; a piece pair carries 23 significant bits
-     * (|x' - a0 - a1 2^-11| <= 2^-23 |x'| worst case, 2^-25 on average) and the dropped term is <= 2^-22 |x w|, mean zero: measured as
-     * accurate as the exact fp32 MFMA kernel, tests/test_gpu_kernels.py::test_gemm_split_bf16_accuracy_vs_exact); the accumulators are multiplied by 2^(4 - b_exp) before the epilogue.
-     * Activation range: |x| < 2^20 (beyond: inf - inf = NaN in the output, never a silently wrong number); full relative
-     * precision down to |x| = 2^-10, absolute error < 2^-32 below.  b_f16 must be 1 with an fp32 A and 0 with A_split (the
-     * plane x plane contraction keeps three bf16 planes per operand: both sides are activations of unknown range). */
+    /* float16 weight planes: see "Split-f16 operands" above.  b_exp / b2_exp: exponents of B_split / B2_split (|.| <= 100) */
     int b_f16, b_exp, b2_exp;
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
-    unsigned long long* clock_probe;               /* diagnostics, optional DEVICE [2]: every workgroup of the split-bf16 kernels adds
+    unsigned long long* clock_probe;               /* diagnostics, optional DEVICE [2]: every workgroup of the split-f16 kernels adds
                                                       its elapsed shader-clock ticks (s_memtime) to [0] and its elapsed constant
                                                       100 MHz ticks (s_memrealtime) to [1]: 100 MHz * [0] / [1] = the shader clock
                                                       the kernel actually ran at (tools/probes/clock_probe.py) */
@@ -132,13 +138,10 @@ typedef struct AbxGemm {
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
-/* fp32 weights W[n][k] (element strides s_n, s_k) -> out[Kp/16][3][N][16] bf16 planes with w = p0 + p1 + p2 exactly,
- * Kp = (K+15)/16*16 (zero padded) */
-int abx_split_weights(const float* w, long long s_n, long long s_k, int N, int K, unsigned short* out, hipStream_t stream);
 /* fp32 weights W[n][k] -> out[Kp/16][3][N][16] float16 planes of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
  * scale_exp = 14 - e with max|w| = m * 2^e, 0.5 <= m < 1 (so that max|w| * 2^scale_exp is in [2^13, 2^14)) */
 int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out, hipStream_t stream);
-/* diagnostics: resident workgroups per CU of the main split-bf16 GEMM instantiations (0: 128x192, 1: 128x128,
+/* diagnostics: resident workgroups per CU of the main split-f16 GEMM instantiations (0: 128x192, 1: 128x128,
  * 2: 128x128 transposed store, 3: 128x192 plane operands); negative on error */
 int abx_gemm3_occupancy(int which);
 
@@ -164,9 +167,10 @@ typedef struct AbxTriAttn {
     float* out; long long ob, os, ol;               /* out (b,s,l,h*D+d) */
     int B, S, L, H, D;                              /* D must be 48 */
     float scale;
-    int exact;                                      /* 0: split-bf16 matrix-core kernel (fp32-accurate, any L <= 1536);
+    int exact;                                      /* 0: split-f16 matrix-core kernel (see AbxGemm: keys / values staged as B-side planes with
+                                                       e = 4, |k|, |v| < 4095; queries and softmax weights as A-side pieces; any L <= 1536);
                                                        1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
-    unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-bf16 kernel) */
+    unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernel) */
 } AbxTriAttn;
 int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);
 

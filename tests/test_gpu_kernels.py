@@ -114,9 +114,14 @@ def test_gemm_ln_gate_resid_rowscale(ops):
     check(xv, ref128 - r128.double(), 2e-6, 'layernorm K=128 in place')
 
 
-def _host_planes(x):
-    """fp32 tensor (..., rows, K) -> int16 k-tiled bf16 planes (..., K/16, 3, rows, 16), x = p0 + p1 + p2 (RNE pieces)."""
-    p0 = x.bfloat16(); r = x - p0.float(); p1 = r.bfloat16(); p2 = (r - p1.float()).bfloat16()
+def _host_planes(x, a_side):
+    """fp32 tensor (..., rows, K) -> int16 k-tiled f16 operand image (..., K/16, 3, rows, 16) of the plane x plane contraction
+    (include/abx_hip.h): A side x' = x / 16, (a0, (x' - a0) 2^11, 0); B side x' = 16 x, (p0, x' - p0, p0 2^-11); RNE pieces."""
+    xs = x / 16 if a_side else x * 16
+    p0 = xs.half()
+    r = xs - p0.float()
+    p1 = (r * 2048).half() if a_side else r.half()
+    p2 = torch.zeros_like(p0) if a_side else (p0.float() / 2048).half()
     pl = torch.stack([p0.view(torch.int16), p1.view(torch.int16), p2.view(torch.int16)], dim=-3)      # (..., 3, rows, K)
     rows, K = x.shape[-2:]
     assert K % 16 == 0
@@ -124,9 +129,10 @@ def _host_planes(x):
     return pl.movedim(-2, -4).contiguous()                                                           # (..., K/16, 3, rows, 16)
 
 
-def _planes_to_f64(pl):
-    """inverse of _host_planes: (..., K/16, 3, rows, 16) int16 -> float64 (..., rows, K)."""
-    f = (pl.to(torch.int32) << 16).view(torch.float32).double().sum(-3)                              # (..., K/16, rows, 16)
+def _planes_to_f64(pl, a_side):
+    """value of an operand image: (..., K/16, 3, rows, 16) int16 -> float64 (..., rows, K)."""
+    h = pl.view(torch.float16).double()
+    f = (h.select(-3, 0) + h.select(-3, 1) / 2048) * 16 if a_side else (h.select(-3, 0) + h.select(-3, 1)) / 16   # (..., K/16, rows, 16)
     return f.movedim(-3, -2).reshape(*f.shape[:-3], f.shape[-2], -1)
 
 
@@ -196,28 +202,13 @@ def test_gemm_split_f16_activation_range(ops):
     assert float((o2.cpu().double() - ref2).abs()[7].max()) < 1e-6 * 2.0 ** 20
 
 
-def test_gemm_split_bf16_weight_image(ops):
-    """abx_split_weights: W = p0 + p1 + p2 EXACTLY (three round-to-nearest bf16 pieces), k-tiled, zero padded rows."""
-    for K, N in ((192, 768), (52, 70), (128, 192)):
-        Wt = (torch.randn(K, N, generator=g(200)) * torch.logspace(-6, 3, N)[None]).to(DEV)
-        w3 = ops.split_planes_bf16(Wt)
-        Kp = (K + 15) // 16 * 16
-        assert w3.shape == (Kp // 16, 3, N, 16)
-        back = _planes_to_f64(w3.cpu())                                                              # (N, Kp)
-        assert torch.equal(back[:, :K], Wt.cpu().double().t()), 'split is not exact'
-        assert (back[:, K:] == 0).all()
-        # reference split on the host (torch bf16 conversion is round-to-nearest-even like v_cvt_pk_bf16_f32)
-        xp = torch.zeros(N, Kp); xp[:, :K] = Wt.cpu().t()
-        assert torch.equal(w3.cpu(), _host_planes(xp))
-
-
 def _err(x, ref):
     d = (x.detach().cpu().double() - ref).abs()
     return float(d.max() / ref.abs().max()), float(d.mean() / ref.abs().mean())
 
 
-def test_gemm_split_bf16_accuracy_vs_exact(ops):
-    """The split-bf16 kernels (gemm3.hip) against float64, next to the exact fp32 MFMA kernel on the same problem: the
+def test_gemm_split_accuracy_vs_exact(ops):
+    """The split-f16 kernels (gemm3.hip) against float64, next to the exact fp32 MFMA kernel on the same problem: the
     split path must be as accurate as native fp32 (max error within 1.5x, mean error within 1.2x of the exact kernel)."""
     for (M, N, K) in ((33000, 192, 192), (66000, 768, 192), (33000, 192, 768), (40000, 128, 192), (70000, 190, 100), (70001, 190, 192),
                       (50003, 322, 128)):
@@ -235,10 +226,10 @@ def test_gemm_split_bf16_accuracy_vs_exact(ops):
         assert e_s[0] < 3e-6
         if K % 16 == 0:
             if ((M + 127) // 128) * ((N + 127) // 128) >= 256:
-                assert not torch.equal(o_split, o_exact), 'the split-bf16 kernel did not run'
+                assert not torch.equal(o_split, o_exact), 'the split-f16 kernel did not run'
 
 
-def test_gemm_split_bf16_operand_larger_than_4gb(ops):
+def test_gemm_split_operand_larger_than_4gb(ops):
     """The pair-stack GEMMs of a 20-sample chunk at L = 352 have A operands beyond 4 GB (2.48 M rows x 768): the DMA offsets
     are tile-relative 32-bit values, so such problems must still run on the split kernels and be right at both ends."""
     M, N, K = 1_450_000, 192, 768                    # M * K * 4 B = 4.45 GB
@@ -250,15 +241,15 @@ def test_gemm_split_bf16_operand_larger_than_4gb(ops):
     ops.gemm(A, W, out, resid=out, B3=ops.split_weights(W))
     oe = res.clone()
     ops.gemm(A, W, oe, resid=oe, exact=True)
-    assert not torch.equal(out[:4096], oe[:4096]), 'the split-bf16 kernel did not run'
+    assert not torch.equal(out[:4096], oe[:4096]), 'the split-f16 kernel did not run'
     for sl in (slice(0, 4096), slice(M // 2, M // 2 + 4096), slice(M - 4096, M)):
         ref = A[sl].double() @ W.double() + res[sl].double()
         check(out[sl], ref, 3e-6, f'>4 GB operand rows {sl.start}')
 
 
-def test_gemm_split_bf16_fused_paths(ops):
+def test_gemm_split_fused_paths(ops):
     """LayerNorm (inline statistics, mean >> sigma), relu-on-load, gate / residual, transposed store and the channel-major A
-    operand on the split-bf16 kernels, against float64."""
+    operand on the split-f16 kernels, against float64."""
     M, N, K = 40 * 1000, 192, 192
     A = torch.randn(M, K, generator=g(204)) * 2 + 0.5
     W = torch.randn(N, K, generator=g(205)) / K ** 0.5
@@ -316,22 +307,22 @@ def test_gemm_split_bf16_fused_paths(ops):
     check(zd, (lnt @ Wo.double().t() + bo.double()) * Gf.double() + z3.double(), 3e-6, 'split gemm channel-major A')
 
 
-def test_gemm_split_bf16_contractions(ops):
-    """TriangleMultiplication einsum (seqformer.py:490-493) on the split-bf16 kernels: both operands as bf16 planes."""
+def test_gemm_split_contractions(ops):
+    """TriangleMultiplication einsum (seqformer.py:490-493) on the split-f16 kernels: both operands as f16 operand images."""
     for nb, L_ in ((640, 80), (512, 128), (260, 208), (130, 352)):
         X = torch.randn(nb, L_, L_, generator=g(230)) * 2
         Y = torch.randn(nb, L_, L_, generator=g(231))
         Xd, Yd = X.to(DEV), Y.to(DEV)
         out = torch.full((nb, L_, L_), float('nan'), device=DEV); oe = torch.empty(nb, L_, L_, device=DEV)
         r_out = torch.einsum('bik,bjk->bij', X.double(), Y.double())
-        ops.gemm(_host_planes(X).to(DEV), _host_planes(Y).to(DEV), out)
+        ops.gemm(_host_planes(X, True).to(DEV), _host_planes(Y, False).to(DEV), out)
         ops.gemm(Xd, Yd.transpose(1, 2), oe, exact=True)
         e_s, e_x = _err(out, r_out), _err(oe, r_out)
         assert e_s[0] <= 1.5 * e_x[0] + 1e-8 and e_s[1] <= 1.2 * e_x[1] + 1e-9 and e_s[0] < 3e-6, ('NT', nb, L_, e_s, e_x)
 
 
-def test_gemm_split_bf16_plane_output_and_pair_transpose(ops):
-    """The projection GEMMs of the triangle multiplication: transposed store as bf16 planes (C_split) and the pair-transposed
+def test_gemm_split_plane_output_and_pair_transpose(ops):
+    """The projection GEMMs of the triangle multiplication: transposed store as f16 operand images (C_split) and the pair-transposed
     row gather (a_pair_transpose) of the incoming variant."""
     B_, L_, K, C_ = 5, 120, 192, 128
     LL = L_ * L_
@@ -349,21 +340,26 @@ def test_gemm_split_bf16_plane_output_and_pair_transpose(ops):
         planes = torch.zeros(B_, C_, (L_ + 15) // 16, 3, L_, 16, dtype=torch.int16, device=DEV)
         # gates / mask are indexed by the GEMM row (i.e. already in the transposed order when a_pair_transpose is used)
         pmv = (pm.transpose(1, 2) if transpose else pm).reshape(-1).contiguous().to(DEV)
-        ops.gemm(zsrc, Wt, planes, bias=bias2, ln=(None, csum), rowscale=pmv,
+        ops.gemm(zsrc, Wt, planes, bias=bias2, ln=(None, csum), rowscale=pmv, c_split_nA=64,
                  gate=GT.to(DEV).transpose(1, 2), gate_sigmoid=False, B3=w3, a_pair_transpose=L_ if transpose else 0)
-        got = _planes_to_f64(planes.cpu())[..., :L_].reshape(B_, C_, LL)                          # (B, C, L, Kp) -> (B, C, LL)
+        pc = planes.cpu()
+        got = torch.cat([_planes_to_f64(pc[:, :64], True), _planes_to_f64(pc[:, 64:], False)], 1)[..., :L_].reshape(B_, C_, LL)
         want = (proj.transpose(1, 2) if transpose else proj).reshape(B_, LL, C_).transpose(1, 2) * GT.double()
         e = float((got - want).abs().max() / want.abs().max())
         assert e < 3e-6, (transpose, e)
-        # the three planes carry EXACTLY the fp32 values the same GEMM stores as fp32; the k padding stays 0
+        # the images are the host's split of the fp32 values the same GEMM stores as fp32, bit for bit; the k padding stays 0
         o32 = torch.empty(B_, C_, LL, device=DEV)
         ops.gemm(zsrc, Wt, o32.transpose(1, 2), bias=bias2, ln=(None, csum), rowscale=pmv,
                  gate=GT.to(DEV).transpose(1, 2), gate_sigmoid=False, B3=w3, a_pair_transpose=L_ if transpose else 0)
-        assert torch.equal(got.float(), o32.cpu()), 'plane output differs from the fp32 output'
-        assert (_planes_to_f64(planes.cpu())[..., L_:] == 0).all()
+        o4 = o32.cpu().view(B_, C_, L_, L_)
+        Kp = pc.shape[2] * 16
+        o4p = torch.zeros(B_, C_, L_, Kp); o4p[..., :L_] = o4
+        assert torch.equal(pc[:, :64], _host_planes(o4p[:, :64], True)) and torch.equal(pc[:, 64:], _host_planes(o4p[:, 64:], False)), \
+            'plane output is not the split of the fp32 output'
+        assert float((got.view(B_, C_, L_, L_) - o4.double()).abs().max() / o4.abs().max()) < 2.0 ** -22
 
 
-def test_gemm_split_bf16_glu_and_two_level_batch(ops):
+def test_gemm_split_glu_and_two_level_batch(ops):
     """The gated projections of the triangle multiplication as ONE glu GEMM (value * sigmoid(gate) from (value, gate) column
     pairs, plane output, pair mask, pair-transposed rows) and the contraction over channel slices of that tensor
     (two-level batch of the plane operands)."""
@@ -385,8 +381,9 @@ def test_gemm_split_bf16_glu_and_two_level_batch(ops):
     for transpose in (False, True):
         planes = torch.zeros(B_, C_, KT, 3, L_, 16, dtype=torch.int16, device=DEV)
         ops.gemm(Z.to(DEV).view(B_, LL, K), Wt, planes, bias=bias2, ln=(None, csum), rowscale=pm.reshape(-1).contiguous().to(DEV),
-                 glu=True, B3=w3, a_pair_transpose=L_ if transpose else 0)
-        got = _planes_to_f64(planes.cpu())[..., :L_]                                    # (B, C, i, k)
+                 glu=True, B3=w3, a_pair_transpose=L_ if transpose else 0, c_split_nA=128)
+        pc = planes.cpu()
+        got = torch.cat([_planes_to_f64(pc[:, :128], True), _planes_to_f64(pc[:, 128:], False)], 1)[..., :L_]      # (B, C, i, k)
         want = (val.transpose(1, 2) if transpose else val).permute(0, 3, 1, 2)
         e = float((got - want).abs().max() / want.abs().max())
         assert e < 3e-6, (transpose, e)
@@ -483,7 +480,7 @@ def test_gemm_small_n_and_relu_input(ops):
 @pytest.mark.parametrize('exact', [False, True])
 @pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False), (200, True), (212, False), (261, True), (300, False)])
 def test_tri_attn(ops, L, per_row, exact):
-    """exact=False: split-bf16 kernel (K/V in double-buffered chunks of 128 keys: L = 200 / 212 cross one chunk boundary, 261 / 300
+    """exact=False: split-f16 kernel (K/V in double-buffered chunks of 128 keys: L = 200 / 212 cross one chunk boundary, 261 / 300
     two, and carry the online softmax state over them); exact=True: fp32 MFMA kernel."""
     from oracle import abx_oracle as O
     B, H, D = (2 if L < 128 else 1), 4, 48
@@ -1172,7 +1169,7 @@ def test_gemm_dual_proj_out_times_gate(ops, L):
                                                  (40 * 40 * 3, 192, 768, 192, True)])
 def test_gemm_fused_transition(ops, M, K, NH, N2, inplace):
     """AbxGemm.mlp: LayerNorm -> Linear -> ReLU -> Linear (+ residual) in ONE kernel (the hidden never leaves the CU; seqformer.py:358-376)
-    against fp64 and against the two-launch path of the same split-bf16 kernels; ragged row tiles, a hidden width that is not a
+    against fp64 and against the two-launch path of the same split-f16 kernels; ragged row tiles, a hidden width that is not a
     multiple of the 128-channel chunk, fewer than 192 output columns, in place over the input rows."""
     ge = g(130 + M % 7)
     z = torch.randn(M, K, generator=ge) * 2 + 0.7
@@ -1205,7 +1202,7 @@ def test_gemm_fused_transition(ops, M, K, NH, N2, inplace):
 @pytest.mark.parametrize('N,M,exact', [(128, 40 * 40 * 9 + 37, 2), (96, 129 * 130, 2)])
 def test_gemm_output_layernorm(ops, N, M, exact):
     """Linear -> LayerNorm in the GEMM epilogue (out_ln; IpaScore's proj_init_pair_act + init_pair_layer_norm,
-    score_network.py:117-120): split-bf16 128x128 tiles with a full / partial (N = 96) row and a ragged last row tile; against fp64."""
+    score_network.py:117-120): split-f16 128x128 tiles with a full / partial (N = 96) row and a ragged last row tile; against fp64."""
     ge = g(131)
     K = 192
     x = torch.randn(M, K, generator=ge) * 1.5 + 0.3
@@ -1223,7 +1220,7 @@ def test_gemm_output_layernorm(ops, N, M, exact):
 @pytest.mark.parametrize('N,K,transposed,ln', [(4, 192, True, True), (32, 192, True, True), (12, 128, False, False)])
 def test_gemm_narrow_split_tile(ops, N, K, transposed, ln):
     """The skinny pair-stack projections (triangle-attention bias 192 -> 4, sequence-attention pair bias 192 -> 32, IPA pair
-    bias 128 -> 12) on the 128 x 32 tile of the split-bf16 GEMM: LayerNorm folded (inline statistics) or plain with alpha,
+    bias 128 -> 12) on the 128 x 32 tile of the split-f16 GEMM: LayerNorm folded (inline statistics) or plain with alpha,
     transposed (b, N, rows) or plain store, ragged last row tile; against fp64."""
     ge = g(140 + N)
     Bc, rows = 3, 37 * 37

@@ -200,9 +200,9 @@ def test_medium_complex_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
     close(ret['heads']['predicted_lddt']['pLDDT'], ref['heads']['predicted_lddt']['pLDDT'], 5e-3, 1e-4, 'pLDDT')
 
 
-def test_split_bf16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
-    """L = 120 (k padding: 120 -> 128), 5 samples in one chunk: large enough for the split-bf16 GEMM kernels, so the triangle
-    multiplication runs through the bf16-plane projections (C_split), the pair-transposed row gather of the incoming variant
+def test_split_f16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
+    """L = 120 (k padding: 120 -> 128), 5 samples in one chunk: large enough for the split-f16 GEMM kernels, so the triangle
+    multiplication runs through the f16-image projections (C_split), the pair-transposed row gather of the incoming variant
     and the plane contraction.  One full call (3 passes) HIP vs oracle, then the same call on the exact fp32 MFMA kernels."""
     from oracle import abx_oracle as O
     from abx_amd import sampler, ops
@@ -241,9 +241,9 @@ def test_split_bf16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_di
     assert not torch.equal(ret['representations']['pair'], rex['representations']['pair']), 'both runs took the same kernels'
 
 
-def test_split_bf16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
-    """Driver-level parity with the split-bf16 kernels active (L = 112, 3 samples: every GEMM, the plane contraction and the
-    triangle attention run on the bf16 matrix cores), TEACHER-FORCED (SURVEY §7 hard part 1a): the warm-up call and every grid
+def test_split_f16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
+    """Driver-level parity with the split-f16 kernels active (L = 112, 3 samples: every GEMM, the plane contraction and the
+    triangle attention run on the float16 matrix cores), TEACHER-FORCED (SURVEY §7 hard part 1a): the warm-up call and every grid
     point of a 3-point trajectory start from the ORACLE's state (rigids_t, seq_t, self-conditioning tensors), so each call and
     each reverse step is compared on identical inputs at 1e-4-class tolerances, for both HIP arithmetic paths.  Inside a call the
     two recycles feed DISCRETE decisions back (distogram bins of prev_pos, argmax tokens): both sides are traced, and a sample whose
@@ -545,8 +545,8 @@ def _cpu_copy(b, sl=slice(None)):
 
 
 class _GemmSpy:
-    """Counts the abx_gemm calls whose A operand is a bf16-plane tensor (the triangle-multiplication contraction on the
-    split-bf16 kernels) and those that use the padded pair-row maps."""
+    """Counts the abx_gemm calls whose A operand is a f16-image tensor (the triangle-multiplication contraction on the
+    split-f16 kernels) and those that use the padded pair-row maps."""
 
     def __enter__(self):
         from abx_amd import ops
@@ -568,12 +568,12 @@ class _GemmSpy:
                                  # L = 402 > 384: the 4-slot triangle-attention instantiation (4 query tiles per wave, 4 key
                                  # chunks), 7 key tasks per head and 34 query blocks in the IPA weights kernel
                                  (dict(L_heavy=126, L_light=110, L_antigen=166, cdr=(100, 112)), 1),
-                                 # L = 65: the first length of the split-bf16 arithmetic class, single partial tiles everywhere
+                                 # L = 65: the first length of the split-f16 arithmetic class, single partial tiles everywhere
                                  (dict(L_heavy=30, L_light=25, L_antigen=10, cdr=(15, 22)), 4),
                                  (dict(L_heavy=80, L_light=70, L_antigen=41, cdr=(50, 61)), 2)])         # L = 191
 def test_any_length_takes_the_plane_path_vs_oracle(gpu_model, params, cfg, oracle_diffuser, w, B):
     """residue counts that are not multiples of 4 (the real complexes are L = 230 and 261) run the triangle
-    multiplication on the same glu -> bf16 planes -> plane contraction route as L = 352, through the padded pair-row maps.
+    multiplication on the same glu -> f16 operand images -> plane contraction route as L = 352, through the padded pair-row maps.
     One full call (3 passes), 4 samples with different noise and a masked antigen tail, HIP vs oracle."""
     from oracle import abx_oracle as O
     from abx_amd import sampler, ops
@@ -708,7 +708,7 @@ def test_full_call_matches_reference_golden_L48(gpu_model, cfg):
 @pytest.mark.parametrize('name', ['L256', 'L352'])
 def test_large_shape_digest_vs_reference(gpu_model, cfg, name):
     """the HIP path against outputs of the REFERENCE ITSELF at the benchmark's sizes (the bench's synthetic
-    complexes, B = 1, one in-loop call = 3 passes on the split-bf16 kernels)."""
+    complexes, B = 1, one in-loop call = 3 passes on the split-f16 kernels)."""
     from abx_amd import features
     from conftest import digest_batch
     model, D = gpu_model
@@ -1072,7 +1072,7 @@ def test_design_driver_two_ranks_shard_the_samples(tmp_path):
 
 
 def test_results_do_not_depend_on_stale_lds(gpu_model, cfg):
-    """No kernel may read LDS it has not written: one ScoreNetwork call (L = 112: split-bf16 GEMMs, plane contraction, both
+    """No kernel may read LDS it has not written: one ScoreNetwork call (L = 112: split-f16 GEMMs, plane contraction, both
     attentions, IPA) is repeated with the LDS of every CU overwritten (abx_debug_poison_lds: NaN pattern, then large finite
     garbage) before EVERY launch of the library; every output must be bit-identical to the un-poisoned call."""
     import ctypes as C

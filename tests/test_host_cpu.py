@@ -152,7 +152,7 @@ def test_gather_results_gloo_world2():
 
 
 def test_glu_weight_packing_and_kernel_name_mirror():
-    """Host-side helpers of the split-bf16 path (no GPU): the (value, gate) column interleave of a glu GEMM and the
+    """Host-side helpers of the split-f16 path (no GPU): the (value, gate) column interleave of a glu GEMM and the
     kernel-selection mirror that bench.py uses to label launches."""
     import torch
     from abx_amd import ops

@@ -34,12 +34,12 @@ def main():
     ap.add_argument('--bc', type=int, default=10)
     ap.add_argument('--L', type=int, default=352)
     ap.add_argument('--only', default='')
-    ap.add_argument('--exact', action='store_true', help='exact fp32 MFMA GEMM kernels instead of the split-bf16 ones')
+    ap.add_argument('--exact', action='store_true', help='exact fp32 MFMA GEMM kernels instead of the split-f16 ones')
     a = ap.parse_args()
     ops.GEMM_EXACT = a.exact
     _gemm, _splits = ops.gemm, {}
 
-    def gemm_with_split(A, B, Cout, **kw):       # weight GEMMs get their pre-split bf16 image, like model/forward.py does
+    def gemm_with_split(A, B, Cout, **kw):       # weight GEMMs get their float16 weight planes, like model/forward.py does
         if not a.exact and B.dim() == 2 and B.stride(1) == 1 and B.shape[1] > 64 and 'B3' not in kw:
             key = (B.data_ptr(), tuple(B.shape))
             if key not in _splits:

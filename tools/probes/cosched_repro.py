@@ -3,7 +3,7 @@
 
 Each worker process repeats ONE kernel N times on bit-identical inputs (restored from a master copy before every launch) and compares
 every output with the output of its own first launch, on the device (torch.equal -> one bool per launch, synchronised in batches).
-Kernels: `rigid_update` (no LDS, no MFMA: B*L threads of scalar fp32 math), the dominant split-bf16 GEMM (LDS-DMA, raw
+Kernels: `rigid_update` (no LDS, no MFMA: B*L threads of scalar fp32 math), the dominant split-f16 GEMM (LDS-DMA, raw
 s_barrier / s_waitcnt), the triangle attention, and a plain torch elementwise kernel as a control.
 Run solo (1 worker) and with 2 / 3 workers started together on the SAME GPU:
 
@@ -87,7 +87,7 @@ def worker(n, tag):
         xc, yc0 = 0.1 * rn(M1 * 3), torch.nn.functional.normalize(rn(M1, 4), dim=-1).reshape(-1).contiguous()
         yc = yc0.clone()
         loop('custom quaternion chain (ctypes .so)', lambda: yc.copy_(yc0), lambda: lib.probe_chain(xc.data_ptr(), yc.data_ptr(), M1, st()), lambda: yc, n)
-    # ---- split-bf16 GEMM (N = 768, K = 192), 2 samples of pair rows
+    # ---- split-f16 GEMM (N = 768, K = 192), 2 samples of pair rows
     M2 = 2 * L * L
     z, W = rn(M2, 192), rn(192, 768) / 14
     C, bias, csum, W3 = torch.empty(M2, 768, device=dev), rn(768), rn(768), ops.split_weights(W)
