@@ -65,6 +65,7 @@ class AbxTriAttn(C.Structure):
         ('scale', F),
         ('exact', I),
         ('clock_probe', c_f),
+        ('tune', I),
     ]
 
 

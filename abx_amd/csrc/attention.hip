@@ -276,11 +276,16 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 
 // KC4: keys per chunk; DB: double-buffered chunks (next chunk's loads ride under this chunk's compute, one barrier per chunk) or
 // a single buffer (load -> split -> write between two barriers at every chunk start, but fewer, larger chunks)
-template <int MAXQ, int KC4, bool DB>
-__global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn a) {
+template <int MAXQ, int KC4, bool DB, int NTH, bool PROD>
+__global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     constexpr int PLN = KC4 * RST;           // bytes per plane
     constexpr int BUF4 = 6 * PLN;            // K planes + V planes of one chunk
-    constexpr int NIT = (KC4 * (TD / 4) + TRI_THREADS - 1) / TRI_THREADS;     // staging items per thread and chunk
+    constexpr int NIT = (KC4 * (TD / 4) + NTH - 1) / NTH;     // staging items per thread and chunk
+    // PROD: the last wave is a PRODUCER - it alone stages the next chunk (loads, splits, LDS writes) while the other NCW waves
+    // compute.  Vector-memory results return in issue order, so a consumer that also carried staging loads (HBM latency) waited for
+    // them at its next bias use (L2 latency); with L = 352 the 22 query tiles are exactly 2 slots of 11 consumer waves.
+    constexpr int NCW = NTH / 64 - (PROD ? 1 : 0);
+    static_assert(!PROD || DB, "producer wave: double-buffered chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     float* Msb = reinterpret_cast<float*>(lds + (DB ? 2 : 1) * BUF4);       // [2][KC4] key-mask clamps of the chunks in flight
@@ -322,8 +327,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
     // Item `it` of the NEXT chunk is loaded before and written after the wave's query-tile slot `it` of the current chunk (the
     // other buffer was last read before the previous barrier), so only one item is live in registers at a time.
     f32x4 kreg, vreg;
-    auto stage_load = [&](int c0, int it) {
-        const int idx = tid + it * TRI_THREADS;
+    auto stage_load = [&](int c0, int idx) {
         const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
         kreg = (f32x4){0.f, 0.f, 0.f, 0.f};
         vreg = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -333,12 +337,13 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             vreg = *reinterpret_cast<const f32x4*>(a.v + off);
         }
     };
-    auto stage_write = [&](int c0, int buf, int it) {
+    auto stage_mask = [&](int c0, int buf, int t) {
+        Msb[buf * KC4 + t] = (c0 + t < L) ? ((!km || km[c0 + t] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+    };
+    auto stage_write = [&](int c0, int buf, int idx) {
         char* Kp = lds + buf * BUF4;
         char* Vp = Kp + 3 * PLN;
-        const int idx = tid + it * TRI_THREADS;
         const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
-        if (it == 0 && tid < KC4) Msb[buf * KC4 + tid] = (c0 + tid < L) ? ((!km || km[c0 + tid] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
         if (kk >= KC4) return;
         unsigned a0, a1, a2, b0, b1, b2;
         split2w(kreg[0], kreg[1], a0, a1, a2);
@@ -359,11 +364,44 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
 
     if (DB) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) { stage_load(0, it); stage_write(0, 0, it); }
+        for (int it = 0; it < NIT; ++it) { stage_load(0, tid + it * NTH); stage_write(0, 0, tid + it * NTH); }
+        if (tid < KC4) stage_mask(0, 0, tid);
         __syncthreads();
     }
 
     const int nchunk = (L + KC4 - 1) / KC4;
+    // the two on-demand global streams of a consumer wave: the raw Q rows of a query tile, the bias of a key tile.  (Requesting them
+    // one slot / one tile ahead was measured: no gain with 8 waves of 256 registers, spills with 12 waves - tools/probes/kb_tri.py)
+    f32x4 qraw[4], bz[4];
+    auto q_load = [&](int qt_) {
+        const int qrow_ = qt_ * 16 + lq;
+        const bool ok_ = qrow_ < L;
+        const float* qp = a.q + base + (long long)(ok_ ? qrow_ : 0) * a.sl;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const bool live = ok_ && (hh == 0 || g < 2);            // d 32..47 only: lane groups 2, 3 of the second step are 0
+            qraw[2 * hh] = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            qraw[2 * hh + 1] = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // bias of the tile (query tile qt_, chunk at key c0_, keys k0_ + sub*16 + 4g + r of nkeys_ in the chunk)
+    auto bias_load = [&](int qt_, int c0_, int nkeys_, int k0_) {
+        const int qrow_ = qt_ * 16 + lq;
+        const float* brow = biasb ? biasb + (long long)(qrow_ < L ? qrow_ : 0) * a.bias_sq + (long long)c0_ * a.bias_sk : nullptr;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const int kq = k0_ + sub * 16 + g * 4;                  // first of this lane's 4 keys (chunk-relative)
+            if (bias_vec && c0_ + kq + 4 <= bias_row) {
+                bz[sub] = *reinterpret_cast<const f32x4*>(brow + kq);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = min(kq + r, nkeys_ - 1);
+                    bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
+                }
+            }
+        }
+    };
     for (int ch = 0; ch < nchunk; ++ch) {
         const int c0 = ch * KC4, buf = DB ? (ch & 1) : 0;
         const int nkeys = min(KC4, L - c0);
@@ -372,7 +410,8 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
         if (!DB) {
             __syncthreads();                                    // the previous chunk has been consumed
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) { stage_load(c0, it); stage_write(c0, 0, it); }
+            for (int it = 0; it < NIT; ++it) { stage_load(c0, tid + it * NTH); stage_write(c0, 0, tid + it * NTH); }
+            if (tid < KC4) stage_mask(c0, 0, tid);
             __syncthreads();
         }
         const char* Kp = lds + buf * BUF4;
@@ -380,25 +419,37 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
         const float* Ms = Msb + buf * KC4;
         const bool masked_chunk = any_masked;                   // (per sample: a masked key anywhere -> clamp every tile)
 
+        if (PROD && wave == NCW) {
+            // ---- producer wave: the whole next chunk, 4 (key, 4-channel) items per lane in flight
+            if (more) {
+                constexpr int NPI = KC4 * (TD / 4) / 64;            // items per lane
+                f32x4 kr[4], vr[4];
+                for (int j0 = 0; j0 < NPI; j0 += 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { stage_load(c0 + KC4, lane + (j0 + j) * 64); kr[j] = kreg; vr[j] = vreg; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { kreg = kr[j]; vreg = vr[j]; stage_write(c0 + KC4, buf ^ 1, lane + (j0 + j) * 64); }
+                }
+                for (int t = lane; t < KC4; t += 64) stage_mask(c0 + KC4, buf ^ 1, t);
+            }
+        } else
 #pragma unroll
         for (int sl = 0; sl < MAXQ; ++sl) {
-            const int qt = wave + sl * (TRI_THREADS / 64);
-            // staging item sl of the next chunk rides along with slot sl (slots >= 2 carry none; a wave without a query tile in
-            // this slot still does its share)
-            if (sl < NIT && more) stage_load(c0 + KC4, sl);
+            const int qt = wave + sl * NCW;
+            // (no producer wave) staging item sl of the next chunk rides along with slot sl (slots >= NIT carry none; a wave without a
+            // query tile in this slot still does its share)
+            if (!PROD && sl < NIT && more) stage_load(c0 + KC4, tid + sl * NTH);
             if (qt < nqt) {
             // ---- Q fragments (B operand of the swapped product), pre-scaled, split: lane holds Q[q][dbase + 8g .. +7]
             const int qrow = qt * 16 + lq;
             const bool qok = qrow < L;
             f16x8 qf[2][2];
+            q_load(qt);
             {
-                const float* qp = a.q + base + (long long)(qok ? qrow : 0) * a.sl;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     float x[8];
-                    const bool live = qok && (hh == 0 || g < 2);        // d 32..47 only: lane groups 2, 3 of the second step are 0
-                    const f32x4 lo = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    const f32x4 hi = live ? *reinterpret_cast<const f32x4*>(qp + hh * 32 + g * 8 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const f32x4 lo = qraw[2 * hh], hi = qraw[2 * hh + 1];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { x[e] = lo[e] * qscale; x[4 + e] = hi[e] * qscale; }
                     unsigned q0[4], q1[4];
@@ -408,7 +459,6 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
                     qf[hh][1] = __builtin_bit_cast(f16x8, u32x4{q1[0], q1[1], q1[2], q1[3]});
                 }
             }
-            const float* brow = biasb ? biasb + (long long)(qok ? qrow : 0) * a.bias_sq + (long long)c0 * a.bias_sk : nullptr;
             float mr = m_run[sl], lr = l_run[sl];
             f32x4 oo[3] = {o[sl][0], o[sl][1], o[sl][2]};
             using T = SplitTerms;                         // A: the two-piece operand (Q, P), B: the plane operand (K, V)
@@ -416,20 +466,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             for (int kt = 0; kt < nkt; ++kt) {
                 const int k0 = kt * 64;
                 // ---- bias of this tile (keys k0 + sub*16 + 4g + r): issued first, consumed after the QK^T MFMAs
-                f32x4 bz[4];
-#pragma unroll
-                for (int sub = 0; sub < 4; ++sub) {
-                    const int kq = k0 + sub * 16 + g * 4;                // first of this lane's 4 keys (chunk-relative)
-                    if (bias_vec && c0 + kq + 4 <= bias_row) {
-                        bz[sub] = *reinterpret_cast<const f32x4*>(brow + kq);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = min(kq + r, nkeys - 1);
-                            bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
-                        }
-                    }
-                }
+                bias_load(qt, c0, nkeys, k0);
                 f32x4 sc[4];
                 // ---- S^T tiles: 4 sub-blocks of 16 keys x 2 d-steps x 6 products
 #pragma unroll
@@ -528,16 +565,19 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn4_kernel(const AbxTriAttn
             l_run[sl] = lr;
             o[sl][0] = oo[0]; o[sl][1] = oo[1]; o[sl][2] = oo[2];
             }
-            if (sl < NIT && more) stage_write(c0 + KC4, buf ^ 1, sl);
+            if (!PROD && sl < NIT && more) {
+                stage_write(c0 + KC4, buf ^ 1, tid + sl * NTH);
+                if (sl == 0 && tid < KC4) stage_mask(c0 + KC4, buf ^ 1, tid);
+            }
         }
         if (DB) __syncthreads();
     }
     // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
 #pragma unroll
     for (int sl = 0; sl < MAXQ; ++sl) {
-        const int qt = wave + sl * (TRI_THREADS / 64);
+        const int qt = wave + sl * NCW;
         const int qrow = qt * 16 + lq;
-        if (qt >= nqt || qrow >= L) continue;
+        if (wave >= NCW || qt >= nqt || qrow >= L) continue;
         const float inv = 0.0625f / l_run[sl];                  // l_run accumulated P / 16
         const long long go = base + (long long)qrow * a.sl;
         float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
@@ -714,8 +754,12 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
     if (!a.exact) {
-        // split-bf16 kernel: K / V staged in (double-buffered) key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
-        const int slots = ((a.L + 15) / 16 + TRI_THREADS / 64 - 1) / (TRI_THREADS / 64);
+        // split-f16 kernel: K / V staged in (double-buffered) key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
+        // Up to 2 slots of 11 consumer waves (L <= 352): the producer-wave variant; else 12 computing waves that share the staging.
+        // (Every query's arithmetic is the same in all variants: results are bit-identical.)  tune bit 0: never the producer wave.
+        const int nqt = (a.L + 15) / 16, nw = TRI_THREADS / 64;
+        const bool prod = (nqt + nw - 2) / (nw - 1) <= 2 && !(a.tune & 1);
+        const int slots = prod ? 2 : (nqt + nw - 1) / nw;
         ABX_REQUIRE(slots <= 8, "abx_tri_attn_fwd: L too large (L <= 1536)");
         const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
         ABX_REQUIRE(nbh8 * a.S < (1LL << 31), "abx_tri_attn_fwd: grid too large");
@@ -726,10 +770,10 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
             return abx_check_launch("abx_tri_attn_fwd");
         };
         auto lds_of = [](int kc, bool db) { return (size_t)(db ? 2 : 1) * (6 * kc * RST + kc * sizeof(float)); };
-        // (single-buffered 192- / 256-key chunks and an 8-wave variant with hoisted Q fragments measured the same as this one)
-        if (slots <= 2) return launch(&tri_attn4_kernel<2, 128, true>, lds_of(128, true));
-        if (slots <= 4) return launch(&tri_attn4_kernel<4, 128, true>, lds_of(128, true));
-        return launch(&tri_attn4_kernel<8, 128, true>, lds_of(128, true));
+        if (prod) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, true>, lds_of(128, true));
+        if (slots <= 2) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, false>, lds_of(128, true));
+        if (slots <= 4) return launch(&tri_attn4_kernel<4, 128, true, TRI_THREADS, false>, lds_of(128, true));
+        return launch(&tri_attn4_kernel<8, 128, true, TRI_THREADS, false>, lds_of(128, true));
     }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout of the exact kernel (L <= 389)");

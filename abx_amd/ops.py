@@ -354,11 +354,14 @@ def tri_attn_kernel_name(L, exact=None):
     """Name of the kernel abx_tri_attn_fwd launches (mirror of the selection in csrc/attention.hip), for per-kernel aggregation."""
     if GEMM_EXACT if exact is None else exact:
         return 'tri_attn_kernel'
-    slots = ((L + 15) // 16 + 11) // 12
-    return f'tri_attn4_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}, 128, true>'
+    nqt = (L + 15) // 16
+    if (nqt + 10) // 11 <= 2:
+        return 'tri_attn4_kernel<2, 128, true, 768, true>'
+    slots = (nqt + 11) // 12
+    return f'tri_attn4_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}, 128, true, 768, false>'
 
 
-def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None):
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):
     """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
     already laid out [b,h,q,k] for this orientation (bias_is_qk=True; then (B,H,L,Lp) with rows padded to Lp % 4 == 0 floats gives
     the kernel 16-byte bias loads for any L); out (B*L*L, H*D)."""
@@ -384,6 +387,7 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.B, a.S, a.L, a.H, a.D = B, L, L, H, D
     a.scale = float(D ** (-0.5))
     a.exact = int(GEMM_EXACT if exact is None else exact)
+    a.tune = int(tune)
     if clock_probe is not None:
         assert clock_probe.dtype == torch.int64 and clock_probe.numel() >= 2
         a.clock_probe = _p(clock_probe)

@@ -510,6 +510,29 @@ def test_tri_attn(ops, L, per_row, exact):
     check(out2.view(B, L, L, C), o, 5e-6, f'tri_attn (qk bias) L={L} per_row={per_row}')
 
 
+@pytest.mark.parametrize('L', [97, 352, 368])
+def test_tri_attn_variants_bit_identical(ops, L):
+    """The producer-wave variant (11 computing waves + 1 staging wave: the library's choice up to L = 352) and the variant whose 12
+    waves share the staging (AbxTriAttn.tune bit 0; the library's choice from L = 353: L = 368 runs it either way) evaluate every
+    query with the same arithmetic: equal bits, masked keys and a ragged last key chunk included; both against the exact kernel."""
+    B, H, D = 1, 4, 48
+    C = H * D
+    gen = torch.Generator(device=DEV).manual_seed(300 + L)
+    x = torch.randn(B * L * L, 4 * C, device=DEV, generator=gen)
+    biasT = torch.randn(B, H, L, L, device=DEV, generator=gen)
+    mask = (torch.rand(B, L, device=DEV, generator=gen) > 0.1).float()
+    mask[:, 0] = 1
+    outs = []
+    for tune in (0, 1):
+        o = torch.full((B * L * L, C), float('nan'), device=DEV)
+        ops.tri_attn(x, biasT, mask, o, B, L, True, tune=tune)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    oe = torch.empty(B * L * L, C, device=DEV)
+    ops.tri_attn(x, biasT, mask, oe, B, L, True, exact=True)
+    assert float((outs[0] - oe).abs().max()) < 5e-6 * float(oe.abs().max()) + 5e-6
+
+
 @pytest.mark.parametrize('exact', [False, True])
 @pytest.mark.parametrize('L,spike', [(80, 70), (200, 190)])
 def test_tri_attn_all_keys_masked_row_and_spike(ops, exact, L, spike):

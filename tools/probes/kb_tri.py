@@ -1,0 +1,26 @@
+"""Triangle attention variants (AbxTriAttn.tune): 0 = library choice (L <= 352: 11 computing waves + 1 producer wave that stages the next
+key chunk), 1 = 12 computing waves that share the staging.  Usage: kb_tri.py [Bc] [L] [m = mask the last 7 keys]"""
+import sys
+import torch
+sys.path.insert(0, '/root/repo')
+from abx_amd import ops
+from tools.kbench import timeit
+DEV = 'cuda:0'
+Bc, L = int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 352
+LL, M2 = L * L, Bc * L * L
+r = lambda *s: torch.randn(*s, device=DEV)
+x, bT, mask = r(M2, 768), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV)
+if len(sys.argv) > 3: mask[:, L - 7:] = 0
+outs = {}
+for per_row in (True, False):
+    for tune in (0, 1):
+        o = torch.empty(M2, 192, device=DEV)
+        ops.tri_attn(x, bT, mask, o, Bc, L, per_row, bias_is_qk=True, tune=tune)
+        outs[(per_row, tune)] = o
+        ms = timeit(lambda: ops.tri_attn(x, bT, mask, o, Bc, L, per_row, bias_is_qk=True, tune=tune), reps=7)
+        print(f'per_row={per_row} tune={tune}: {ms:7.3f} ms  {4.0 * Bc * L * 4 * LL * 48 / ms / 1e9:6.1f} TFLOP/s', flush=True)
+    print('   bit-identical across variants:', all(torch.equal(outs[(per_row, 0)], outs[(per_row, t)]) for t in (1,)))
+if L <= 389:
+    oe = torch.empty(M2, 192, device=DEV)
+    ops.tri_attn(x, bT, mask, oe, Bc, L, True, bias_is_qk=True, exact=True)
+    print('max |split - exact|', float((outs[(True, 0)] - oe).abs().max()), 'max |exact|', float(oe.abs().max()))
