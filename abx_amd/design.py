@@ -117,7 +117,12 @@ def main(argv=None):
     ap.add_argument('--gpu_list', type=int, nargs='+', default=None, help='GPUs to use, one rank each (default: the launcher\'s ranks / GPU 0)')
     ap.add_argument('--batch_size', type=int, default=1, help='accepted for compatibility (complexes per batch upstream); ignored')
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--exact_gemm', action='store_true', help='exact fp32-MFMA kernels instead of the split-f16 ones (slower; the remedy when '
+                    'the sampler reports non-finite frames: an activation beyond the split kernels\' range)')
     a = ap.parse_args(argv)
+    if a.exact_gemm:
+        from abx_amd import ops
+        ops.GEMM_EXACT = True
     if a.gpu_list and len(a.gpu_list) > 1 and 'WORLD_SIZE' not in os.environ:
         import sys
         rc_ = _relaunch_on_gpus(a.gpu_list, sys.argv[1:] if argv is None else argv)

@@ -96,7 +96,19 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
                     on_record(traj[-1])
             if on_step is not None:
                 on_step(k, t, batch, out)
+    check_finite(batch['rigids_t'], traj[-1]['atom14_results'])
     return traj
+
+
+def check_finite(*tensors):
+    """One reduction + host sync at the end of a trajectory.  The split-f16 contractions turn an operand beyond their range
+    (include/abx_hip.h, "Split-f16 operands": |x| >= 2^20, 4095 for attention keys / values and the right tri-mul operand) into NaN
+    rows instead of wrong numbers; this is where that becomes an error, with the remedy."""
+    ok = torch.stack([torch.isfinite(t).all() for t in tensors if t is not None and t.numel() > 0] or [torch.tensor(True)]).all()
+    if not bool(ok):
+        raise FloatingPointError('non-finite frames / coordinates at the end of the trajectory: an activation left the range of the '
+                                 'split-f16 kernels (or the inputs / weights are not finite).  Re-run with the exact fp32-MFMA '
+                                 'kernels: abx_amd.ops.GEMM_EXACT = True (design.py --exact_gemm)')
 
 
 # -------------------------------------------------------------------------------------------------------------------

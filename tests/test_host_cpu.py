@@ -266,3 +266,18 @@ def test_metrics_match_reference_calc_ab_metrics():
         for (k, v), r in zip(m.items(), ref):
             assert abs(v - r) <= (0.0 if k.endswith('AAR') else 1e-9 * max(1.0, abs(r))), (c, k, v, r)
     assert float(z['c3.values'].max()) > 5.0 and float(z['c0.values'].min()) < 1e-12
+
+
+def test_sampler_reports_non_finite_results():
+    """The split-f16 kernels answer an out-of-range activation with NaN rows (tests/test_gpu_kernels.py::
+    test_gemm_split_f16_activation_range); the sampler turns that into an error that names the remedy."""
+    import pytest
+    import torch
+    from abx_amd import sampler
+    sampler.check_finite(torch.zeros(2, 5, 7, dtype=torch.float64), torch.ones(2, 5, 14, 3), None, torch.zeros(0, 3))
+    bad = torch.ones(2, 5, 14, 3)
+    bad[1, 2, 3, 0] = float('nan')
+    with pytest.raises(FloatingPointError, match='GEMM_EXACT'):
+        sampler.check_finite(torch.zeros(2, 5, 7), bad)
+    with pytest.raises(FloatingPointError):
+        sampler.check_finite(torch.full((1, 3, 7), float('inf')))
