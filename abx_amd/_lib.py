@@ -66,6 +66,7 @@ class AbxTriAttn(C.Structure):
         ('exact', I),
         ('clock_probe', c_f),
         ('tune', I),
+        ('q_parts', I),
     ]
 
 

@@ -291,8 +291,11 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     float* Msb = reinterpret_cast<float*>(lds + (DB ? 2 : 1) * BUF4);       // [2][KC4] key-mask clamps of the chunks in flight
     const int L = a.L;
     // ---- (b, h, s) of this workgroup: XCD x (blockIdx & 7) owns the (b, h) pairs x, x + 8, ... and walks their rows in order
+    // Long rows: the query tiles of a row are dealt to q_parts workgroups (each stages all keys of the row; neighbours in the grid, so
+    // the row's K / V come from the L2 the second time): a wave never carries more than MAXQ tiles of online-softmax state.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int bh = (slot / a.S) * 8 + xcd, s = slot % a.S;
+    const int per_bh = a.S * a.q_parts, sp = slot % per_bh;
+    const int bh = (slot / per_bh) * 8 + xcd, s = sp / a.q_parts, part = sp % a.q_parts;
     if (bh >= a.B * a.H) return;
     const ClockProbe probe(a.clock_probe);
     const int b = bh / a.H, h = bh % a.H;
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
     const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
     const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
-    const int nqt = (L + 15) / 16;
+    const int nqt_row = (L + 15) / 16, tpp = (nqt_row + a.q_parts - 1) / a.q_parts;   // query tiles of the row / of one part
+    const int qt0 = part * tpp, nqt = min(nqt_row, qt0 + tpp);
     const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
     const int bias_row = (int)a.bias_sq;                        // readable floats per bias row when bias_sk == 1
     // split-f16 scales: keys / values are staged as 16 x, queries and softmax weights enter as x / 16, so the products need no rescale
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
         } else
 #pragma unroll
         for (int sl = 0; sl < MAXQ; ++sl) {
-            const int qt = wave + sl * NCW;
+            const int qt = qt0 + wave + sl * NCW;
             // (no producer wave) staging item sl of the next chunk rides along with slot sl (slots >= NIT carry none; a wave without a
             // query tile in this slot still does its share)
             if (!PROD && sl < NIT && more) stage_load(c0 + KC4, tid + sl * NTH);
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
 #pragma unroll
     for (int sl = 0; sl < MAXQ; ++sl) {
-        const int qt = wave + sl * NCW;
+        const int qt = qt0 + wave + sl * NCW;
         const int qrow = qt * 16 + lq;
         if (wave >= NCW || qt >= nqt || qrow >= L) continue;
         const float inv = 0.0625f / l_run[sl];                  // l_run accumulated P / 16
@@ -755,25 +759,25 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
     if (!a.exact) {
         // split-f16 kernel: K / V staged in (double-buffered) key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
-        // Up to 2 slots of 11 consumer waves (L <= 352): the producer-wave variant; else 12 computing waves that share the staging.
+        // A workgroup carries 2 query-tile slots per wave: 24 tiles with 12 computing waves, 22 with 11 + the producer wave.  Rows with
+        // more tiles are dealt to q_parts workgroups of (almost) equal share; the producer variant whenever the share fits its 22.
         // (Every query's arithmetic is the same in all variants: results are bit-identical.)  tune bit 0: never the producer wave.
+        AbxTriAttn aa = a;
         const int nqt = (a.L + 15) / 16, nw = TRI_THREADS / 64;
-        const bool prod = (nqt + nw - 2) / (nw - 1) <= 2 && !(a.tune & 1);
-        const int slots = prod ? 2 : (nqt + nw - 1) / nw;
-        ABX_REQUIRE(slots <= 8, "abx_tri_attn_fwd: L too large (L <= 1536)");
+        aa.q_parts = (nqt + 2 * nw - 1) / (2 * nw);
+        const int tpp = (nqt + aa.q_parts - 1) / aa.q_parts;
+        const bool prod = tpp <= 2 * (nw - 1) && !(a.tune & 1);
         const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
-        ABX_REQUIRE(nbh8 * a.S < (1LL << 31), "abx_tri_attn_fwd: grid too large");
-        const dim3 grid((unsigned)(nbh8 * a.S)), block(TRI_THREADS);
+        ABX_REQUIRE(nbh8 * a.S * aa.q_parts < (1LL << 31), "abx_tri_attn_fwd: grid too large");
+        const dim3 grid((unsigned)(nbh8 * a.S * aa.q_parts)), block(TRI_THREADS);
         auto launch = [&](auto kern, size_t lds4) -> int {
             if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds4, "abx_tri_attn_fwd")) return rc;
-            hipLaunchKernelGGL(kern, grid, block, lds4, st, a);
+            hipLaunchKernelGGL(kern, grid, block, lds4, st, aa);
             return abx_check_launch("abx_tri_attn_fwd");
         };
         auto lds_of = [](int kc, bool db) { return (size_t)(db ? 2 : 1) * (6 * kc * RST + kc * sizeof(float)); };
         if (prod) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, true>, lds_of(128, true));
-        if (slots <= 2) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, false>, lds_of(128, true));
-        if (slots <= 4) return launch(&tri_attn4_kernel<4, 128, true, TRI_THREADS, false>, lds_of(128, true));
-        return launch(&tri_attn4_kernel<8, 128, true, TRI_THREADS, false>, lds_of(128, true));
+        return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, false>, lds_of(128, true));
     }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout of the exact kernel (L <= 389)");

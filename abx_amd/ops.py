@@ -355,10 +355,9 @@ def tri_attn_kernel_name(L, exact=None):
     if GEMM_EXACT if exact is None else exact:
         return 'tri_attn_kernel'
     nqt = (L + 15) // 16
-    if (nqt + 10) // 11 <= 2:
-        return 'tri_attn4_kernel<2, 128, true, 768, true>'
-    slots = (nqt + 11) // 12
-    return f'tri_attn4_kernel<{2 if slots <= 2 else 4 if slots <= 4 else 8}, 128, true, 768, false>'
+    parts = (nqt + 23) // 24
+    prod = (nqt + parts - 1) // parts <= 22
+    return f"tri_attn4_kernel<2, 128, true, 768, {'true' if prod else 'false'}>"
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):

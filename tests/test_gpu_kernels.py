@@ -533,6 +533,36 @@ def test_tri_attn_variants_bit_identical(ops, L):
     assert float((outs[0] - oe).abs().max()) < 5e-6 * float(oe.abs().max()) + 5e-6
 
 
+@pytest.mark.parametrize('L,per_row', [(416, True), (560, False), (752, True)])
+def test_tri_attn_long_rows(ops, L, per_row):
+    """Rows with more than 24 query tiles are dealt to several workgroups (AbxTriAttn.q_parts: 416 -> 2 x 13 tiles and 560 -> 2 x 18
+    on the producer-wave variant, 752 -> 2 x 24 on the shared-staging one); no instantiation carries more than two tiles of softmax
+    state per wave, whatever L.  Reference: the same attention in float64 torch ops on the GPU, one head at a time."""
+    B, H, D = 1, 4, 48
+    C = H * D
+    gen = torch.Generator(device=DEV).manual_seed(400 + L)
+    x = torch.randn(B, L, L, 4 * C, device=DEV, generator=gen)
+    biasT = torch.randn(B, H, L, L, device=DEV, generator=gen)             # (b, h, q, k)
+    mask = (torch.rand(B, L, device=DEV, generator=gen) > 0.1)
+    mask[:, 0] = True
+    out = torch.full((B * L * L, C), float('nan'), device=DEV)
+    ops.tri_attn(x.view(B * L * L, 4 * C), biasT, mask.float(), out, B, L, per_row)
+    out = out.view(B, L, L, C)
+    xx = x if per_row else x.transpose(1, 2)
+    got = out if per_row else out.transpose(1, 2)
+    neg = torch.finfo(torch.float32).min
+    worst = 0.0
+    for h in range(H):
+        q, k, v, gt = [xx[0, :, :, j * C + h * D:j * C + (h + 1) * D].double() for j in range(4)]      # (s, l, d)
+        bias_h = biasT[0, h] if per_row else biasT[0, h].t()                  # (the ending-node orientation reads the bias transposed)
+        logits = torch.einsum('sqd,skd->sqk', q, k) * D ** -0.5 + bias_h.double()[None]
+        logits = torch.where(mask[0][None, None, :], logits, torch.full_like(logits, neg))
+        o = torch.einsum('sqk,skd->sqd', torch.softmax(logits, -1), v) * torch.sigmoid(gt)
+        worst = max(worst, float((got[0, :, :, h * D:(h + 1) * D].double() - o).abs().max() / o.abs().max()))
+        del logits, o
+    assert worst < 5e-6, (L, per_row, worst)
+
+
 @pytest.mark.parametrize('exact', [False, True])
 @pytest.mark.parametrize('L,spike', [(80, 70), (200, 190)])
 def test_tri_attn_all_keys_masked_row_and_spike(ops, exact, L, spike):
