@@ -80,39 +80,60 @@ def atom37_to_frames(aatype, pos37, mask37):
             'rigidgroups_group_exists': group_exists}
 
 
-def invert_apply(rots, trans, pts):
-    """R^T (p - t)  ==  invert_rigids then rigids_mul_vecs (r3.py:54-59,18-25)."""
-    return torch.einsum('...dr,...d->...r', rots, pts) - torch.einsum('...dr,...d->...r', rots, trans)
+# The seven torsions of a residue as ONE table of (residue offset, atom37 index) quadruples: rows 0-2 are the backbone torsions
+# pre-omega (CA, C of the previous residue; N, CA), phi (C of the previous residue; N, CA, C) and psi (N, CA, C, O), rows 3-6 the side
+# chain chi angles of the residue type.  A quadruple (a, b, c, d) measures the rotation of d about the b -> c axis, from the a side.
+_BACKBONE_TORSIONS = (((-1, 'CA'), (-1, 'C'), (0, 'N'), (0, 'CA')),
+                      ((-1, 'C'), (0, 'N'), (0, 'CA'), (0, 'C')),
+                      ((0, 'N'), (0, 'CA'), (0, 'C'), (0, 'O')))
+_PSI_SIGN = (1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 1.0)       # the reference stores psi mirrored (geometry.py:196-198)
+
+
+def _torsion_tables(device):
+    """-> atom (21, 7, 4) int64 atom37 slots, prev (7, 4) bool (atom taken from residue l - 1), defined (21, 7) bool, mirror (21, 7)."""
+    key = str(device)
+    if key not in _torsion_tables.cache:
+        chi = torch.as_tensor(rc.chi_angles_atom_indices).long()                                  # (21, 4, 4)
+        bb = torch.tensor([[rc.atom_order[name] for _, name in quad] for quad in _BACKBONE_TORSIONS])
+        atom = torch.cat([bb[None].expand(chi.shape[0], 3, 4), chi], dim=1)
+        prev = torch.tensor([[off < 0 for off, _ in quad] for quad in _BACKBONE_TORSIONS] + [[False] * 4] * 4)
+        defined = torch.cat([torch.ones(chi.shape[0], 3, dtype=torch.bool), torch.as_tensor(rc.chi_angles_mask) > 0], dim=1)
+        mirror = torch.cat([torch.ones(chi.shape[0], 3), 1.0 - 2.0 * torch.as_tensor(rc.chi_pi_periodic).float()], dim=1)
+        _torsion_tables.cache[key] = tuple(t.to(device) for t in (atom, prev, defined, mirror))
+    return _torsion_tables.cache[key]
+
+
+_torsion_tables.cache = {}
+
+
+def dihedral_sin_cos(a, b, c, d):
+    """(sin, cos) of the rotation of d about the axis b -> c, measured from a (..., 3 each): d is expressed in the frame whose
+    origin is c, whose x axis continues b -> c and whose xy plane holds a; its (z, y) coordinates, normalised with the reference's
+    1e-8 under the root, are (sin, cos).  The coordinates are taken as R^T d - R^T c - two rotations, then the difference - because
+    that is the rounding the reference's frame algebra has (geometry.py:176-190) and the goldens are compared at 2e-6."""
+    frame, origin = rigids_from_3_points(b, c, a)                                                 # columns e0, e1, e2
+    local = torch.einsum('...dr,...d->...r', frame, d) - torch.einsum('...dr,...d->...r', frame, origin)
+    zy = local[..., [2, 1]]
+    return zy / torch.sqrt((zy * zy).sum(-1, keepdim=True) + 1e-8)
 
 
 def atom37_to_torsion_angles(aatype, pos, mask):
-    dev = aatype.device
+    """make_torsion_angles (abx/model/features.py:107-115 -> abx/common/geometry.py:115-211): torsion_angles_sin_cos (B, L, 7, 2),
+    the pi-periodic alternative and the mask (all four atoms present and the torsion defined for the residue type; residue 0 has
+    no predecessor: its pre-omega / phi are masked and evaluated on zero coordinates, like the reference's zero padding)."""
     B, L = aatype.shape
+    atom, prev, defined, mirror = _torsion_tables(aatype.device)
     aa = aatype.long()
-    prev_pos = F.pad(pos[:, :-1], [0, 0, 0, 0, 1, 0])
-    prev_mask = F.pad(mask[:, :-1], [0, 0, 1, 0])
-    pre_omega = torch.cat([prev_pos[:, :, 1:3], pos[:, :, 0:2]], dim=-2)
-    phi = torch.cat([prev_pos[:, :, 2:3], pos[:, :, 0:3]], dim=-2)
-    psi = torch.cat([pos[:, :, 0:3], pos[:, :, 4:5]], dim=-2)
-    pre_omega_mask = torch.logical_and(torch.all(prev_mask[:, :, 1:3], dim=-1), torch.all(mask[:, :, 0:2], dim=-1))
-    phi_mask = torch.logical_and(prev_mask[:, :, 2], torch.all(mask[:, :, 0:3], dim=-1))
-    psi_mask = torch.logical_and(torch.all(mask[:, :, 0:3], dim=-1), mask[:, :, 4])
-    atom_idx = _t(rc.chi_angles_atom_indices, dev).long()[aa]                     # (B,L,4,4)
-    chis_pos = gather_rows(pos, atom_idx.reshape(B, L, 16)).reshape(B, L, 4, 4, 3)
-    chis_mask = _t(rc.chi_angles_mask, dev)[aa]
-    chi_atoms_mask = torch.all(gather_rows(mask, atom_idx.reshape(B, L, 16)).reshape(B, L, 4, 4), dim=-1)
-    chis_mask = torch.logical_and(chis_mask, chi_atoms_mask)
-    tors_pos = torch.cat([pre_omega[:, :, None], phi[:, :, None], psi[:, :, None], chis_pos], dim=2)
-    tors_mask = torch.cat([pre_omega_mask[:, :, None], phi_mask[:, :, None], psi_mask[:, :, None], chis_mask], dim=2)
-    rots, trans = rigids_from_3_points(tors_pos[:, :, :, 1], tors_pos[:, :, :, 2], tors_pos[:, :, :, 0])
-    rel = invert_apply(rots, trans, tors_pos[:, :, :, 3])
-    sc = torch.stack([rel[..., 2], rel[..., 1]], dim=-1)
-    sc = sc / torch.sqrt(torch.sum(sc * sc, dim=-1, keepdim=True) + 1e-8)
-    sc = sc * torch.tensor([1.0, 1.0, -1.0, 1.0, 1.0, 1.0, 1.0], device=dev)[..., None]
-    amb = _t(rc.chi_pi_periodic, dev)[aa]
-    mirror = torch.cat([torch.ones([B, L, 3], device=dev), 1.0 - 2.0 * amb], dim=-1)
-    return {'torsion_angles_sin_cos': sc, 'alt_torsion_angles_sin_cos': sc * mirror[..., None],
-            'torsion_angles_mask': tors_mask}
+    slot = atom[aa].reshape(B, L, 28)                                                             # atom37 slot of every torsion atom
+    here = (gather_rows(pos, slot), gather_rows(mask.bool(), slot))
+    before = tuple(F.pad(t[:, :-1], [0, 0] * (t.dim() - 2) + [1, 0]) for t in here)               # the same slots of residue l - 1
+    take_prev = prev.reshape(1, 1, 28)
+    xyz = torch.where(take_prev[..., None], before[0], here[0]).reshape(B, L, 7, 4, 3)
+    present = torch.where(take_prev, before[1], here[1]).reshape(B, L, 7, 4)
+    sc = dihedral_sin_cos(xyz[..., 0, :], xyz[..., 1, :], xyz[..., 2, :], xyz[..., 3, :])
+    sc = sc * torch.tensor(_PSI_SIGN, device=sc.device)[:, None]
+    return {'torsion_angles_sin_cos': sc, 'alt_torsion_angles_sin_cos': sc * mirror[aa][..., None],
+            'torsion_angles_mask': present.all(-1) & defined[aa]}
 
 
 def pseudo_beta_fn(aatype, pos37, mask37):
@@ -161,16 +182,22 @@ def make_diffuser_features(batch, generate_area, diffuser, diff_conf=None, opt_s
         cdrs = sorted(set(anchor_flag[anchor_flag > 0].tolist()))
     else:
         cdrs = [rc.cdr_str_to_enum[generate_area]]
+    # Anchors of a CDR come in (opening, closing) pairs along a row.  Diffused: strictly between them minus the last residue before the
+    # closing anchor (features.py:166: positions opening + 1 ... closing - 2); the structure-loss window runs from one residue before
+    # the opening anchor through the closing one and never takes the last antibody position (features.py:167).
+    Lab_ = anchor_flag.shape[1]
     diffused = torch.zeros_like(batch['mask'], dtype=torch.int32)
     ab_loss_mask = torch.zeros_like(anchor_flag, dtype=torch.int32)
     struc_loss_mask = batch['mask'].to(torch.int32).clone()
     for c in cdrs:
-        idx = torch.nonzero(anchor_flag == c).tolist()
-        for i in range(0, len(idx) - 1, 2):
-            b, right = idx[i]
-            left = idx[i + 1][1]
-            diffused[b, right + 1:left - 1] = 1
-            ab_loss_mask[b, max(right - 1, 0):min(left + 1, diffused.shape[1] - 1)] = 1
+        hit = anchor_flag == c
+        odd = torch.cumsum(hit, dim=1) % 2 == 1                   # from an opening anchor up to (not including) its closing anchor
+        closing, between = hit & ~odd, odd & ~hit
+        before_closing = F.pad(closing[:, 1:], [0, 1])
+        diffused[:, :Lab_] |= (between & ~before_closing).int()
+        span = odd | closing
+        ab_loss_mask |= (span | F.pad(span[:, 1:], [0, 1])).int()
+    ab_loss_mask[:, Lab_ - 1] = 0
     struc_loss_mask[:, :Lab] = ab_loss_mask
     fixed_mask = 1 - diffused
     if opt_step is None:
