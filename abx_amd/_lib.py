@@ -54,6 +54,21 @@ class AbxGemm(C.Structure):
     ]
 
 
+class AbxIpaTail(C.Structure):
+    _fields_ = [
+        ('feat', c_f), ('s_feat', LL),
+        ('s', c_f), ('s_s', LL),
+        ('M', I), ('K1', I), ('C', I),
+        ('W_final', C.c_void_p), ('e_final', I), ('b_final', c_f),
+        ('ln1_w', c_f), ('ln1_b', c_f),
+        ('W_t0', C.c_void_p), ('e_t0', I), ('b_t0', c_f),
+        ('W_t2', C.c_void_p), ('e_t2', I), ('b_t2', c_f),
+        ('W_t4', C.c_void_p), ('e_t4', I), ('b_t4', c_f),
+        ('ln2_w', c_f), ('ln2_b', c_f),
+        ('ln_eps', F),
+    ]
+
+
 class AbxTriAttn(C.Structure):
     _fields_ = [
         ('q', c_f), ('k', c_f), ('v', c_f), ('gate', c_f),
@@ -121,6 +136,7 @@ _PROTOS = {
     'abx_init': (I, [I]),
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
     'abx_split_weights_f16': (I, [c_f, LL, LL, I, I, I, C.c_void_p, _S]),
+    'abx_ipa_tail': (I, [C.POINTER(AbxIpaTail), _S]),
     'abx_gemm3_occupancy': (I, [I]),
     'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),
     'abx_layernorm': (I, [c_f, LL, LL, I, c_f, c_f, F, c_f, LL, c_f, LL, _S]),

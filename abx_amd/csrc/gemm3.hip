@@ -79,13 +79,16 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
 // A row): the fused transition consumes it as the A operand of its second GEMM straight from the registers.
 // STATS: accumulate the inline LayerNorm partial sums and set lshift (the per-row shift of the operand, part of the statistics'
 // meaning); a caller that walks the same A rows again passes STATS = false and the lshift of its first walk.
+// AMODE 3: the A operand is resident in LDS (a_lds: BM fp32 rows of a_lds_stride bytes, k-contiguous; written by the caller before
+// the call): no A stage, no A DMA - the fused IPA tail chains its GEMMs this way.
 template <int BM, int BN, int WM, int WN, int AMODE, bool SWAP = false, bool STATS = true>
 __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, int mt, int nt, int b, f32x16 (&acc)[WM / 32][WN / 32],
-                                               float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32]) {
+                                               float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32],
+                                               const char* a_lds = nullptr, int a_lds_stride = 0) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int A_IMG = AMODE == 2 ? 2 * BM * 32 : BM * 64;                  // bytes per A stage (planes: the two pieces a0, a1)
-    constexpr int NLA = (A_IMG + 4095) / 4096;                                  // DMA instructions per wave per A tile
+    constexpr int A_IMG = AMODE == 3 ? 0 : (AMODE == 2 ? 2 * BM * 32 : BM * 64);   // bytes per A stage (planes: the two pieces a0, a1)
+    constexpr int NLA = AMODE == 3 ? 1 : (A_IMG + 4095) / 4096;                 // DMA instructions per wave per A tile
     constexpr int A_STAGE = A_IMG;
     constexpr int B_IMG = 3 * BN * 32;
     constexpr int NLB = (B_IMG + 4095) / 4096;
@@ -107,9 +110,11 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     // ---- DMA sources: a block-uniform base pointer (advanced per k-tile) plus per-lane 32-bit byte offsets, so the loads
     // use the scalar-base addressing form and cost no vector address arithmetic in the loop
     unsigned offsA[NLA], offsB[NLB];
-    const char* baseA;
-    long long a_step;                                          // bytes per k-tile
-    if constexpr (AMODE == 0) {
+    const char* baseA = nullptr;
+    long long a_step = 0;                                      // bytes per k-tile
+    if constexpr (AMODE == 3) {
+        offsA[0] = 0;
+    } else if constexpr (AMODE == 0) {
         // offsets are relative to the tile's first row (to the batch base when the rows are pair-transposed)
         const bool remap = g.a_pair_transpose > 0 || g.a_pair != 0;
         const long long row0 = remap ? 0 : m0;
@@ -155,6 +160,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     const int nk = g.K / BK;
 
     auto issue_a = [&](int tile) {          // tile index clamped by the caller
+        if constexpr (AMODE == 3) return;
         char* dst = As + (tile % RING) * A_STAGE + wave * NLA * 1024;
         const char* src = baseA + tile * a_step;
 #pragma unroll
@@ -192,11 +198,14 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     wait_vm_and_barrier<0>();
 
     // per-lane LDS fragment offsets
-    int offA[TM][AMODE == 0 ? 2 : 1];
+    int offA[TM][(AMODE == 0 || AMODE == 3) ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + (lane & 31);
-        if constexpr (AMODE == 0) {
+        if constexpr (AMODE == 3) {
+            offA[i][0] = r * a_lds_stride + (2 * h) * 16;
+            offA[i][1] = r * a_lds_stride + (2 * h + 1) * 16;
+        } else if constexpr (AMODE == 0) {
             const int x = (r >> 2) & 3;
             offA[i][0] = r * 64 + (((2 * h) ^ x) << 4);
             offA[i][1] = r * 64 + (((2 * h + 1) ^ x) << 4);
@@ -224,7 +233,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         // next tiles
         issue_b(min(t + 1, nk - 1));
         issue_a(min(t + RING - 1, nk - 1));
-        const char* as = As + (t % RING) * A_STAGE;
+        const char* as = AMODE == 3 ? a_lds + t * 64 : As + (t % RING) * A_STAGE;
         const char* bs = Bs + (t & 1) * B_STAGE;
         u32x4 a[TM][2];
 #pragma unroll
@@ -234,7 +243,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                 for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const u32x4*>(as + offA[i][0] + p * (BM * 32));
             } else {
                 float x[8];
-                if constexpr (AMODE == 0) {
+                if constexpr (AMODE == 0 || AMODE == 3) {
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(as + offA[i][0]);
                     const f32x4 hi = *reinterpret_cast<const f32x4*>(as + offA[i][1]);
 #pragma unroll
@@ -595,6 +604,138 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
     probe.finish();
 }
 
+
+// ---- IPA layer tail (score_network.py:126-163 per layer: the single representation after the attention) in ONE kernel:
+//     s <- LN1(s + feat W_final + b)                                 attention_module.final_proj + attention_layer_norm
+//     s <- LN2(s + relu(relu(s W0 + b0) W2 + b2) W4 + b4)            transition_module.0 / .2 / .4 + transition_layer_norm
+// A block owns 32 rows and all 256 channels: 4 waves x (32 rows x 64 columns), the main loop with swapped MFMA operands (lane = row, 16
+// columns per 32 x 32 tile in registers), so bias / ReLU / residual are lane-local and the LayerNorm statistics need one 32-lane
+// exchange + a 4-wave fold through LDS.  The activations between the GEMMs never leave the CU: each epilogue writes the block's
+// 32 x 256 tile to one of two LDS buffers (1040-byte rows: conflict-free 16-byte fragment reads), which IS the A operand of the next
+// main loop (AMODE 3); only the weight planes stream (DMA, 24 KB per k-tile).  Six launches per layer become one; the arithmetic of a
+// row does not depend on the batch (one instantiation for every size).
+constexpr int IT_C = 256;
+constexpr int IT_ASTR = IT_C * 4 + 16;                                      // bytes per activation row in LDS
+constexpr int IT_OPER = 2 * (32 * 64) + 2 * (3 * IT_C * 32);                // main-loop stages: A 2 x 2 KB + weights 2 x 24 KB
+constexpr int IT_LDS = IT_OPER + 2 * 32 * IT_ASTR + 2 * 4 * 32 * 4;
+
+__global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
+    constexpr int BM = 32, BN = IT_C, WM = 32, WN = 64, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) float it_smem[];
+    char* lds = reinterpret_cast<char*>(it_smem);
+    char* act[2] = {lds + IT_OPER, lds + IT_OPER + 32 * IT_ASTR};
+    float* red = reinterpret_cast<float*>(lds + IT_OPER + 2 * 32 * IT_ASTR);    // [2][4][32]
+    const int mt = blockIdx.x, m0 = mt * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, row = lane & 31;
+    const int grc = min(m0 + row, a.M - 1);
+    // column of accumulator register r of tile j (swapped operands): wave * 64 + j * 32 + 8 (r >> 2) + 4 h + (r & 3)
+    const int colb = wave * WN + 4 * h;
+
+    AbxGemm g = {};
+    g.M = a.M; g.N = IT_C; g.batch = 1; g.b_f16 = 1;
+    g.sB3k = 3 * IT_C * 16; g.sB3p = IT_C * 16; g.sB3n = 16;
+    f32x16 acc[1][TN];
+    float ls[1], lq[1], lsh[1];
+    float x[TN][16];
+
+    // rows of 4 consecutive channels <-> registers 4 q .. 4 q + 3 of tile j
+    auto for_groups = [&](auto&& fn) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fn(j, q, colb + j * 32 + 8 * q);
+    };
+    // LayerNorm over the 256 channels of this lane's row (values in x): two passes like torch, gamma / beta applied in place
+    auto layer_norm = [&](const float* gamma, const float* beta) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += x[j][r];
+        sm += __shfl_xor(sm, 32, 64);
+        if (h == 0) red[wave * 32 + row] = sm;
+        __syncthreads();
+        const float mean = (red[row] + red[32 + row] + red[64 + row] + red[96 + row]) * (1.0f / IT_C);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[j][r] -= mean; sq = fmaf(x[j][r], x[j][r], sq); }
+        sq += __shfl_xor(sq, 32, 64);
+        if (h == 0) red[128 + wave * 32 + row] = sq;
+        __syncthreads();
+        const float var = (red[128 + row] + red[160 + row] + red[192 + row] + red[224 + row]) * (1.0f / IT_C);
+        const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+        for_groups([&](int j, int q, int c) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[j][4 * q + e] = x[j][4 * q + e] * rstd * gm[e] + bt[e];
+        });
+    };
+    auto to_lds = [&](char* buf) {
+        for_groups([&](int j, int q, int c) {
+            *reinterpret_cast<f32x4*>(buf + row * IT_ASTR + c * 4) = (f32x4){x[j][4 * q], x[j][4 * q + 1], x[j][4 * q + 2], x[j][4 * q + 3]};
+        });
+    };
+    auto bias_act = [&](const float* bias, bool relu) {
+        for_groups([&](int j, int q, int c) {
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[0][j][4 * q + e] + bi[e];
+                x[j][4 * q + e] = relu ? fmaxf(v, 0.f) : v;
+            }
+        });
+    };
+
+    // ---- 1: s + feat W_final + b -> LN1 -> act[0] (and kept in registers: the residual of the transition)
+    g.A = a.feat; g.sAm = a.s_feat; g.sAk = 1; g.K = a.K1;
+    g.B_split = a.W_final; g.b_exp = a.e_final;
+    gemm3_mainloop<BM, BN, WM, WN, 0, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh);
+    bias_act(a.b_final, false);
+    for_groups([&](int j, int q, int c) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(a.s + (long long)grc * a.s_s + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[j][4 * q + e] += rv[e];
+    });
+    layer_norm(a.ln1_w, a.ln1_b);
+    float res[TN][16];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[j][r] = x[j][r];
+    to_lds(act[0]);
+    __syncthreads();
+    // ---- 2, 3: relu(. W0 + b0) -> act[1], relu(. W2 + b2) -> act[0]
+    g.K = IT_C;
+    g.B_split = a.W_t0; g.b_exp = a.e_t0;
+    gemm3_mainloop<BM, BN, WM, WN, 3, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[0], IT_ASTR);
+    bias_act(a.b_t0, true);
+    to_lds(act[1]);
+    __syncthreads();
+    g.B_split = a.W_t2; g.b_exp = a.e_t2;
+    gemm3_mainloop<BM, BN, WM, WN, 3, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[1], IT_ASTR);
+    bias_act(a.b_t2, true);
+    to_lds(act[0]);
+    __syncthreads();
+    // ---- 4: residual + . W4 + b4 -> LN2 -> act[1] -> the rows of s, coalesced
+    g.B_split = a.W_t4; g.b_exp = a.e_t4;
+    gemm3_mainloop<BM, BN, WM, WN, 3, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[0], IT_ASTR);
+    bias_act(a.b_t4, false);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[j][r] += res[j][r];
+    layer_norm(a.ln2_w, a.ln2_b);
+    to_lds(act[1]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BM * (IT_C / 4); idx += 256) {
+        const int r = idx / (IT_C / 4), c4 = idx % (IT_C / 4);
+        if (m0 + r < a.M)
+            *reinterpret_cast<f32x4*>(a.s + (long long)(m0 + r) * a.s_s + c4 * 4) = *reinterpret_cast<const f32x4*>(act[1] + r * IT_ASTR + c4 * 16);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch3(const AbxGemm& g, hipStream_t st) {
     const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
@@ -754,4 +895,21 @@ extern "C" int abx_split_weights_f16(const float* w, long long s_n, long long s_
     hipLaunchKernelGGL(split_weights_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, s_n, s_k, N, K, Kp,
                        ldexpf(1.0f, scale_exp), out);
     return abx_check_launch("abx_split_weights_f16");
+}
+
+extern "C" int abx_ipa_tail(const AbxIpaTail* ap, hipStream_t st) {
+    ABX_REQUIRE(ap != nullptr, "abx_ipa_tail: null descriptor");
+    const AbxIpaTail a = *ap;
+    auto al16 = [](const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    ABX_REQUIRE(a.M > 0 && a.K1 > 0 && a.K1 % 16 == 0 && a.C == IT_C, "abx_ipa_tail: M > 0, K1 % 16 == 0, C == 256");
+    ABX_REQUIRE(al16(a.feat) && al16(a.s) && a.s_feat % 4 == 0 && a.s_s % 4 == 0 && a.s_feat >= a.K1 && a.s_s >= IT_C,
+                "abx_ipa_tail: feat / s must be 16-byte aligned rows");
+    ABX_REQUIRE(32LL * a.s_feat < (1LL << 28), "abx_ipa_tail: feature rows too long");
+    ABX_REQUIRE(al16(a.W_final) && al16(a.W_t0) && al16(a.W_t2) && al16(a.W_t4), "abx_ipa_tail: weight planes (abx_split_weights_f16)");
+    ABX_REQUIRE(al16(a.b_final) && al16(a.b_t0) && al16(a.b_t2) && al16(a.b_t4) && al16(a.ln1_w) && al16(a.ln1_b) && al16(a.ln2_w) && al16(a.ln2_b),
+                "abx_ipa_tail: biases and LayerNorm parameters ([256], 16-byte aligned)");
+    for (int e : {a.e_final, a.e_t0, a.e_t2, a.e_t4}) ABX_REQUIRE(e >= -100 && e <= 100, "abx_ipa_tail: weight exponent out of range");
+    if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&ipa_tail_kernel), IT_LDS, "abx_ipa_tail")) return rc;
+    hipLaunchKernelGGL(ipa_tail_kernel, dim3((unsigned)((a.M + 31) / 32)), dim3(256), IT_LDS, st, a);
+    return abx_check_launch("abx_ipa_tail");
 }

@@ -427,17 +427,27 @@ class Engine:
         ifeat = ws.get('i_feat', (M1, 2112))
         h1 = ws.get('i_h1', (M1, NC)); h2 = ws.get('i_h2', (M1, NC))
         upd = ws.get('i_upd', (M1, 6))
+        tail = None
+        if P.gemm_mode == 2 and NC == 256:
+            wb = lambda n: (P.split(P_IPA + n), P.b[P_IPA + n])
+            tail = (wb('attention_module.final_proj'), P.ln(P_IPA + 'attention_layer_norm'), wb('transition_module.0'),
+                    wb('transition_module.2'), wb('transition_module.4'), P.ln(P_IPA + 'transition_layer_norm'))
         for _ in range(ic.num_layer):
             _lin(P, P_IPA + 'attention_module.proj', s, proj)
             ops.ipa_pack(proj, cur_R, cur_t, qpack, kpack, vpack, Bc, L, P.ipa_ws)
             ops.ipa_weights(qpack, kpack, vpack, bias2d, mask_f, cur_R, cur_t, P.ipa_pw, attn_ws, ifeat, Bc, L)
             ops.ipa_pair(attn_ws, zi, ifeat, Bc, L)
-            _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)
-            ops.layernorm(s, *P.ln(P_IPA + 'attention_layer_norm'), out=s)
-            _lin(P, P_IPA + 'transition_module.0', s, h1, act=1)
-            _lin(P, P_IPA + 'transition_module.2', h1, h2, act=1)
-            _lin(P, P_IPA + 'transition_module.4', h2, s, resid=s)
-            ops.layernorm(s, *P.ln(P_IPA + 'transition_layer_norm'), out=s)
+            if tail is not None:
+                # final_proj + residual + LayerNorm + the three-layer transition + residual + LayerNorm: one launch, the 256-wide
+                # activations stay on the CU (six launches otherwise)
+                ops.ipa_tail(ifeat, s, *tail)
+            else:
+                _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)
+                ops.layernorm(s, *P.ln(P_IPA + 'attention_layer_norm'), out=s)
+                _lin(P, P_IPA + 'transition_module.0', s, h1, act=1)
+                _lin(P, P_IPA + 'transition_module.2', h1, h2, act=1)
+                _lin(P, P_IPA + 'transition_module.4', h2, s, resid=s)
+                ops.layernorm(s, *P.ln(P_IPA + 'transition_layer_norm'), out=s)
             _lin(P, P_IPA + 'affine_update', s, upd)
             ops.rigid_update(upd, fixed.reshape(-1), init_q, init_t, cur_q, cur_t, cur_R, delta_q, M1, ic.position_scale)
         # torsions (sidechain.py:28-72)

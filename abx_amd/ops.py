@@ -6,7 +6,7 @@ import math
 import torch
 
 from abx_amd import _lib
-from abx_amd._lib import AbxGemm, AbxTriAttn, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, check
+from abx_amd._lib import AbxGemm, AbxTriAttn, AbxIpaTail, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, check
 
 
 def _stream():
@@ -412,6 +412,24 @@ def ipa_weights(qpack, kpack, vpack, bias2d, mask, rots, trans, pw, attn_ws, fea
 def ipa_pair(attn_ws, z, feat, B, L):
     """Second launch: attention over the pair slab z (B*L*L, 128) -> feat[:, 576:]."""
     check(_lib.load().abx_ipa_pair(_p(attn_ws), _p(z), _p(feat), B, L, _stream()), 'abx_ipa_pair')
+
+
+def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5):
+    """The tail of an IPA layer in one launch (csrc/gemm3.hip ipa_tail_kernel; reference score_network.py:126-163):
+    s <- LN1(s + feat @ W_final + b_final);  s <- LN2(s + relu(relu(s @ W0 + b0) @ W2 + b2) @ W4 + b4), in place.
+    feat (M, K1) and s (M, 256) fp32 rows; w_* = (WeightPlanes of the (K, 256) weight, bias (256)); ln* = (gamma, beta)."""
+    M, K1 = feat.shape
+    assert s.shape == (M, 256) and feat.stride(1) == 1 and s.stride(1) == 1 and K1 % 16 == 0
+    a = AbxIpaTail()
+    a.feat, a.s_feat, a.s, a.s_s, a.M, a.K1, a.C = _p(_f32(feat)), feat.stride(0), _p(_f32(s)), s.stride(0), M, K1, 256
+    for tag, (w3, bias), K in (('final', w_final, K1), ('t0', w_t0, 256), ('t2', w_t2, 256), ('t4', w_t4, 256)):
+        _weight_planes(w3, 256, K, what='ipa_tail ' + tag)
+        assert w3.shape[0] * 16 == K and bias.numel() == 256
+        setattr(a, 'W_' + tag, _p(w3)); setattr(a, 'e_' + tag, w3.w_exp); setattr(a, 'b_' + tag, _p(_f32(bias)))
+    a.ln1_w, a.ln1_b, a.ln2_w, a.ln2_b = _p(_f32(ln1[0])), _p(_f32(ln1[1])), _p(_f32(ln2[0])), _p(_f32(ln2[1]))
+    a.ln_eps = float(eps)
+    check(_lib.load().abx_ipa_tail(C.byref(a), _stream()), 'abx_ipa_tail')
+    return s
 
 
 def ipa_qpack_numel(B, L):

@@ -97,6 +97,9 @@ class OpTimer:
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
             return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
+        if name == 'ipa_tail':
+            M, K1 = args[0].shape
+            return 'ipa_tail_kernel', 2.0 * M * 256 * (K1 + 3 * 256), 4.0 * M * (K1 + 2 * 256) + 6.0 * 256 * (K1 + 3 * 256)
         if name == 'ipa_attn':
             Bc, L = args[10], args[11]
             return 'ipa_attn (weights + pair slab kernels)', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12 + 24)
@@ -514,7 +517,7 @@ def main():
         tot_ms = sum(s[1] for s in summ)
         name, ms, calls, fl, by = summ[0]
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
-        if name.startswith('ipa_'):
+        if name.startswith('ipa_') and name != 'ipa_tail_kernel':
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
         elif name.startswith('gemm3_') or name.startswith('tri_attn3') or name.startswith('tri_attn4'):
             # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs three f16 MFMA

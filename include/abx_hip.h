@@ -141,6 +141,24 @@ int abx_gemm(const AbxGemm* desc, hipStream_t stream);
 /* fp32 weights W[n][k] -> out[Kp/16][3][N][16] float16 planes of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
  * scale_exp = 14 - e with max|w| = m * 2^e, 0.5 <= m < 1 (so that max|w| * 2^scale_exp is in [2^13, 2^14)) */
 int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out, hipStream_t stream);
+/* The tail of an IPA layer on the single representation s (M = B*L rows of C = 256 channels), reference score_network.py:126-163 /
+ * folding.py (per layer, after the attention): s <- LN1(s + feat W_final + b_final); s <- LN2(s + relu(relu(s W0 + b0) W2 + b2) W4 + b4)
+ * (attention_module.final_proj + attention_layer_norm + transition_module.0/.2/.4 + transition_layer_norm) in ONE launch: the
+ * intermediate activations never leave the CU (split-f16 arithmetic of AbxGemm; weights as abx_split_weights_f16 planes
+ * [K/16][3][256][16] with their exponents).  s is updated in place. */
+typedef struct AbxIpaTail {
+    const float* feat; long long s_feat;           /* IPA features (M, K1), row stride in floats (K1 % 16 == 0) */
+    float* s; long long s_s;                       /* (M, 256) in / out */
+    int M, K1, C;                                  /* C must be 256 */
+    const unsigned short* W_final; int e_final; const float* b_final;
+    const float* ln1_w; const float* ln1_b;
+    const unsigned short* W_t0; int e_t0; const float* b_t0;
+    const unsigned short* W_t2; int e_t2; const float* b_t2;
+    const unsigned short* W_t4; int e_t4; const float* b_t4;
+    const float* ln2_w; const float* ln2_b;
+    float ln_eps;
+} AbxIpaTail;
+int abx_ipa_tail(const AbxIpaTail* desc, hipStream_t stream);
 /* diagnostics: resident workgroups per CU of the main split-f16 GEMM instantiations (0: 128x192, 1: 128x128,
  * 2: 128x128 transposed store, 3: 128x192 plane operands); negative on error */
 int abx_gemm3_occupancy(int which);

@@ -583,6 +583,39 @@ def test_tri_attn_all_keys_masked_row_and_spike(ops, exact, L, spike):
         check(out.view(B, L, L, C), o, 5e-6, f'tri_attn mask all={bool(mask.all())}')
 
 
+@pytest.mark.parametrize('M', [352, 4224 + 5, 31])
+def test_ipa_tail(ops, M):
+    """abx_ipa_tail: final_proj + residual + LayerNorm + the three-layer transition + residual + LayerNorm of an IPA layer in one launch
+    (reference score_network.py:126-163) against float64, and against the same chain as six launches (the path it replaces)."""
+    K1, Cc = 2112, 256
+    gen = lambda i: g(500 + i)
+    feat = torch.randn(M, K1, generator=gen(0)) * 1.5
+    s0 = torch.randn(M, Cc, generator=gen(1))
+    Wf = torch.randn(K1, Cc, generator=gen(2)) / K1 ** 0.5; W0 = torch.randn(Cc, Cc, generator=gen(3)) / 16
+    W2 = torch.randn(Cc, Cc, generator=gen(4)) / 16; W4 = torch.randn(Cc, Cc, generator=gen(5)) / 16
+    bs = [torch.randn(Cc, generator=gen(6 + i)) * 0.3 for i in range(4)]
+    ln = [(1 + 0.2 * torch.randn(Cc, generator=gen(10 + i)), 0.2 * torch.randn(Cc, generator=gen(12 + i))) for i in range(2)]
+    d = lambda t: t.to(DEV).contiguous()
+    LN = lambda x, p: torch.nn.functional.layer_norm(x, (Cc,), p[0].double(), p[1].double(), 1e-5)
+    x = LN(s0.double() + feat.double() @ Wf.double() + bs[0].double(), ln[0])
+    hdn = torch.relu(torch.relu(x @ W0.double() + bs[1].double()) @ W2.double() + bs[2].double())
+    ref = LN(x + hdn @ W4.double() + bs[3].double(), ln[1])
+    featd, sd = d(feat), d(s0)
+    wd = [(ops.split_weights(d(W)), d(b)) for W, b in zip((Wf, W0, W2, W4), bs)]
+    lnd = [(d(a), d(b)) for a, b in ln]
+    ops.ipa_tail(featd, sd, wd[0], lnd[0], wd[1], wd[2], wd[3], lnd[1])
+    check(sd, ref, 5e-6, f'ipa_tail M={M}')
+    # the six-launch path on the same split-f16 GEMM kernels
+    s6, h1, h2 = d(s0), torch.empty(M, Cc, device=DEV), torch.empty(M, Cc, device=DEV)
+    ops.gemm(featd, d(Wf), s6, bias=wd[0][1], B3=wd[0][0], resid=s6, exact=2)
+    ops.layernorm(s6, *lnd[0], out=s6)
+    ops.gemm(s6, d(W0), h1, bias=wd[1][1], B3=wd[1][0], act=1, exact=2)
+    ops.gemm(h1, d(W2), h2, bias=wd[2][1], B3=wd[2][0], act=1, exact=2)
+    ops.gemm(h2, d(W4), s6, bias=wd[3][1], B3=wd[3][0], resid=s6, exact=2)
+    ops.layernorm(s6, *lnd[1], out=s6)
+    assert float((sd - s6).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize('L', [52, 131, 230, 402, 600])
 def test_seq_attn(ops, L):
     """L = 52: one key per lane slot, partial; 131: three key slots (4-slot instantiation), one query block; 230: two query

@@ -54,7 +54,7 @@ def test_argument_checks_return_codes_without_gpu(lib):
 def test_ctypes_structs_match_c_layout():
     from abx_amd import _lib
     structs = {'AbxGemm': _lib.AbxGemm, 'AbxTriAttn': _lib.AbxTriAttn, 'AbxScoreArgs': _lib.AbxScoreArgs,
-               'AbxReverseArgs': _lib.AbxReverseArgs, 'AbxGuidanceArgs': _lib.AbxGuidanceArgs}
+               'AbxReverseArgs': _lib.AbxReverseArgs, 'AbxGuidanceArgs': _lib.AbxGuidanceArgs, 'AbxIpaTail': _lib.AbxIpaTail}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(){']
     for name, st in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
