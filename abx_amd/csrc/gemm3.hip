@@ -81,7 +81,7 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
 // meaning); a caller that walks the same A rows again passes STATS = false and the lshift of its first walk.
 // AMODE 3: the A operand is resident in LDS (a_lds: BM fp32 rows of a_lds_stride bytes, k-contiguous; written by the caller before
 // the call): no A stage, no A DMA - the fused IPA tail chains its GEMMs this way.
-template <int BM, int BN, int WM, int WN, int AMODE, bool SWAP = false, bool STATS = true>
+template <int BM, int BN, int WM, int WN, int AMODE, bool SWAP = false, bool STATS = true, int RING = 2>
 __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, int mt, int nt, int b, f32x16 (&acc)[WM / 32][WN / 32],
                                                float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32],
                                                const char* a_lds = nullptr, int a_lds_stride = 0) {
@@ -89,19 +89,23 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     constexpr int WAVES_N = BN / WN;
     constexpr int A_IMG = AMODE == 3 ? 0 : (AMODE == 2 ? 2 * BM * 32 : BM * 64);   // bytes per A stage (planes: the two pieces a0, a1)
     constexpr int NLA = AMODE == 3 ? 1 : (A_IMG + 4095) / 4096;                 // DMA instructions per wave per A tile
-    constexpr int A_STAGE = A_IMG;
+    constexpr int A_STAGE = RING == 2 ? A_IMG : (A_IMG + 4095) / 4096 * 4096;
     constexpr int B_IMG = 3 * BN * 32;
     constexpr int NLB = (B_IMG + 4095) / 4096;
     // with counted waits every wave must issue the same number of DMA instructions (stage padded to 4 KB multiples); the
     // 2-stage protocol waits for everything, so the surplus chunks are simply skipped and the stage is the bare image
     constexpr int B_STAGE = B_IMG;
-    // Two stages per operand: tile t + 1 is fetched (DMA) while tile t is consumed and waited for at the end of the step.  A
-    // deeper ring (one tile in flight across the barrier, counted vmcnt) was measured slower: with K <= 192 the fixed
-    // per-tile latencies (dispatch, first DMA, epilogue) weigh more than pipeline depth, and the smaller LDS footprint buys a
-    // third / fourth resident block per CU (40 KB with 128x128 tiles, 52 KB with 128x192) that hides them.
-    constexpr int RING = 2;
+    // RING stages per operand: tile t + RING - 1 is fetched (DMA) while tile t is consumed.  RING = 2 (tile t + 1 waited for at the
+    // end of step t) for the pair-stack GEMMs: with K <= 192 the fixed per-tile latencies (dispatch, first DMA, epilogue) weigh more
+    // than pipeline depth, and the smaller LDS footprint buys a third / fourth resident block per CU (40 KB with 128x128 tiles, 52 KB
+    // with 128x192) that hides them.  RING = 3 where ONE block owns the CU anyway (the IPA tail: 180 k-steps per block and nothing
+    // else to hide a DMA round trip): two tiles in flight, counted waits (vmcnt: results return in issue order, so every wave must
+    // issue the same NI instructions per tile - a stage is then padded to 4 KB and the surplus chunk loads rows nobody reads).
+    constexpr int NI = (AMODE == 3 ? 0 : NLA) + NLB;
+    constexpr int INFLIGHT = (RING - 2) * NI;                  // DMA instructions of this wave allowed to be outstanding at a wait
+    static_assert(RING == 2 || B_IMG % 4096 == 0, "counted waits: uniform DMA instruction counts per wave");
     char* As = reinterpret_cast<char*>(smem);                 // RING stages
-    char* Bs = As + RING * A_STAGE;                           // 2 stages
+    char* Bs = As + RING * A_STAGE;                           // RING stages
     const int m0 = mt * BM, n0 = nt * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -165,10 +169,10 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         const char* src = baseA + tile * a_step;
 #pragma unroll
         for (int i = 0; i < NLA; ++i)
-            if (A_IMG % 4096 == 0 || (wave * NLA + i) * 1024 < A_IMG) glds16(src + offsA[i], dst + i * 1024);
+            if (RING > 2 || A_IMG % 4096 == 0 || (wave * NLA + i) * 1024 < A_IMG) glds16(src + offsA[i], dst + i * 1024);
     };
     auto issue_b = [&](int tile) {
-        char* dst = Bs + (tile & 1) * B_STAGE + wave * NLB * 1024;
+        char* dst = Bs + (tile % RING) * B_STAGE + wave * NLB * 1024;
         const char* src = baseB + tile * b_step;
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
@@ -193,9 +197,12 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     }
 
     // prologue
-    issue_a(0);
-    issue_b(0);
-    wait_vm_and_barrier<0>();
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r) {
+        issue_a(min(r, nk - 1));
+        issue_b(min(r, nk - 1));
+    }
+    wait_vm_and_barrier<INFLIGHT>();
 
     // per-lane LDS fragment offsets
     int offA[TM][(AMODE == 0 || AMODE == 3) ? 2 : 1];
@@ -224,17 +231,17 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     const bool rows_live = m0 + wm * WM < g.M;
     if (!rows_live) {
         for (int t = 0; t < nk; ++t) {
-            issue_b(min(t + 1, nk - 1));
+            issue_b(min(t + RING - 1, nk - 1));
             issue_a(min(t + RING - 1, nk - 1));
-            wait_vm_and_barrier<0>();
+            wait_vm_and_barrier<INFLIGHT>();
         }
     } else
     for (int t = 0; t < nk; ++t) {
         // next tiles
-        issue_b(min(t + 1, nk - 1));
+        issue_b(min(t + RING - 1, nk - 1));
         issue_a(min(t + RING - 1, nk - 1));
         const char* as = AMODE == 3 ? a_lds + t * 64 : As + (t % RING) * A_STAGE;
-        const char* bs = Bs + (t & 1) * B_STAGE;
+        const char* bs = Bs + (t % RING) * B_STAGE;
         u32x4 a[TM][2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -301,7 +308,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                         acc[i][j0 + j] = SWAP ? mfma_split(bb[j][T::B[term]], a[i][T::A[term]], acc[i][j0 + j])
                                               : mfma_split(a[i][T::A[term]], bb[j][T::B[term]], acc[i][j0 + j]);
         }
-        wait_vm_and_barrier<0>();
+        wait_vm_and_barrier<INFLIGHT>();
     }
     if constexpr (AMODE != 2) {
         // the planes hold w * 2^b_exp, the activations went in as x * 2^ABX_F16_A_EXP: exact power-of-two rescale
@@ -616,7 +623,8 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
 // row does not depend on the batch (one instantiation for every size).
 constexpr int IT_C = 256;
 constexpr int IT_ASTR = IT_C * 4 + 16;                                      // bytes per activation row in LDS
-constexpr int IT_OPER = 2 * (32 * 64) + 2 * (3 * IT_C * 32);                // main-loop stages: A 2 x 2 KB + weights 2 x 24 KB
+constexpr int IT_RING = 3;
+constexpr int IT_OPER = IT_RING * (4096 + 3 * IT_C * 32);                   // main-loop stages: A 3 x 4 KB (padded) + weights 3 x 24 KB
 constexpr int IT_LDS = IT_OPER + 2 * 32 * IT_ASTR + 2 * 4 * 32 * 4;
 
 __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
     // ---- 1: s + feat W_final + b -> LN1 -> act[0] (and kept in registers: the residual of the transition)
     g.A = a.feat; g.sAm = a.s_feat; g.sAk = 1; g.K = a.K1;
     g.B_split = a.W_final; g.b_exp = a.e_final;
-    gemm3_mainloop<BM, BN, WM, WN, 0, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh);
+    gemm3_mainloop<BM, BN, WM, WN, 0, true, false, IT_RING>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh);
     bias_act(a.b_final, false);
     for_groups([&](int j, int q, int c) {
         const f32x4 rv = *reinterpret_cast<const f32x4*>(a.s + (long long)grc * a.s_s + c);
@@ -709,18 +717,18 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
     // ---- 2, 3: relu(. W0 + b0) -> act[1], relu(. W2 + b2) -> act[0]
     g.K = IT_C;
     g.B_split = a.W_t0; g.b_exp = a.e_t0;
-    gemm3_mainloop<BM, BN, WM, WN, 3, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[0], IT_ASTR);
+    gemm3_mainloop<BM, BN, WM, WN, 3, true, false, IT_RING>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[0], IT_ASTR);
     bias_act(a.b_t0, true);
     to_lds(act[1]);
     __syncthreads();
     g.B_split = a.W_t2; g.b_exp = a.e_t2;
-    gemm3_mainloop<BM, BN, WM, WN, 3, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[1], IT_ASTR);
+    gemm3_mainloop<BM, BN, WM, WN, 3, true, false, IT_RING>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[1], IT_ASTR);
     bias_act(a.b_t2, true);
     to_lds(act[0]);
     __syncthreads();
     // ---- 4: residual + . W4 + b4 -> LN2 -> act[1] -> the rows of s, coalesced
     g.B_split = a.W_t4; g.b_exp = a.e_t4;
-    gemm3_mainloop<BM, BN, WM, WN, 3, true, false>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[0], IT_ASTR);
+    gemm3_mainloop<BM, BN, WM, WN, 3, true, false, IT_RING>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh, act[0], IT_ASTR);
     bias_act(a.b_t4, false);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
