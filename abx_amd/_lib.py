@@ -81,7 +81,7 @@ class AbxTriAttn(C.Structure):
         ('exact', I),
         ('clock_probe', c_f),
         ('tune', I),
-        ('q_parts', I),
+        ('q_parts', I), ('row_groups', I),
     ]
 
 

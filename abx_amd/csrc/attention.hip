@@ -293,10 +293,14 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     // ---- (b, h, s) of this workgroup: XCD x (blockIdx & 7) owns the (b, h) pairs x, x + 8, ... and walks their rows in order
     // Long rows: the query tiles of a row are dealt to q_parts workgroups (each stages all keys of the row; neighbours in the grid, so
     // the row's K / V come from the L2 the second time): a wave never carries more than MAXQ tiles of online-softmax state.
+    // When B * H is not a multiple of 8 (one sample: 4 pairs - half of the XCDs would idle) the rows of every pair are dealt to
+    // row_groups = 2 virtual pairs (even / odd rows), which always gives a multiple of 8 with H = 4.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_bh = a.S * a.q_parts, sp = slot % per_bh;
-    const int bh = (slot / per_bh) * 8 + xcd, s = sp / a.q_parts, part = sp % a.q_parts;
-    if (bh >= a.B * a.H) return;
+    const int G = a.row_groups, rows_g = (a.S + G - 1) / G;
+    const int per_vp = rows_g * a.q_parts, sp = slot % per_vp;
+    const int vp = (slot / per_vp) * 8 + xcd;
+    const int bh = vp / G, s = (sp / a.q_parts) * G + vp % G, part = sp % a.q_parts;
+    if (bh >= a.B * a.H || s >= a.S) return;
     const ClockProbe probe(a.clock_probe);
     const int b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -767,9 +771,10 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         aa.q_parts = (nqt + 2 * nw - 1) / (2 * nw);
         const int tpp = (nqt + aa.q_parts - 1) / aa.q_parts;
         const bool prod = tpp <= 2 * (nw - 1) && !(a.tune & 1);
-        const long long nbh8 = ((long long)a.B * a.H + 7) / 8 * 8;
-        ABX_REQUIRE(nbh8 * a.S * aa.q_parts < (1LL << 31), "abx_tri_attn_fwd: grid too large");
-        const dim3 grid((unsigned)(nbh8 * a.S * aa.q_parts)), block(TRI_THREADS);
+        aa.row_groups = ((long long)a.B * a.H) % 8 == 0 ? 1 : 2;
+        const long long nvp8 = ((long long)a.B * a.H * aa.row_groups + 7) / 8 * 8, rows_g = (a.S + aa.row_groups - 1) / aa.row_groups;
+        ABX_REQUIRE(nvp8 * rows_g * aa.q_parts < (1LL << 31), "abx_tri_attn_fwd: grid too large");
+        const dim3 grid((unsigned)(nvp8 * rows_g * aa.q_parts)), block(TRI_THREADS);
         auto launch = [&](auto kern, size_t lds4) -> int {
             if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds4, "abx_tri_attn_fwd")) return rc;
             hipLaunchKernelGGL(kern, grid, block, lds4, st, aa);

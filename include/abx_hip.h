@@ -191,7 +191,7 @@ typedef struct AbxTriAttn {
     unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernel) */
     int tune;                                       /* 0 = library default; bit 0: never the producer-wave variant (benchmarking;
                                                        all variants give bit-identical results) */
-    int q_parts;                                    /* filled by the library */
+    int q_parts, row_groups;                        /* filled by the library */
 } AbxTriAttn;
 int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);
 
