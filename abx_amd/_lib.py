@@ -66,6 +66,9 @@ class AbxIpaTail(C.Structure):
         ('W_t4', C.c_void_p), ('e_t4', I), ('b_t4', c_f),
         ('ln2_w', c_f), ('ln2_b', c_f),
         ('ln_eps', F),
+        ('W_aff', c_f), ('b_aff', c_f),
+        ('fixed', c_f), ('init_q', c_f), ('init_t', c_f),
+        ('cur_q', c_f), ('cur_t', c_f), ('cur_R', c_f), ('delta_q', c_f), ('pscale', F),
     ]
 
 

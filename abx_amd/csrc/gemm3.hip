@@ -28,6 +28,7 @@
 #include "common.h"
 #include "abx_hip.h"
 #include "gemm_epilogue.h"
+#include "rigid_dev.h"
 
 namespace {
 
@@ -742,6 +743,20 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
         if (m0 + r < a.M)
             *reinterpret_cast<f32x4*>(a.s + (long long)(m0 + r) * a.s_s + c4 * 4) = *reinterpret_cast<const f32x4*>(act[1] + r * IT_ASTR + c4 * 16);
     }
+    // ---- 5 (optional): affine_update (256 -> 6, fp32 FMA chain in channel order) and the frame update of the block's residues
+    if (a.W_aff) {
+        const int r = threadIdx.x >> 3, o = threadIdx.x & 7;
+        if (o < 6) {
+            const float* y = reinterpret_cast<const float*>(act[1] + r * IT_ASTR);
+            float u = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < IT_C; ++c) u = fmaf(y[c], a.W_aff[c * 6 + o], u);
+            red[r * 8 + o] = u + a.b_aff[o];
+        }
+        __syncthreads();
+        if (threadIdx.x < BM && m0 + threadIdx.x < a.M)
+            rigid_update_row(m0 + threadIdx.x, red + threadIdx.x * 8, a.fixed, a.init_q, a.init_t, a.cur_q, a.cur_t, a.cur_R, a.delta_q, a.pscale);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int MINW>
@@ -917,6 +932,8 @@ extern "C" int abx_ipa_tail(const AbxIpaTail* ap, hipStream_t st) {
     ABX_REQUIRE(al16(a.b_final) && al16(a.b_t0) && al16(a.b_t2) && al16(a.b_t4) && al16(a.ln1_w) && al16(a.ln1_b) && al16(a.ln2_w) && al16(a.ln2_b),
                 "abx_ipa_tail: biases and LayerNorm parameters ([256], 16-byte aligned)");
     for (int e : {a.e_final, a.e_t0, a.e_t2, a.e_t4}) ABX_REQUIRE(e >= -100 && e <= 100, "abx_ipa_tail: weight exponent out of range");
+    ABX_REQUIRE(!a.W_aff || (a.b_aff && a.fixed && a.init_q && a.init_t && a.cur_q && a.cur_t && a.cur_R && a.delta_q && a.pscale != 0.f),
+                "abx_ipa_tail: the affine / frame update needs all of its operands");
     if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&ipa_tail_kernel), IT_LDS, "abx_ipa_tail")) return rc;
     hipLaunchKernelGGL(ipa_tail_kernel, dim3((unsigned)((a.M + 31) / 32)), dim3(256), IT_LDS, st, a);
     return abx_check_launch("abx_ipa_tail");

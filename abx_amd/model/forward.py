@@ -438,9 +438,11 @@ class Engine:
             ops.ipa_weights(qpack, kpack, vpack, bias2d, mask_f, cur_R, cur_t, P.ipa_pw, attn_ws, ifeat, Bc, L)
             ops.ipa_pair(attn_ws, zi, ifeat, Bc, L)
             if tail is not None:
-                # final_proj + residual + LayerNorm + the three-layer transition + residual + LayerNorm: one launch, the 256-wide
-                # activations stay on the CU (six launches otherwise)
-                ops.ipa_tail(ifeat, s, *tail)
+                # final_proj + residual + LayerNorm + the three-layer transition + residual + LayerNorm + affine_update + frame update:
+                # one launch, the 256-wide activations stay on the CU (eight launches otherwise)
+                ops.ipa_tail(ifeat, s, *tail, affine=(P.wt[P_IPA + 'affine_update'], P.b[P_IPA + 'affine_update']),
+                             rigid=(fixed.reshape(-1), init_q, init_t, cur_q, cur_t, cur_R, delta_q, ic.position_scale))
+                continue
             else:
                 _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)
                 ops.layernorm(s, *P.ln(P_IPA + 'attention_layer_norm'), out=s)

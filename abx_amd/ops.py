@@ -414,10 +414,12 @@ def ipa_pair(attn_ws, z, feat, B, L):
     check(_lib.load().abx_ipa_pair(_p(attn_ws), _p(z), _p(feat), B, L, _stream()), 'abx_ipa_pair')
 
 
-def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5):
+def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5, affine=None, rigid=None):
     """The tail of an IPA layer in one launch (csrc/gemm3.hip ipa_tail_kernel; reference score_network.py:126-163):
     s <- LN1(s + feat @ W_final + b_final);  s <- LN2(s + relu(relu(s @ W0 + b0) @ W2 + b2) @ W4 + b4), in place.
-    feat (M, K1) and s (M, 256) fp32 rows; w_* = (WeightPlanes of the (K, 256) weight, bias (256)); ln* = (gamma, beta)."""
+    feat (M, K1) and s (M, 256) fp32 rows; w_* = (WeightPlanes of the (K, 256) weight, bias (256)); ln* = (gamma, beta).
+    affine = (Wt (256, 6) fp32, bias (6)) with rigid = (fixed_i32, init_q, init_t, cur_q, cur_t, cur_R, delta_q, position_scale): also
+    affine_update of the new s and the frame update of rigid_update() in the same launch."""
     M, K1 = feat.shape
     assert s.shape == (M, 256) and feat.stride(1) == 1 and s.stride(1) == 1 and K1 % 16 == 0
     a = AbxIpaTail()
@@ -428,6 +430,13 @@ def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5):
         setattr(a, 'W_' + tag, _p(w3)); setattr(a, 'e_' + tag, w3.w_exp); setattr(a, 'b_' + tag, _p(_f32(bias)))
     a.ln1_w, a.ln1_b, a.ln2_w, a.ln2_b = _p(_f32(ln1[0])), _p(_f32(ln1[1])), _p(_f32(ln2[0])), _p(_f32(ln2[1]))
     a.ln_eps = float(eps)
+    if affine is not None:
+        wa, ba = affine
+        fixed, init_q, init_t, cur_q, cur_t, cur_R, delta_q, pscale = rigid
+        assert wa.shape == (256, 6) and wa.is_contiguous() and ba.numel() == 6 and fixed.dtype == torch.int32 and fixed.numel() == M
+        a.W_aff, a.b_aff, a.fixed = _p(_f32(wa)), _p(_f32(ba)), _p(fixed)
+        a.init_q, a.init_t, a.cur_q, a.cur_t, a.cur_R, a.delta_q = [_p(_f32(t)) for t in (init_q, init_t, cur_q, cur_t, cur_R, delta_q)]
+        a.pscale = float(pscale)
     check(_lib.load().abx_ipa_tail(C.byref(a), _stream()), 'abx_ipa_tail')
     return s
 

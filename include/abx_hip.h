@@ -157,6 +157,11 @@ typedef struct AbxIpaTail {
     const unsigned short* W_t4; int e_t4; const float* b_t4;
     const float* ln2_w; const float* ln2_b;
     float ln_eps;
+    /* optional (W_aff != NULL): affine_update (W_aff [256][6] fp32, b_aff [6]) of the new s and the frame update of abx_rigid_update
+     * (same operands: fixed_mask, init / current frames, accumulated quaternion, position scale) in the same launch */
+    const float* W_aff; const float* b_aff;
+    const int* fixed; const float* init_q; const float* init_t;
+    float* cur_q; float* cur_t; float* cur_R; float* delta_q; float pscale;
 } AbxIpaTail;
 int abx_ipa_tail(const AbxIpaTail* desc, hipStream_t stream);
 /* diagnostics: resident workgroups per CU of the main split-f16 GEMM instantiations (0: 128x192, 1: 128x128,

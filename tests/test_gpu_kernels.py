@@ -614,6 +614,27 @@ def test_ipa_tail(ops, M):
     ops.gemm(h2, d(W4), s6, bias=wd[3][1], B3=wd[3][0], resid=s6, exact=2)
     ops.layernorm(s6, *lnd[1], out=s6)
     assert float((sd - s6).abs().max()) < 2e-5
+    # with the affine_update + frame update in the same launch: against abx_gemm (exact kernel, N = 6) + abx_rigid_update on the new s
+    Wa, ba = d(torch.randn(Cc, 6, generator=gen(20)) * 0.05), d(torch.randn(6, generator=gen(21)) * 0.05)
+    q0 = torch.nn.functional.normalize(torch.randn(M, 4, generator=gen(22)), dim=-1)
+    t0 = torch.randn(M, 3, generator=gen(23)) * 10
+    fixed = d((torch.rand(M, generator=gen(24)) < 0.3).to(torch.int32))
+    frames = []
+    for fused in (True, False):
+        iq, it, cq, ct, cR, dq = (torch.empty(M, 4, device=DEV), torch.empty(M, 3, device=DEV), torch.empty(M, 4, device=DEV),
+                                  torch.empty(M, 3, device=DEV), torch.empty(M, 9, device=DEV), torch.empty(M, 4, device=DEV))
+        ops.frames_init(d(torch.cat([q0, t0], -1)), iq, it, cq, ct, cR, dq, M, 10.0)
+        s7 = d(s0)
+        if fused:
+            ops.ipa_tail(featd, s7, wd[0], lnd[0], wd[1], wd[2], wd[3], lnd[1], affine=(Wa, ba), rigid=(fixed, iq, it, cq, ct, cR, dq, 10.0))
+            assert torch.equal(s7, sd)
+        else:
+            upd = torch.empty(M, 6, device=DEV)
+            ops.gemm(sd, Wa, upd, bias=ba, exact=1)
+            ops.rigid_update(upd, fixed, iq, it, cq, ct, cR, dq, M, 10.0)
+        frames.append((cq, ct, cR, dq))
+    for x1, x2, nm in zip(frames[0], frames[1], ('cur_q', 'cur_t', 'cur_R', 'delta_q')):
+        assert float((x1 - x2).abs().max()) < 1e-5, nm
 
 
 @pytest.mark.parametrize('L', [52, 131, 230, 402, 600])
