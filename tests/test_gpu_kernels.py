@@ -229,6 +229,26 @@ def test_gemm_split_accuracy_vs_exact(ops):
                 assert not torch.equal(o_split, o_exact), 'the split-f16 kernel did not run'
 
 
+def test_gemm_split_f16_error_model_heavy_tails(ops):
+    """The error model of the split-f16 product on operands that are NOT well scaled: log-normal magnitudes over
+    eight decades inside one row of A and inside the weights, random signs (heavy cancellation).  Every output must stay within
+    the same multiple of 2^-24 * sum_k |a_k w_k| as the exact fp32-MFMA kernel reaches on the same problem (max <= 1.5x, mean <= 1.2x)."""
+    for (M, N, K) in ((40000, 256, 128), (33000, 192, 768), (36000, 256, 2112)):
+        A = torch.randn(M, K, generator=g(260)) * torch.exp(torch.randn(M, K, generator=g(261)) * 2.0)
+        W = torch.randn(N, K, generator=g(262)) * torch.exp(torch.randn(N, K, generator=g(263)) * 2.0) / K ** 0.5
+        Ad, Wt = A.to(DEV), W.t().contiguous().to(DEV)
+        ref = A.double() @ W.double().t()
+        den = A.double().abs() @ W.double().abs().t()
+        o_x, o_s = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        ops.gemm(Ad, Wt, o_x, exact=True)
+        ops.gemm(Ad, Wt, o_s, B3=ops.split_weights(Wt), exact=2)
+        e_x = (o_x.cpu().double() - ref).abs() / den / 2.0 ** -24
+        e_s = (o_s.cpu().double() - ref).abs() / den / 2.0 ** -24
+        assert float(A.abs().max()) < 2.0 ** 20
+        assert float(e_s.max()) <= 1.5 * float(e_x.max()) and float(e_s.mean()) <= 1.2 * float(e_x.mean()), \
+            (M, N, K, float(e_x.max()), float(e_s.max()), float(e_x.mean()), float(e_s.mean()))
+
+
 def test_gemm_split_operand_larger_than_4gb(ops):
     """The pair-stack GEMMs of a 20-sample chunk at L = 352 have A operands beyond 4 GB (2.48 M rows x 768): the DMA offsets
     are tile-relative 32-bit values, so such problems must still run on the split kernels and be right at both ends."""
