@@ -341,8 +341,10 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
         vreg = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (kk < KC4 && c0 + kk < L) {
             const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
-            kreg = *reinterpret_cast<const f32x4*>(a.k + off);
-            vreg = *reinterpret_cast<const f32x4*>(a.v + off);
+            // read once per launch: non-temporal, so that the K / V stream does not push the Q rows (re-read at every chunk) and the
+            // pair's bias out of the L2
+            kreg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.k + off));
+            vreg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.v + off));
         }
     };
     auto stage_mask = [&](int c0, int buf, int t) {
