@@ -35,6 +35,7 @@ class AbxGemm(C.Structure):
         ('B_split', C.c_void_p), ('sB3p', LL), ('sB3n', LL), ('sB3k', LL), ('sB3b', LL),
         ('A_split', C.c_void_p), ('sA3p', LL), ('sA3m', LL), ('sA3k', LL), ('sA3b', LL),
         ('batch_inner', I), ('sA3i', LL), ('sB3i', LL),
+        ('c_split_tile', I),
         ('c_split_nA', I),
         ('C_split', C.c_void_p), ('sCp', LL), ('sCk', LL), ('c_split_L', I),
         ('glu', I),

@@ -215,13 +215,14 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
     }
 }
 
-// ---- triangle attention on the bf16 matrix cores (split-bf16, see gemm3.hip for the arithmetic) ------------------------------
-// Same (b, row s, head h) decomposition, online softmax and swapped S^T product as tri_attn_kernel, with every fp32 operand written
-// exactly as three bf16 pieces (6 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate: fp32-accurate).
+// ---- triangle attention on the float16 matrix cores (split-f16, see gemm3.hip for the arithmetic) ----------------------------
+// Same (b, row s, head h) decomposition, online softmax and swapped S^T product as tri_attn_kernel, with every fp32 product evaluated
+// from 3 exact f16 products (v_mfma_f32_16x16x32_f16, fp32 accumulate): keys / values are the plane side (16 k, 16 v as p0, p1,
+// p2 = p0 2^-11), queries and softmax weights the two-piece side (q / 16, P / 16 as a0, a1), so the products need no rescale.
 //   K, V of the row are split ONCE, while they are staged, in chunks of 128 keys, DOUBLE BUFFERED: the global loads of chunk
 //   c + 1 are issued before the wave computes on chunk c and are split + written afterwards, ONE barrier per chunk.
-//     K planes [3][key][48 d] bf16 (96-byte rows)  -> A operand of S^T = K Q^T          (lane: key, 8 consecutive d; ds_read_b128)
-//     V planes [3][key][48 d] bf16 (same image)    -> A operand of O^T += V^T P         (lane: d, 8 keys) through the transposing
+//     K planes [3][key][48 d] f16 (96-byte rows)   -> A operand of S^T = K Q^T          (lane: key, 8 consecutive d; ds_read_b128)
+//     V planes [3][key][48 d] f16 (same image)     -> A operand of O^T += V^T P         (lane: d, 8 keys) through the transposing
 //                                                     LDS read ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 d] block
 //                                                     and lane n receives its column n; no transposed staging writes
 //   Q is split per query tile in registers; P per key tile in registers: the S^T accumulators of two 16-key sub-blocks (lane:

@@ -101,4 +101,15 @@ struct ClockProbe {
     }
 };
 
+// AbxGemm.c_split_tile: the GEMM rows of a plane-output projection are pair positions in (8 i x 16 k) block order, so that the 32 rows
+// of a wave tile are two i of ONE k-tile: their plane bytes ([k-tile][plane][i][16]) are 64 contiguous bytes per channel and store
+// instruction (row order m = i Lp + k gave two 32-byte pieces a k-tile apart: twice the HBM write bytes on the counter).
+__device__ __forceinline__ void pair_tile_decode(int m, int Lp, int& pi, int& pj) {
+    const int KT = (Lp + 15) >> 4;
+    const int blk = m >> 7, r = m & 127;
+    const int ib = blk / KT, kt = blk - ib * KT;
+    pi = ib * 8 + (r >> 4);
+    pj = kt * 16 + (r & 15);
+}
+
 #define ABX_NEG_MAX (-3.4028234663852886e38f)  // torch.finfo(float32).min

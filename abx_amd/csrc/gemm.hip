@@ -430,11 +430,14 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     AbxGemm g = *gp;
     ABX_REQUIRE((g.A || g.A_split) && (g.B || g.B_split) && (g.C || g.C_split), "abx_gemm: null operand");
     ABX_REQUIRE(!g.glu || (g.c_transposed && g.N % 128 == 0 && !g.gate), "abx_gemm: glu needs a transposed store, N % 128 == 0, no gate");
-    ABX_REQUIRE(!g.C_split || (g.c_transposed && g.c_split_L > 0 && g.c_split_L % 4 == 0 && g.M % g.c_split_L == 0),
+    const long long tile_rows = ((long long)(g.pair_L + 7) / 8 * 8) * ((long long)(g.pair_Lp + 15) / 16 * 16);
+    ABX_REQUIRE(!g.c_split_tile || (g.C_split && g.a_pair && g.pair_Lp > 0 && g.M == tile_rows && !g.gate && !g.resid),
+                "abx_gemm: c_split_tile needs C_split, a_pair, pair_L / pair_Lp, M == ceil8(pair_L) * ceil16(pair_Lp), no gate / resid");
+    ABX_REQUIRE(!g.C_split || (g.c_transposed && g.c_split_L > 0 && g.c_split_L % 4 == 0 && (g.c_split_tile || g.M % g.c_split_L == 0)),
                 "abx_gemm: C_split needs the transposed store of a (padded) pair tensor (M = rows * c_split_L, c_split_L % 4 == 0)");
     ABX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "abx_gemm: empty problem");
     ABX_REQUIRE(g.pair_Lp == 0 || (g.pair_L > 0 && g.pair_Lp >= g.pair_L && g.pair_Lp % 4 == 0 &&
-                                   g.M == (long long)g.pair_L * g.pair_Lp && (!g.C_split || g.c_split_L == g.pair_Lp)),
+                                   (g.c_split_tile || g.M == (long long)g.pair_L * g.pair_Lp) && (!g.C_split || g.c_split_L == g.pair_Lp)),
                 "abx_gemm: padded pair rows need M == pair_L * pair_Lp, pair_Lp % 4 == 0 (and c_split_L == pair_Lp)");
     ABX_REQUIRE((!g.a_pair && !g.c_pair) || g.pair_Lp > 0, "abx_gemm: a_pair / c_pair need pair_L / pair_Lp");
     ABX_REQUIRE(!g.A || g.sAk == 1 || g.sAm == 1, "abx_gemm: A must be k- or m-contiguous");
@@ -458,14 +461,14 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
         int rc = 0;
         if (!abx_gemm3_dispatch(g, st, &rc)) return rc;
     }
-    ABX_REQUIRE(g.A && g.B, "abx_gemm: split-bf16 operands given but the problem does not qualify for the split kernels "
+    ABX_REQUIRE(g.A && g.B, "abx_gemm: split-f16 operands given but the problem does not qualify for the split kernels "
                             "(K % 16, alignment, size) and no fp32 operands were passed for the exact kernel");
-    ABX_REQUIRE(g.a_pair_transpose <= 0 && g.pair_Lp == 0, "abx_gemm: pair-row remapping is served by the split-bf16 kernels only");
+    ABX_REQUIRE(g.a_pair_transpose <= 0 && g.pair_Lp == 0, "abx_gemm: pair-row remapping is served by the split-f16 kernels only");
     ABX_REQUIRE(g.batch <= 65535, "abx_gemm: batch > 65535 (exact fp32 kernels)");
-    ABX_REQUIRE(!g.glu, "abx_gemm: glu is served by the split-bf16 kernels only (large problems, K % 16 == 0)");
-    ABX_REQUIRE(!g.A2, "abx_gemm: the dual GEMM is served by the split-bf16 kernels only");
-    ABX_REQUIRE(!g.out_ln_w, "abx_gemm: out_ln is served by the split-bf16 kernels only");
-    ABX_REQUIRE(!g.mlp, "abx_gemm: the fused transition (mlp) is served by the split-bf16 kernels only (exact = 2, K % 16 == 0)");
+    ABX_REQUIRE(!g.glu, "abx_gemm: glu is served by the split-f16 kernels only (large problems, K % 16 == 0)");
+    ABX_REQUIRE(!g.A2, "abx_gemm: the dual GEMM is served by the split-f16 kernels only");
+    ABX_REQUIRE(!g.out_ln_w, "abx_gemm: out_ln is served by the split-f16 kernels only");
+    ABX_REQUIRE(!g.mlp, "abx_gemm: the fused transition (mlp) is served by the split-f16 kernels only (exact = 2, K % 16 == 0)");
     const long long mt128 = ((long long)g.M + 127) / 128;
     if (g.N <= 32) return launch_cfg<128, 32, 32, 32>(g, st);
     if (g.N <= 64) return launch_cfg<128, 64, 32, 64>(g, st);

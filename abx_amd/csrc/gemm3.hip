@@ -1,12 +1,14 @@
-// fp32 GEMM on the bf16 matrix cores by operand splitting ("bf16x3"): the large contractions of the pair stack.
+// fp32 GEMM on the float16 matrix cores by operand splitting ("split-f16"): the large contractions of the pair stack.
 //
-// Every fp32 operand element is written EXACTLY as the sum of three bf16 values x = x0 + x1 + x2 (round-to-nearest pieces:
-// 8 + 8 + 8 significand bits), and a*b is evaluated as the six products with i + j <= 2
-//     a0 b2 + a1 b1 + a2 b0 + a0 b1 + a1 b0 + a0 b0            (smallest terms first)
-// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each bf16 x bf16 product is exact in fp32; the three dropped terms are
-// below 2^-25 |a||b|, i.e. under the rounding error of a native fp32 fma, so the result is fp32-accurate (measured against
-// fp64 in tests/test_gpu_kernels.py: same error as the exact v_mfma_f32_32x32x2_f32 kernel of gemm.hip) while the matrix
-// cores run 16/6 = 2.7x faster than their fp32 rate.  The exact kernel remains selectable (AbxGemm.exact).
+// An fp32 product is evaluated from three exact partial products on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+//     x y ~ a1 p2 + a0 p1 + a0 p0                              (smallest terms first)
+//     A side (two pieces):   x' = x 2^-4,  a0 = f16(x'),  a1 = f16((x' - a0) 2^11)
+//     B side (three planes): y' = y 2^e,   p0 = f16(y'),  p1 = f16(y' - p0),  p2 = f16(p0 2^-11)
+// Each f16 x f16 product is exact in fp32.  A piece pair holds 23 significant bits and the dropped term a1 p1 2^-11 is <= 2^-22 |x y|,
+// mean zero: measured against fp64 (tests/test_gpu_kernels.py) the error is that of the exact v_mfma_f32_32x32x2_f32 kernel of
+// gemm.hip, while the matrix cores run 16/3 = 5.3x faster than their fp32 rate.  The power-of-two scales keep the pieces normal
+// float16 numbers (range contract and what happens beyond it: include/abx_hip.h, "Split-f16 operands").  The
+// exact kernel remains selectable (AbxGemm.exact).  Rounds 1-2 used three bf16 pieces per operand and six products.
 //
 // Data movement is all asynchronous global->LDS DMA (global_load_lds_dwordx4): no operand passes through VGPRs on its way
 // to LDS (no staging registers, no ds_write pass, no vector address arithmetic); the k-loop waits with an explicit
@@ -17,9 +19,9 @@
 //      Optional pair transposition of the rows (a_pair_transpose): the DMA source address is per lane, so the incoming
 //      TriangleMultiplication reads z[k][i] rows in (i,k) order for free.
 //   A  fp32, row-contiguous / channel-major (AMODE 1): 2 stages [16 k][BM] fp32, fragments by 4-byte LDS reads.
-//   A  pre-split bf16 planes (AMODE 2) and B always pre-split planes, k-TILED in memory: [K/16][3][rows][16] so that the
+//   A  pre-split pieces (AMODE 2: planes 0, 1) and B always pre-split planes, k-TILED in memory: [K/16][3][rows][16] so that the
 //      32 bytes a row contributes to a k-tile sit next to the neighbouring rows' (full 128-byte lines per DMA instead of a
-//      quarter line per row, which the 32 KB L1 cannot keep until the next k-tile): weights from abx_split_weights, or
+//      quarter line per row, which the 32 KB L1 cannot keep until the next k-tile): weights from abx_split_weights_f16, or
 //      activations written by a producer GEMM with C_split (the TriangleMultiplication einsum seqformer.py:490-493 takes
 //      both operands this way).  LDS image [plane][row][32 B], the two 16-byte halves swapped on odd row-octets:
 //      conflict-free ds_read_b128 fragment reads (lane -> row, lane >> 5 -> k half).
@@ -49,13 +51,13 @@ template <int N> __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// byte offset of (plane, row, 16-byte half) in a [3][ROWS][16] bf16 tile image
+// byte offset of (plane, row, 16-byte half) in a [3][ROWS][16] 16-bit tile image
 template <int ROWS>
 __device__ __forceinline__ int plane_off(int plane, int row, int half) {
     return plane * (ROWS * 32) + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
 }
 
-// DMA source byte offsets (from the operand's batch base) of one wave for a [3][ROWS][16] bf16 plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
+// DMA source byte offsets (from the operand's batch base) of one wave for a [3][ROWS][16] 16-bit plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
 // Surplus chunks (image not a multiple of 4 KB) and rows past the matrix re-read a valid row; their LDS bytes are never used
 // for valid outputs.
 template <int ROWS, int NL, int NPL = 3>
@@ -133,7 +135,15 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
             if (g.a_pair) {
                 // padded pair position (i, j) of the GEMM -> row of the unpadded pair tensor (pad columns re-read column L-1;
                 // their outputs are zeroed by the row scale / never stored)
-                const int pi = gri / g.pair_Lp, pj = min(gri - pi * g.pair_Lp, g.pair_L - 1);
+                int pi, pj;
+                if (g.c_split_tile) {
+                    pair_tile_decode(gri, g.pair_Lp, pi, pj);
+                    pi = min(pi, g.pair_L - 1);
+                    pj = min(pj, g.pair_L - 1);
+                } else {
+                    pi = gri / g.pair_Lp;
+                    pj = min(gri - pi * g.pair_Lp, g.pair_L - 1);
+                }
                 gr = g.a_pair_transpose > 0 ? (long long)pj * g.pair_L + pi : (long long)pi * g.pair_L + pj;
             } else if (g.a_pair_transpose > 0) {
                 const int qi = gri / g.a_pair_transpose;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
 // The hidden activations never exist in memory.  The hidden dimension is walked in chunks of 128:
 //   GEMM 1 of a chunk is the ordinary main loop with the MFMA operands SWAPPED, so a wave's accumulators hold the TRANSPOSED tiles
 //   H^T[hidden][row]: lane = row, registers = 16 hidden channels.  Folded LayerNorm (the row statistics are lane-local in this
-//   orientation), bias and ReLU are applied to the registers, which are then split into bf16 pieces and ARE the A operand of GEMM 2
+//   orientation), bias and ReLU are applied to the registers, which are then split into f16 pieces and ARE the A operand of GEMM 2
 //   (lane = row, 8 k values per k-step): a 32 x 32 tile feeds two k-steps whose k slots (lane half h, slot i) hold the hidden
 //   channel 8 (i >> 2) + 4 h + (i & 3) of a 16-channel k-tile.  The W2 planes are stored with exactly that order inside every
 //   k-tile (AbxGemm.B2_split of an mlp descriptor; abx_amd.ops.permute_k16), so its fragments are the usual 16-byte reads.
@@ -482,7 +492,7 @@ template <bool EDGE>
 __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, int mt, int b) {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 128, BN2 = 192, TN2 = BN2 / 32;
     constexpr int G1_BYTES = 2 * BM * 64 + 2 * 3 * BN * 32;                  // stages of GEMM 1 (A fp32 + W1 planes)
-    constexpr int B2_IMG = 3 * BN2 * 32;                                     // one k-tile of W2: [3][192][16] bf16
+    constexpr int B2_IMG = 3 * BN2 * 32;                                     // one k-tile of W2: [3][192][16] f16
     constexpr int NL2 = (B2_IMG + 4095) / 4096;
     char* W2s = reinterpret_cast<char*>(smem) + G1_BYTES;                    // 2 stages
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -802,7 +812,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if (!g.B_split || g.K % 16 != 0 || (g.N <= 64 && !narrow)) return 1;
     if ((g.A_split != nullptr) == (g.b_f16 != 0) || g.b_exp < -100 || g.b_exp > 100 || g.b2_exp < -100 || g.b2_exp > 100) {
         abx_set_error("abx_gemm: B_split must be float16 weight planes (abx_split_weights_f16, b_f16 = 1, |b_exp| <= 100) with an fp32 A "
-                      "and bf16 planes (b_f16 = 0) with A_split");
+                      "and activation images (b_f16 = 0) with A_split");
         *rc = ABX_ERR_ARG;
         return 0;
     }
@@ -832,7 +842,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
     if (g.out_ln_w) {
         if (g.N > 128 || g.c_transposed || g.C_split || g.A2 || g.A_split || g.sAk != 1 || !g.out_ln_b) {
-            abx_set_error("abx_gemm: out_ln needs N <= 128, a k-contiguous fp32 A and a plain store (split-bf16 path)");
+            abx_set_error("abx_gemm: out_ln needs N <= 128, a k-contiguous fp32 A and a plain store (split-f16 path)");
             *rc = ABX_ERR_ARG;
             return 0;
         }
@@ -864,7 +874,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
             !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 || !g.ln2_csum ||
             (g.pair_Lp > 0 ? (long long)g.pair_L * g.pair_L * g.sA2m : 128LL * g.sA2m) >= (1LL << 30) ||
             (long long)(g.K2 / 16) * g.sB23k >= (1LL << 31)) {
-            abx_set_error("abx_gemm: dual (A2 / B2_split) operands do not qualify for the split-bf16 dual kernel");
+            abx_set_error("abx_gemm: dual (A2 / B2_split) operands do not qualify for the split-f16 dual kernel");
             *rc = ABX_ERR_ARG;
             return 0;
         }
@@ -887,7 +897,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     // (the plane x plane contraction at L = 352 pads to 384 either way: the wide tile measured 10 % faster)
     const bool wide = g.glu ? false : force ? force == 2 : (g.A_split ? pad192 <= pad128 : (pad192 <= pad128 && g.N % 128 != 0));
     // waves are stacked along M (4 x 1): every wave owns 32 rows and the full tile width, so each A row is read from LDS and
-    // split into bf16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
+    // split into f16 pieces by exactly one wave (the VALU issue slots next to the MFMAs are the scarce resource)
     // Small problems (the per-residue GEMMs of the IPA loop / sequence track at a dozen samples per GPU: 4 224 rows x 256 columns = 66
     // tiles of 128 x 128 on 256 CUs): 64 x 128 tiles, 2 x 2 waves, twice the workgroups.  Every output element still accumulates its k
     // in the same order (same MFMA, same term order, same row statistics), so the tile choice does not change a single bit and

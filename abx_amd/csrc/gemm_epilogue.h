@@ -1,4 +1,4 @@
-// Fused GEMM epilogue shared by the exact-fp32 (gemm.hip) and the split-bf16 (gemm3.hip) kernels.
+// Fused GEMM epilogue shared by the exact-fp32 (gemm.hip) and the split-f16 (gemm3.hip) kernels.
 // The accumulators use the C/D layout of the 32x32 MFMAs (dtype independent on gfx950):
 //   col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 // st_lds: [BM][2] (mean - shift, rstd) of this M-panel when `stats`; scratch: per-wave store staging (4 waves).
@@ -77,7 +77,14 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                 split2w(v[2], v[3], b0, b1, b2);
             }
             // m = i * L + k: the planes are the k-tiled operand image [k/16][plane][i][16] of the following contraction
-            const int ii = m_idx / g.c_split_L, kk = m_idx - ii * g.c_split_L;
+            int ii, kk;
+            if (g.c_split_tile) {
+                pair_tile_decode(m_idx, g.c_split_L, ii, kk);
+                if (ii >= g.pair_L || kk >= g.c_split_L) return;    // padding rows of the (8 i x 16 k) blocks: nothing to store
+            } else {
+                ii = m_idx / g.c_split_L;
+                kk = m_idx - ii * g.c_split_L;
+            }
             unsigned short* cs = g.C_split + (long long)b * g.sCb + (long long)n_idx * g.sCm + (kk >> 4) * g.sCk + ii * 16 + (kk & 15);
             if (c_vec && cnt == 4) {
                 *reinterpret_cast<u32x2*>(cs) = u32x2{a0, b0};
@@ -262,7 +269,14 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                     cnt = min(4, g.M - m);
                 }
                 if (rs) {
-                    const f32x4 s = load4(rs + m, rs_vec, cnt);
+                    long long rsi = m;
+                    if (g.c_split_tile) {                       // the row scale stays in (i, k) order: [i * Lp + k]
+                        int pi, pj;
+                        pair_tile_decode(m, g.pair_Lp, pi, pj);
+                        if (pi >= g.pair_L || pj >= g.pair_Lp) continue;
+                        rsi = (long long)pi * g.pair_Lp + pj;
+                    }
+                    const f32x4 s = load4(rs + rsi, rs_vec, cnt);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] *= s[c];
                 }

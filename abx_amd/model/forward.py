@@ -343,8 +343,9 @@ class Engine:
                 else:
                     pm = ws.get('pmask_p', (Bc * LLp,))
                     ops.pair_mask(mask_f, pm, Bc, L, Lp)
-                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, zin, lrp, rowscale=pm, glu=True, c_split_nA=128,
-                        a_pair_transpose=0 if outgoing else L, pair=pad, a_pair=pad is not None)
+                # (GEMM rows in (8 i x 16 k) block order: 64 contiguous plane bytes per store instruction - half the HBM write bytes)
+                _ln_lin(P, pre + 'lr_glu', pre + 'norm', None, zin, lrp, rowscale=pm, glu=True, c_split_nA=128, c_split_tile=True,
+                        a_pair_transpose=0 if outgoing else L, pair=(L, Lp), a_pair=True)
                 tt = w384[:Bc * 128 * LLp].view(Bc, 128, LLp)      # channel-major product, padded pair rows (pads: never stored)
                 tz = tt.as_strided((Bc * 128, L, L), (LLp, Lp, 1))
                 ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz, exact=2)

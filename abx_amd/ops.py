@@ -148,7 +148,7 @@ def _weight_planes(w3, N, K=None, what='B3'):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0, c_split_tile=False):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -194,6 +194,8 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         if a_pair:
             assert pair is not None and M == pair[0] * pair[0], (A.shape, pair)
             M = pair[0] * pair[1]
+            if c_split_tile:        # GEMM rows = pair positions in (8 i x 16 k) blocks (AbxGemm.c_split_tile)
+                M = ((pair[0] + 7) // 8 * 8) * ((pair[1] + 15) // 16 * 16)
     if b_planes:
         assert B.dim() == 5 and B.shape[2] == 3 and B.shape[4] == 16 and B.stride(4) == 1 and B.shape[1] * 16 == K and B.shape[0] == nb
         N = B.shape[3]
@@ -220,10 +222,11 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     if c_planes:
         L = Cout.shape[4]
         Lp = pair[1] if pair is not None else L
-        assert Cout.dim() == 6 and Cout.shape == (nb, No, (Lp + 15) // 16, 3, L, 16) and M == L * Lp, (Cout.shape, nb, M, N)
+        assert Cout.dim() == 6 and Cout.shape == (nb, No, (Lp + 15) // 16, 3, L, 16) and (c_split_tile or M == L * Lp), (Cout.shape, nb, M, N)
+        assert not c_split_tile or (a_pair and pair is not None), 'c_split_tile: the A rows come through the pair-row map (a_pair, pair=(L, Lp))'
         assert Cout.stride(5) == 1 and Cout.stride(4) == 16
         g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), Lp
-        g.c_transposed, g.c_split_nA = 1, int(c_split_nA)
+        g.c_transposed, g.c_split_nA, g.c_split_tile = 1, int(c_split_nA), int(bool(c_split_tile))
     else:
         if Cout.dim() == 2:
             Cout = Cout.unsqueeze(0)
@@ -241,7 +244,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     g.a_pair_transpose = int(a_pair_transpose)
     if pair is not None:
         g.pair_L, g.pair_Lp, g.a_pair, g.c_pair = int(pair[0]), int(pair[1]), int(bool(a_pair)), int(bool(c_pair))
-        assert M == pair[0] * pair[1], (M, pair)
+        assert c_split_tile or M == pair[0] * pair[1], (M, pair)
     g.glu = int(bool(glu))
     if ln is not None:
         stats, csum = ln                     # stats None: the kernel derives (mean, rstd) from its own A stream
@@ -284,8 +287,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     g.alpha = float(alpha)
     g.act = int(act)
     if rowscale is not None:
-        assert rowscale.numel() == nb * M and rowscale.is_contiguous()
-        g.rowscale, g.sRSb = _p(_f32(rowscale)), M
+        rs_rows = pair[0] * pair[1] if c_split_tile else M
+        assert rowscale.numel() == nb * rs_rows and rowscale.is_contiguous()
+        g.rowscale, g.sRSb = _p(_f32(rowscale)), rs_rows
     if gate is not None:
         if gate.dim() == 2:
             gate = gate.unsqueeze(0)

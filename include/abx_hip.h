@@ -83,6 +83,10 @@ typedef struct AbxGemm {
     int batch_inner; long long sA3i, sB3i;         /* batch_inner > 0: two-level batch of the plane operands, entry b sits at
                                                       (b / batch_inner) * sX3b + (b % batch_inner) * sX3i (left / right channels of
                                                       one sample inside a wider channel tensor) */
+    int c_split_tile;                              /* with C_split, pair_Lp > 0 and a_pair: the M = ceil8(pair_L) * ceil16(pair_Lp) GEMM rows are
+                                                      pair positions (i, k) in blocks of (8 i x 16 k), m = ((i/8) * KT + k/16) * 128 + (i%8) * 16
+                                                      + k%16 (KT = ceil(pair_Lp / 16)): 64 contiguous plane bytes per store instruction and
+                                                      channel.  rowscale stays indexed [i * pair_Lp + k] */
     int c_split_nA;                                /* with C_split: output channels n < c_split_nA are written as the A side of the
                                                       following contraction (two pieces), the others as its B side (three planes) */
     unsigned short* C_split; long long sCp, sCk; int c_split_L;   /* write the output as planes instead of C, laid out as the

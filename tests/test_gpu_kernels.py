@@ -407,6 +407,11 @@ def test_gemm_split_glu_and_two_level_batch(ops):
         want = (val.transpose(1, 2) if transpose else val).permute(0, 3, 1, 2)
         e = float((got - want).abs().max() / want.abs().max())
         assert e < 3e-6, (transpose, e)
+        # the same GEMM with its rows in (8 i x 16 k) block order (AbxGemm.c_split_tile: what the model runs): identical images
+        planes_t = torch.zeros(B_, C_, KT, 3, L_, 16, dtype=torch.int16, device=DEV)
+        ops.gemm(Z.to(DEV).view(B_, LL, K), Wt, planes_t, bias=bias2, ln=(None, csum), rowscale=pm.reshape(-1).contiguous().to(DEV),
+                 glu=True, B3=w3, a_pair_transpose=L_ if transpose else 0, c_split_nA=128, c_split_tile=True, pair=(L_, L_), a_pair=True)
+        assert torch.equal(planes_t, planes), 'tile-ordered rows changed the plane images'
         # contraction over the channel halves: out[b,c,i,j] = sum_k left[b,c,i,k] right[b,c,j,k]
         out = torch.full((B_ * 128, L_, L_), float('nan'), device=DEV)
         ops.gemm(planes[:, 0:128], planes[:, 128:256], out)

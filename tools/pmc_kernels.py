@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Launch ONE of the dominant kernels a few times at the bench geometry, for rocprofv3 --pmc passes (tools/pmc_run.sh).
     python tools/pmc_kernels.py <which> [Bc] [L]
-which: qkvg (LN -> 768, gemm3 128x128)  trans2 (768 -> 192 + resid, gemm3 128x192)  glu (LN -> glu planes, transposed store)
+which: qkvg (LN -> 768, gemm3 128x128)  mlp (fused transition)  trans2 (768 -> 192 + resid, gemm3 128x192)  glu (LN -> glu planes, transposed store)
        contract (plane x plane)  projout (channel-major A, gate, resid)  tri (triangle attention)  ipa (IPA attention)"""
 import os
 import sys
@@ -23,6 +23,12 @@ if which == 'qkvg':
     C, bias, csum, W3 = torch.empty(M2, 768, device=DEV), r(768), r(768), ops.split_weights(W)
     for _ in range(REPS):
         ops.gemm(z, W, C, bias=bias, ln=(None, csum), B3=W3, exact=2)
+elif which == 'mlp':
+    z, W1, W2 = r(M2, 192), r(192, 768) / 14, r(768, 192) / 28
+    W13, W23p = ops.split_weights(W1), ops.split_weights(ops.permute_k16(W2))
+    b1, b2, cs = r(768), r(192), W1.sum(0).contiguous()
+    for _ in range(REPS):
+        ops.gemm(z, W1, z, bias=b1, ln=(None, cs), B3=W13, act=1, resid=z, exact=2, mlp=(W23p, b2))
 elif which == 'trans2':
     h, W, z = r(M2, 768), r(768, 192) / 28, r(M2, 192)
     W3 = ops.split_weights(W)
@@ -35,7 +41,8 @@ elif which == 'glu':
     lrp = torch.zeros(Bc, 256, (L + 15) // 16, 3, L, 16, dtype=torch.int16, device=DEV)
     pm = torch.ones(Bc * LL, device=DEV)
     for _ in range(REPS):
-        ops.gemm(z3, W, lrp, bias=b, ln=(None, W.sum(0).contiguous()), B3=W3, rowscale=pm, glu=True, exact=2)
+        ops.gemm(z3, W, lrp, bias=b, ln=(None, W.sum(0).contiguous()), B3=W3, rowscale=pm, glu=True, exact=2, c_split_nA=128,
+                 c_split_tile=True, pair=(L, L), a_pair=True)
 elif which == 'contract':
     KT = (L + 15) // 16
     lrp = (torch.randn(Bc, 256, KT, 3, L, 16, device=DEV) * 100).to(torch.int16)
