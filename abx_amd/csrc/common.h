@@ -57,9 +57,24 @@ __device__ __forceinline__ void split2w(float a, float b, unsigned& p0, unsigned
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     p2 = __builtin_bit_cast(unsigned, h0 * (f16x2){(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f});
 }
-// Product terms of one fp32 product, smallest first.  A: the two-piece operand a0 + a1 2^-11; B: planes p0, p1, p2 = p0 2^-11:
+// Product terms of one fp32 product, smallest first.  A: the two-piece operand a0 + a1 2^-11; B: planes p0, p1 (in memory) and p2 = p0 2^-11 (derived in registers):
 // a1 p2 + a0 p1 + a0 p0 (every f16 x f16 product is exact in fp32; dropped: a1 p1 2^-11 <= 2^-22 |a b|).
 struct SplitTerms { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {2, 1, 0}; };
+// third term's operand of the plane side: p2 = p0 * 2^-11, derived in registers (one rounding of an exact value: the same bits a
+// stored plane would hold) - 4 v_pk_mul_f16 per fragment instead of a third plane in memory, in the DMA stream and in the LDS reads
+__device__ __forceinline__ u32x4 f16x8_lo(u32x4 v) {
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+    const _Float16 k = (_Float16)4.8828125e-4f;
+    return __builtin_bit_cast(u32x4, h * (f16x8){k, k, k, k, k, k, k, k});
+}
+// the plane side of an activation for C_split outputs: 16 x as p0 = f16(x'), p1 = f16(x' - p0)
+__device__ __forceinline__ void split2b(float a, float b, unsigned& p0, unsigned& p1) {
+    const f32x2 x = (f32x2){a, b} * (f32x2){16.0f, 16.0f};
+    const f16x2 h0 = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h0, f32x2);
+    p0 = __builtin_bit_cast(unsigned, h0);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
 // one product term of the split GEMMs on 8-element fragments held as raw 16 bytes
 __device__ __forceinline__ f32x16 mfma_split(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);

@@ -3,7 +3,7 @@
 // An fp32 product is evaluated from three exact partial products on v_mfma_f32_32x32x16_f16 with fp32 accumulation
 //     x y ~ a1 p2 + a0 p1 + a0 p0                              (smallest terms first)
 //     A side (two pieces):   x' = x 2^-4,  a0 = f16(x'),  a1 = f16((x' - a0) 2^11)
-//     B side (three planes): y' = y 2^e,   p0 = f16(y'),  p1 = f16(y' - p0),  p2 = f16(p0 2^-11)
+//     B side (two planes):   y' = y 2^e,   p0 = f16(y'),  p1 = f16(y' - p0);  p2 = f16(p0 2^-11) is derived in registers
 // Each f16 x f16 product is exact in fp32.  A piece pair holds 23 significant bits and the dropped term a1 p1 2^-11 is <= 2^-22 |x y|,
 // mean zero: measured against fp64 (tests/test_gpu_kernels.py) the error is that of the exact v_mfma_f32_32x32x2_f32 kernel of
 // gemm.hip, while the matrix cores run 16/3 = 5.3x faster than their fp32 rate.  The power-of-two scales keep the pieces normal
@@ -19,7 +19,7 @@
 //      Optional pair transposition of the rows (a_pair_transpose): the DMA source address is per lane, so the incoming
 //      TriangleMultiplication reads z[k][i] rows in (i,k) order for free.
 //   A  fp32, row-contiguous / channel-major (AMODE 1): 2 stages [16 k][BM] fp32, fragments by 4-byte LDS reads.
-//   A  pre-split pieces (AMODE 2: planes 0, 1) and B always pre-split planes, k-TILED in memory: [K/16][3][rows][16] so that the
+//   A  pre-split pieces (AMODE 2: planes 0, 1) and B always pre-split planes, k-TILED in memory: [K/16][2][rows][16] so that the
 //      32 bytes a row contributes to a k-tile sit next to the neighbouring rows' (full 128-byte lines per DMA instead of a
 //      quarter line per row, which the 32 KB L1 cannot keep until the next k-tile): weights from abx_split_weights_f16, or
 //      activations written by a producer GEMM with C_split (the TriangleMultiplication einsum seqformer.py:490-493 takes
@@ -51,16 +51,16 @@ template <int N> __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// byte offset of (plane, row, 16-byte half) in a [3][ROWS][16] 16-bit tile image
+// byte offset of (plane, row, 16-byte half) in a [2][ROWS][16] 16-bit tile image
 template <int ROWS>
 __device__ __forceinline__ int plane_off(int plane, int row, int half) {
     return plane * (ROWS * 32) + row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
 }
 
-// DMA source byte offsets (from the operand's batch base) of one wave for a [3][ROWS][16] 16-bit plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
+// DMA source byte offsets (from the operand's batch base) of one wave for a [2][ROWS][16] 16-bit plane image stage: chunk c (1 KB of LDS) = wave * NL + i.
 // Surplus chunks (image not a multiple of 4 KB) and rows past the matrix re-read a valid row; their LDS bytes are never used
 // for valid outputs.
-template <int ROWS, int NL, int NPL = 3>
+template <int ROWS, int NL, int NPL = 2>
 __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row, int r0, int R, unsigned (&off)[NL]) {
     // (the k-tile stride is applied by the caller: one k-tile = 16 consecutive k of every row)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     constexpr int A_IMG = AMODE == 3 ? 0 : (AMODE == 2 ? 2 * BM * 32 : BM * 64);   // bytes per A stage (planes: the two pieces a0, a1)
     constexpr int NLA = AMODE == 3 ? 1 : (A_IMG + 4095) / 4096;                 // DMA instructions per wave per A tile
     constexpr int A_STAGE = RING == 2 ? A_IMG : (A_IMG + 4095) / 4096 * 4096;
-    constexpr int B_IMG = 3 * BN * 32;
+    constexpr int B_IMG = 2 * BN * 32;
     constexpr int NLB = (B_IMG + 4095) / 4096;
     // with counted waits every wave must issue the same number of DMA instructions (stage padded to 4 KB multiples); the
     // 2-stage protocol waits for everything, so the surplus chunks are simply skipped and the stage is the bare image
@@ -164,7 +164,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     } else {
         baseA = reinterpret_cast<const char*>(g.A_split + (g.batch_inner > 0 ? (long long)(b / g.batch_inner) * g.sA3b + (long long)(b % g.batch_inner) * g.sA3i
                                                                                   : (long long)b * g.sA3b));
-        plane_sources<BM, NLA, 2>(g.sA3p, g.sA3m, m0, g.M, offsA);
+        plane_sources<BM, NLA>(g.sA3p, g.sA3m, m0, g.M, offsA);
         a_step = g.sA3k * 2;
     }
     const char* baseB = reinterpret_cast<const char*>(
@@ -309,7 +309,9 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 #pragma unroll
             for (int j = 0; j < JG; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bb[j][p] = *reinterpret_cast<const u32x4*>(bs + offB[j0 + j] + p * (BN * 32));
+                for (int p = 0; p < 2; ++p) bb[j][p] = *reinterpret_cast<const u32x4*>(bs + offB[j0 + j] + p * (BN * 32));
+#pragma unroll
+            for (int j = 0; j < JG; ++j) bb[j][2] = f16x8_lo(bb[j][0]);
 #pragma unroll
             for (int term = 0; term < T::N; ++term)
 #pragma unroll
@@ -410,7 +412,7 @@ template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_IMG = AMODE == 2 ? 2 * BM * 32 : BM * 64;
     constexpr int A_STAGE = A_IMG;
-    constexpr int B_STAGE = 3 * BN * 32;
+    constexpr int B_STAGE = 2 * BN * 32;
     constexpr int RING = 2;
     constexpr int OPER = (RING * A_STAGE + 2 * B_STAGE) / 4;                       // floats
     constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;      // epilogue column group (gemm_epilogue.h)
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
 // Linear -> LayerNorm over the output row (out_ln): k-contiguous fp32 A, one n-tile, plain store
 template <int BM, int BN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_oln_kernel(const AbxGemm g) {
-    constexpr int OPER = (2 * BM * 64 + 2 * 3 * BN * 32) / 4;
+    constexpr int OPER = (2 * BM * 64 + 2 * 2 * BN * 32) / 4;
     constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;
     constexpr int EPI = 2 * BM + 4 * 32 * (TGW * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, MINW) void gemm3_oln_kernel(const AbxGemm g) {
 
 template <int BM, int BN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) {
-    constexpr int A_STAGE = BM * 64, B_STAGE = 3 * BN * 32;
+    constexpr int A_STAGE = BM * 64, B_STAGE = 2 * BN * 32;
     constexpr int OPER = (2 * A_STAGE + 2 * B_STAGE) / 4;
     constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;
     constexpr int EPI = 4 * BM + 4 * 32 * (TGW * 32 + 4);
@@ -491,8 +493,8 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
 template <bool EDGE>
 __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, int mt, int b) {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 128, BN2 = 192, TN2 = BN2 / 32;
-    constexpr int G1_BYTES = 2 * BM * 64 + 2 * 3 * BN * 32;                  // stages of GEMM 1 (A fp32 + W1 planes)
-    constexpr int B2_IMG = 3 * BN2 * 32;                                     // one k-tile of W2: [3][192][16] f16
+    constexpr int G1_BYTES = 2 * BM * 64 + 2 * 2 * BN * 32;                  // stages of GEMM 1 (A fp32 + W1 planes)
+    constexpr int B2_IMG = 2 * BN2 * 32;                                     // one k-tile of W2: [2][192][16] f16
     constexpr int NL2 = (B2_IMG + 4095) / 4096;
     char* W2s = reinterpret_cast<char*>(smem) + G1_BYTES;                    // 2 stages
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -582,7 +584,9 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
 #pragma unroll
                         for (int t = 0; t < TG2; ++t)
 #pragma unroll
-                            for (int p = 0; p < 3; ++p) wb[t][p] = *reinterpret_cast<const u32x4*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
+                            for (int p = 0; p < 2; ++p) wb[t][p] = *reinterpret_cast<const u32x4*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
+#pragma unroll
+                        for (int t = 0; t < TG2; ++t) wb[t][2] = f16x8_lo(wb[t][0]);
 #pragma unroll
                         for (int term = 0; term < T::N; ++term)
 #pragma unroll
@@ -608,7 +612,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
 
 template <int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
-    constexpr int OPER = (2 * 128 * 64 + 2 * 3 * 128 * 32 + 2 * 3 * 192 * 32) / 4;           // floats
+    constexpr int OPER = (2 * 128 * 64 + 2 * 2 * 128 * 32 + 2 * 2 * 192 * 32) / 4;           // floats
     constexpr int EPI = 2 * 128 + 4 * 32 * (3 * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntm = (g.M + 127) / 128;
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
 constexpr int IT_C = 256;
 constexpr int IT_ASTR = IT_C * 4 + 16;                                      // bytes per activation row in LDS
 constexpr int IT_RING = 3;
-constexpr int IT_OPER = IT_RING * (4096 + 3 * IT_C * 32);                   // main-loop stages: A 3 x 4 KB (padded) + weights 3 x 24 KB
+constexpr int IT_OPER = IT_RING * (4096 + 2 * IT_C * 32);                   // main-loop stages: A 3 x 4 KB (padded) + weights 3 x 16 KB
 constexpr int IT_LDS = IT_OPER + 2 * 32 * IT_ASTR + 2 * 4 * 32 * 4;
 
 __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
 
     AbxGemm g = {};
     g.M = a.M; g.N = IT_C; g.batch = 1; g.b_f16 = 1;
-    g.sB3k = 3 * IT_C * 16; g.sB3p = IT_C * 16; g.sB3n = 16;
+    g.sB3k = 2 * IT_C * 16; g.sB3p = IT_C * 16; g.sB3n = 16;
     f32x16 acc[1][TN];
     float ls[1], lq[1], lsh[1];
     float x[TN][16];
@@ -783,7 +787,7 @@ int launch3(const AbxGemm& g, hipStream_t st) {
     return abx_check_launch("abx_gemm");
 }
 
-// fp32 weights -> k-tiled float16 planes of w' = w * scale: p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 / 2048) (AbxGemm.b_f16)
+// fp32 weights -> k-tiled float16 planes [Kp/16][2][N][16] of w' = w * scale: p0 = f16(w'), p1 = f16(w' - p0) (AbxGemm.b_f16)
 __global__ __launch_bounds__(256) void split_weights_f16_kernel(const float* __restrict__ w, long long s_n, long long s_k, int N, int K,
                                                                 int Kp, float scale, unsigned short* __restrict__ out) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -792,11 +796,9 @@ __global__ __launch_bounds__(256) void split_weights_f16_kernel(const float* __r
     const float x = k < K ? w[n * s_n + k * s_k] * scale : 0.f;
     const _Float16 h0 = (_Float16)x;
     const _Float16 h1 = (_Float16)(x - (float)h0);
-    const _Float16 h2 = (_Float16)((float)h0 * (1.0f / 2048.0f));
-    const long long o = ((long long)(k >> 4) * 3 * N + n) * 16 + (k & 15);
+    const long long o = ((long long)(k >> 4) * 2 * N + n) * 16 + (k & 15);
     out[o] = __builtin_bit_cast(unsigned short, h0);
     out[o + (long long)N * 16] = __builtin_bit_cast(unsigned short, h1);
-    out[o + 2LL * N * 16] = __builtin_bit_cast(unsigned short, h2);
 }
 
 }  // namespace

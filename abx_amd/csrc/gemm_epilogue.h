@@ -64,17 +64,16 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             for (int c = 0; c < 4; ++c) v[c] += rv[c];
         }
         if (g.C_split) {
-            // output as the pre-split f16 operand image of the next contraction: channels below c_split_nA are its A side (two
-            // pieces of v 2^-4: a0, a1 = (v' - a0) 2^11; plane 2 is not written), the others its B side (three planes of v 2^4:
-            // p0, p1 = v' - p0, p2 = p0 2^-11) - common.h split2h / split2w
-            unsigned a0, a1, a2 = 0, b0, b1, b2 = 0;
-            const bool a_side = n_idx < g.c_split_nA;
-            if (a_side) {
+            // output as the pre-split f16 operand image of the next contraction, two planes per channel: channels below c_split_nA are
+            // its A side (pieces of v 2^-4: a0, a1 = (v' - a0) 2^11), the others its B side (planes of v 2^4: p0, p1 = v' - p0) -
+            // common.h split2h / split2b
+            unsigned a0, a1, b0, b1;
+            if (n_idx < g.c_split_nA) {
                 split2h(v[0], v[1], a0, a1);
                 split2h(v[2], v[3], b0, b1);
             } else {
-                split2w(v[0], v[1], a0, a1, a2);
-                split2w(v[2], v[3], b0, b1, b2);
+                split2b(v[0], v[1], a0, a1);
+                split2b(v[2], v[3], b0, b1);
             }
             // m = i * L + k: the planes are the k-tiled operand image [k/16][plane][i][16] of the following contraction
             int ii, kk;
@@ -89,11 +88,10 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             if (c_vec && cnt == 4) {
                 *reinterpret_cast<u32x2*>(cs) = u32x2{a0, b0};
                 *reinterpret_cast<u32x2*>(cs + g.sCp) = u32x2{a1, b1};
-                if (!a_side) *reinterpret_cast<u32x2*>(cs + 2 * g.sCp) = u32x2{a2, b2};
             } else {
-                const unsigned pa[3] = {a0, a1, a2}, pb[3] = {b0, b1, b2};
+                const unsigned pa[2] = {a0, a1}, pb[2] = {b0, b1};
 #pragma unroll
-                for (int p = 0; p < (a_side ? 2 : 3); ++p) {
+                for (int p = 0; p < 2; ++p) {
                     unsigned short* o = cs + p * g.sCp;
                     if (cnt > 0) o[0] = (unsigned short)(pa[p] & 0xffffu);
                     if (cnt > 1) o[1] = (unsigned short)(pa[p] >> 16);

@@ -337,7 +337,7 @@ class Engine:
                 zin, zout = (z3, zb) if outgoing else (zb, z3)
                 # one GEMM: [left | right] projections * sigmoid(their gates) * pair mask -> plane operands of the contraction
                 KT = (Lp + 15) // 16
-                lrp = ws.get('tm_lr', (Bc, 256, KT, 3, L, 16), torch.int16, zero=(Lp % 16 != 0))
+                lrp = ws.get('tm_lr', (Bc, 256, KT, 2, L, 16), torch.int16, zero=(Lp % 16 != 0))
                 if pad is None:
                     pm = pmask
                 else:

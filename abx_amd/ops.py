@@ -109,15 +109,16 @@ def permute_k16(Wt):
 
 
 class WeightPlanes(torch.Tensor):
-    """float16 tensor [Kp/16][3][N][16] of split weight planes + the power-of-two exponent they were scaled with (`w_exp`)."""
+    """float16 tensor [Kp/16][2][N][16] of split weight planes + the power-of-two exponent they were scaled with (`w_exp`)."""
     w_exp = 0
     __torch_function__ = torch._C._disabled_torch_function_impl     # a plain data carrier: no dispatch overhead on .stride() / .shape
 
 
 def split_weights(Wt):
-    """Wt (K, N) packed weight (n-contiguous) -> WeightPlanes [Kp/16][3][N][16] float16: the k-tiled operand image of the split-f16
+    """Wt (K, N) packed weight (n-contiguous) -> WeightPlanes [Kp/16][2][N][16] float16: the k-tiled operand image of the split-f16
     weight GEMMs (AbxGemm.b_f16, include/abx_hip.h): with w' = w * 2^w_exp, max|w'| in [2^13, 2^14):
-    p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 * 2^-11);  w' = p0 + p1 up to 2^-23 |w'| (+ 2^-25 absolute).  One host sync (the
+    p0 = f16(w'), p1 = f16(w' - p0) (the kernels derive p2 = f16(p0 * 2^-11) in registers);  w' = p0 + p1 up to 2^-23 |w'| (+ 2^-25
+    absolute).  One host sync (the
     maximum) per call: weights are packed once, outside any graph capture.  Kp = K rounded up to 16."""
     K, N = Wt.shape
     _f32(Wt)
@@ -127,7 +128,7 @@ def split_weights(Wt):
         raise ValueError('split_weights: non-finite weight')
     w_exp = 14 - math.frexp(amax)[1] if amax > 0 else 0
     w_exp = max(-100, min(100, w_exp))
-    out = torch.empty(Kp // 16, 3, N, 16, device=Wt.device, dtype=torch.float16)
+    out = torch.empty(Kp // 16, 2, N, 16, device=Wt.device, dtype=torch.float16)
     check(_lib.load().abx_split_weights_f16(_p(Wt), Wt.stride(1), Wt.stride(0), N, K, w_exp, _p(out), _stream()), 'abx_split_weights_f16')
     out = out.as_subclass(WeightPlanes)
     out.w_exp = w_exp
@@ -141,7 +142,7 @@ def weights_to_float(w3):
 
 
 def _weight_planes(w3, N, K=None, what='B3'):
-    assert isinstance(w3, WeightPlanes) and w3.dtype == torch.float16 and w3.is_contiguous() and w3.shape[1:] == (3, N, 16), \
+    assert isinstance(w3, WeightPlanes) and w3.dtype == torch.float16 and w3.is_contiguous() and w3.shape[1:] == (2, N, 16), \
         f'{what}: WeightPlanes (ops.split_weights) of N = {N} expected'
     assert K is None or w3.shape[0] * 16 >= K
     return w3
@@ -153,9 +154,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
     tensors laid out like Cout (n-contiguous, or m-contiguous when Cout is stored transposed).
-    Split-f16 operands (include/abx_hip.h, "Split-f16 operands"): B3 (K/16,3,N,16) = split_weights(B), float16 weight planes;
-    A (b,K/16,3,M,16) and B (b,K/16,3,N,16) both int16 tensors of activation images: the TriangleMultiplication contraction (A: the
-    two pieces in planes 0, 1; B: three planes); Cout (b,N,L/16,3,L,16) int16 (M = L*L pair rows, m = i*L + k): the output is written
+    Split-f16 operands (include/abx_hip.h, "Split-f16 operands"): B3 (K/16,2,N,16) = split_weights(B), float16 weight planes;
+    A (b,K/16,2,M,16) and B (b,K/16,2,N,16) both int16 tensors of activation images: the TriangleMultiplication contraction (A: the
+    pieces a0, a1; B: the planes p0, p1); Cout (b,N,L/16,2,L,16) int16 (M = L*L pair rows, m = i*L + k): the output is written
     as the operand image [n][k/16][plane][i][16] of that contraction (transposed store), channels n < c_split_nA as its A side, the
     others as its B side.  a_pair_transpose=L: GEMM row i*L+k reads A row k*L+i.
     glu=True: B holds (value, gate) column pairs (pack_glu_weights); Cout has N/2 channels = value * sigmoid(gate).
@@ -170,7 +171,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
-    if a_planes and A.dim() == 6:      # (Bo, Bi, K/16, 3, M, 16): two-level batch (channel slices of a wider per-sample tensor)
+    if a_planes and A.dim() == 6:      # (Bo, Bi, K/16, 2, M, 16): two-level batch (channel slices of a wider per-sample tensor)
         assert B.dtype == torch.int16 and B.dim() == 6 and B.shape[:2] == A.shape[:2]
         g.batch_inner, g.sA3i, g.sB3i = A.shape[1], A.stride(1), B.stride(1)
         bo_a, bo_b = A.stride(0), B.stride(0)
@@ -179,7 +180,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     else:
         bo_a = bo_b = None
     if a_planes:
-        assert A.dim() == 5 and A.shape[2] == 3 and A.shape[4] == 16 and A.stride(4) == 1
+        assert A.dim() == 5 and A.shape[2] == 2 and A.shape[4] == 16 and A.stride(4) == 1
         nb, KT, _, M, _ = A.shape
         K = KT * 16
         g.A_split, g.sA3b, g.sA3k, g.sA3p, g.sA3m = _p(A), (A.stride(0) if nb > 1 else 0), A.stride(1), A.stride(2), A.stride(3)
@@ -197,7 +198,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
             if c_split_tile:        # GEMM rows = pair positions in (8 i x 16 k) blocks (AbxGemm.c_split_tile)
                 M = ((pair[0] + 7) // 8 * 8) * ((pair[1] + 15) // 16 * 16)
     if b_planes:
-        assert B.dim() == 5 and B.shape[2] == 3 and B.shape[4] == 16 and B.stride(4) == 1 and B.shape[1] * 16 == K and B.shape[0] == nb
+        assert B.dim() == 5 and B.shape[2] == 2 and B.shape[4] == 16 and B.stride(4) == 1 and B.shape[1] * 16 == K and B.shape[0] == nb
         N = B.shape[3]
         g.B_split, g.sB3b, g.sB3k, g.sB3p, g.sB3n = _p(B), (B.stride(0) if nb > 1 else 0), B.stride(1), B.stride(2), B.stride(3)
         if bo_b is not None:
@@ -222,7 +223,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     if c_planes:
         L = Cout.shape[4]
         Lp = pair[1] if pair is not None else L
-        assert Cout.dim() == 6 and Cout.shape == (nb, No, (Lp + 15) // 16, 3, L, 16) and (c_split_tile or M == L * Lp), (Cout.shape, nb, M, N)
+        assert Cout.dim() == 6 and Cout.shape == (nb, No, (Lp + 15) // 16, 2, L, 16) and (c_split_tile or M == L * Lp), (Cout.shape, nb, M, N)
         assert not c_split_tile or (a_pair and pair is not None), 'c_split_tile: the A rows come through the pair-row map (a_pair, pair=(L, Lp))'
         assert Cout.stride(5) == 1 and Cout.stride(4) == 16
         g.C_split, g.sCb, g.sCm, g.sCk, g.sCp, g.c_split_L = _p(Cout), (Cout.stride(0) if nb > 1 else 0), Cout.stride(1), Cout.stride(2), Cout.stride(3), Lp
@@ -307,7 +308,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
 
 
 def planes_to_float(p, a_side, dim=0):
-    """int16 activation images (size 3 along `dim`) of the contraction -> the float32 value they stand for: A side (p0 + p1 2^-11) 2^4,
+    """int16 activation images (size 2 along `dim`) of the contraction -> the float32 value they stand for: A side (p0 + p1 2^-11) 2^4,
     B side (p0 + p1) 2^-4."""
     h = p.view(torch.float16).float()
     p0, p1 = h.select(dim, 0), h.select(dim, 1)

@@ -75,31 +75,31 @@ class OpTimer:
     def _sig(self, name, args, kw):
         if name == 'gemm':
             A, B, C = args[0], args[1], args[2]
-            if A.dtype == torch.int16:          # k-tiled f16 operand images (b, K/16, 3, rows, 16): the tri-mul contraction
+            if A.dtype == torch.int16:          # k-tiled f16 operand images (b, K/16, 2, rows, 16): the tri-mul contraction
                 if A.dim() == 6:        # two-level batch (channel slices)
                     nb, M, K, N = A.shape[0] * A.shape[1], A.shape[4], A.shape[2] * 16, B.shape[4]
                 else:
                     nb, M, K, N = A.shape[0], A.shape[3], A.shape[1] * 16, B.shape[3]
                 kern = self.ops.gemm_kernel_name(M, N, K, nb, split=True, a_split=True, exact=kw.get('exact'))
-                return kern, 2.0 * nb * M * N * K, nb * (6.0 * (M + N) * K + 4.0 * M * N)
+                return kern, 2.0 * nb * M * N * K, nb * (4.0 * (M + N) * K + 4.0 * M * N)
             nb = A.shape[0] if A.dim() == 3 else 1
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
             c_planes = C.dtype == torch.int16
             if kw.get('mlp') is not None:       # fused transition: both layers' flops, rows in + rows out of HBM
                 N2 = kw['mlp'][0].shape[2]
-                return 'gemm3_mlp_kernel<2>', 2.0 * nb * M * N * (K + N2), 4.0 * nb * M * (K + 2 * N2) + 6.0 * N * (K + N2)
+                return 'gemm3_mlp_kernel<2>', 2.0 * nb * M * N * (K + N2), 4.0 * nb * M * (K + 2 * N2) + 4.0 * N * (K + N2)
             kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
                                              split=kw.get('B3') is not None, exact=kw.get('exact'), dual=kw.get('dual') is not None,
                                              out_ln=kw.get('out_ln') is not None)
             K2 = kw['dual'][0].shape[-1] if kw.get('dual') is not None else 0
-            return kern, 2.0 * nb * M * N * (K + K2), 4.0 * nb * (M * (K + K2)) + (6.0 if c_planes else 4.0) * nb * M * N + 4.0 * (K + K2) * N
+            return kern, 2.0 * nb * M * N * (K + K2), 4.0 * nb * (M * (K + K2)) + 4.0 * nb * M * N + 4.0 * (K + K2) * N
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
             return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
         if name == 'ipa_tail':
             M, K1 = args[0].shape
-            return 'ipa_tail_kernel', 2.0 * M * 256 * (K1 + 3 * 256), 4.0 * M * (K1 + 2 * 256) + 6.0 * 256 * (K1 + 3 * 256)
+            return 'ipa_tail_kernel', 2.0 * M * 256 * (K1 + 3 * 256), 4.0 * M * (K1 + 2 * 256) + 4.0 * 256 * (K1 + 3 * 256)
         if name == 'ipa_attn':
             Bc, L = args[10], args[11]
             return 'ipa_attn (weights + pair slab kernels)', 2.0 * Bc * L * L * 12 * (28 + 40 + 128), 4.0 * Bc * L * L * (128 + 12 + 24)

@@ -64,7 +64,8 @@ typedef struct AbxGemm {
     /* Split-f16 operands and output (csrc/gemm3.hip): every fp32 product of the large contractions is evaluated on the float16
      * matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate) from 3 exact partial products:
      *     x y  ~  a1 p2 + a0 p1 + a0 p0      A side (two pieces):  x' = x 2^-4,  a0 = f16(x'),  a1 = f16((x' - a0) 2^11)
-     *                                        B side (three planes): y' = y 2^e,   p0 = f16(y'),  p1 = f16(y' - p0),  p2 = f16(p0 2^-11)
+     *                                        B side (two planes):   y' = y 2^e,   p0 = f16(y'),  p1 = f16(y' - p0);  p2 = f16(p0 2^-11)
+ *                                                               is derived in registers (one rounding of an exact value)
      * A piece pair carries 23 significant bits (|x' - a0 - a1 2^-11| <= 2^-23 |x'| worst case, 2^-25 on average), the dropped term
      * a1 p1 2^-11 is <= 2^-22 |x y| with mean zero: measured as accurate as the exact fp32 MFMA kernel
      * (tests/test_gpu_kernels.py::test_gemm_split_accuracy_vs_exact).  A-side range: |x| < 2^20, full relative precision from
@@ -75,10 +76,10 @@ typedef struct AbxGemm {
      *   Activations on both sides (A_split and B_split: the TriangleMultiplication contraction): images written by the C_split
      *     epilogue of the projection GEMM, B side with the fixed e = 4 (|y| < 4095; 2^-29 absolute below 2^-6); b_f16 = 0.
      * The planes are k-TILED: element (row, k) of plane p at base + batch*sXb + (k/16)*sXk + p*sXp + row*sXr + k%16 (16-bit units),
-     * i.e. the 16 k of one k-tile are contiguous (abx_split_weights_f16 writes [Kp/16][3][N][16]: sB3k = 3*N*16, sB3p = N*16,
+     * i.e. the 16 k of one k-tile are contiguous (abx_split_weights_f16 writes [Kp/16][2][N][16]: sB3k = 2*N*16, sB3p = N*16,
      * sB3n = 16). */
     const unsigned short* B_split; long long sB3p, sB3n, sB3k, sB3b;   /* B as planes (sB3b = 0: shared weights); used instead of B */
-    const unsigned short* A_split; long long sA3p, sA3m, sA3k, sA3b;   /* A as planes (pieces a0, a1 in planes 0, 1), used instead of A:
+    const unsigned short* A_split; long long sA3p, sA3m, sA3k, sA3b;   /* A as planes (pieces a0, a1), used instead of A:
                                                       the TriangleMultiplication contraction takes both operands this way (K % 16 == 0) */
     int batch_inner; long long sA3i, sB3i;         /* batch_inner > 0: two-level batch of the plane operands, entry b sits at
                                                       (b / batch_inner) * sX3b + (b % batch_inner) * sX3i (left / right channels of
@@ -88,7 +89,7 @@ typedef struct AbxGemm {
                                                       + k%16 (KT = ceil(pair_Lp / 16)): 64 contiguous plane bytes per store instruction and
                                                       channel.  rowscale stays indexed [i * pair_Lp + k] */
     int c_split_nA;                                /* with C_split: output channels n < c_split_nA are written as the A side of the
-                                                      following contraction (two pieces), the others as its B side (three planes) */
+                                                      following contraction (pieces a0, a1), the others as its B side (planes p0, p1): two planes per channel */
     unsigned short* C_split; long long sCp, sCk; int c_split_L;   /* write the output as planes instead of C, laid out as the
                                                       k-tiled OPERAND of the following contraction: with m = i*L + k (L =
                                                       c_split_L, M % L == 0, transposed store only), element (m, n) of plane p goes to
@@ -117,7 +118,7 @@ typedef struct AbxGemm {
     /* Fused two-layer transition (split-f16 path, plain store; seqformer.py:358-376 LayerNorm -> Linear -> ReLU -> Linear + residual):
      * mlp != 0:  C = relu(LN(A) B + bias) B2 + bias2 (+ resid), the N-wide hidden activations never leave the CU.  A k-contiguous
      * fp32 with inline LayerNorm (ln_csum, ln_stats NULL), act = 1; N % 16 == 0 = hidden width; C / resid have N2 <= 192 columns;
-     * B2_split = planes of the second layer's weights [N/16][3][N2][16] (strides sB23k / sB23p / sB23n) whose 16 k of every k-tile
+     * B2_split = planes of the second layer's weights [N/16][2][N2][16] (strides sB23k / sB23p / sB23n) whose 16 k of every k-tile
      * are stored in the order 0-3, 8-11, 4-7, 12-15 (the accumulator layout of the first GEMM feeds the second one from
      * registers); C may alias resid and A (a block reads its rows before it writes them). */
     int mlp, N2;
@@ -142,14 +143,14 @@ typedef struct AbxGemm {
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
-/* fp32 weights W[n][k] -> out[Kp/16][3][N][16] float16 planes of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
+/* fp32 weights W[n][k] -> out[Kp/16][2][N][16] float16 planes (p0, p1) of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
  * scale_exp = 14 - e with max|w| = m * 2^e, 0.5 <= m < 1 (so that max|w| * 2^scale_exp is in [2^13, 2^14)) */
 int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out, hipStream_t stream);
 /* The tail of an IPA layer on the single representation s (M = B*L rows of C = 256 channels), reference score_network.py:126-163 /
  * folding.py (per layer, after the attention): s <- LN1(s + feat W_final + b_final); s <- LN2(s + relu(relu(s W0 + b0) W2 + b2) W4 + b4)
  * (attention_module.final_proj + attention_layer_norm + transition_module.0/.2/.4 + transition_layer_norm) in ONE launch: the
  * intermediate activations never leave the CU (split-f16 arithmetic of AbxGemm; weights as abx_split_weights_f16 planes
- * [K/16][3][256][16] with their exponents).  s is updated in place. */
+ * [K/16][2][256][16] with their exponents).  s is updated in place. */
 typedef struct AbxIpaTail {
     const float* feat; long long s_feat;           /* IPA features (M, K1), row stride in floats (K1 % 16 == 0) */
     float* s; long long s_s;                       /* (M, 256) in / out */
@@ -194,7 +195,7 @@ typedef struct AbxTriAttn {
     float* out; long long ob, os, ol;               /* out (b,s,l,h*D+d) */
     int B, S, L, H, D;                              /* D must be 48 */
     float scale;
-    int exact;                                      /* 0: split-f16 matrix-core kernel (see AbxGemm: keys / values staged as B-side planes with
+    int exact;                                      /* 0: split-f16 matrix-core kernel (see AbxGemm: keys / values staged as B-side planes (p2 kept in LDS) with
                                                        e = 4, |k|, |v| < 4095; queries and softmax weights as A-side pieces; any L);
                                                        1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
     unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernel) */

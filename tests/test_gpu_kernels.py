@@ -115,22 +115,21 @@ def test_gemm_ln_gate_resid_rowscale(ops):
 
 
 def _host_planes(x, a_side):
-    """fp32 tensor (..., rows, K) -> int16 k-tiled f16 operand image (..., K/16, 3, rows, 16) of the plane x plane contraction
-    (include/abx_hip.h): A side x' = x / 16, (a0, (x' - a0) 2^11, 0); B side x' = 16 x, (p0, x' - p0, p0 2^-11); RNE pieces."""
+    """fp32 tensor (..., rows, K) -> int16 k-tiled f16 operand image (..., K/16, 2, rows, 16) of the plane x plane contraction
+    (include/abx_hip.h): A side x' = x / 16, (a0, (x' - a0) 2^11); B side x' = 16 x, (p0, x' - p0); RNE pieces."""
     xs = x / 16 if a_side else x * 16
     p0 = xs.half()
     r = xs - p0.float()
     p1 = (r * 2048).half() if a_side else r.half()
-    p2 = torch.zeros_like(p0) if a_side else (p0.float() / 2048).half()
-    pl = torch.stack([p0.view(torch.int16), p1.view(torch.int16), p2.view(torch.int16)], dim=-3)      # (..., 3, rows, K)
+    pl = torch.stack([p0.view(torch.int16), p1.view(torch.int16)], dim=-3)                            # (..., 2, rows, K)
     rows, K = x.shape[-2:]
     assert K % 16 == 0
-    pl = pl.reshape(*x.shape[:-2], 3, rows, K // 16, 16)
-    return pl.movedim(-2, -4).contiguous()                                                           # (..., K/16, 3, rows, 16)
+    pl = pl.reshape(*x.shape[:-2], 2, rows, K // 16, 16)
+    return pl.movedim(-2, -4).contiguous()                                                           # (..., K/16, 2, rows, 16)
 
 
 def _planes_to_f64(pl, a_side):
-    """value of an operand image: (..., K/16, 3, rows, 16) int16 -> float64 (..., rows, K)."""
+    """value of an operand image: (..., K/16, 2, rows, 16) int16 -> float64 (..., rows, K)."""
     h = pl.view(torch.float16).double()
     f = (h.select(-3, 0) + h.select(-3, 1) / 2048) * 16 if a_side else (h.select(-3, 0) + h.select(-3, 1)) / 16   # (..., K/16, rows, 16)
     return f.movedim(-3, -2).reshape(*f.shape[:-3], f.shape[-2], -1)
@@ -138,17 +137,17 @@ def _planes_to_f64(pl, a_side):
 
 def test_gemm_split_f16_weight_image(ops):
     """abx_split_weights_f16 (the operand image of the split-f16 weight GEMMs): with w' = w 2^w_exp, max|w'| in [2^13, 2^14):
-    p0 = f16(w'), p1 = f16(w' - p0), p2 = f16(p0 2^-11), bit for bit the host's round-to-nearest conversions; p0 + p1 = w' to
+    p0 = f16(w'), p1 = f16(w' - p0), bit for bit the host's round-to-nearest conversions; p0 + p1 = w' to
     2^-23 |w'| + 2^-25 (two 11-bit pieces and a sign: 23 significant bits, worst case); k-tiled, zero padded rows."""
     for K, N, scale in ((192, 768, 1.0), (52, 70, 1e-3), (128, 192, 300.0)):
         Wt = (scale * torch.randn(K, N, generator=g(200)) * torch.logspace(-6, 0, N)[None]).to(DEV)
         w3 = ops.split_weights(Wt)
         Kp = (K + 15) // 16 * 16
-        assert w3.shape == (Kp // 16, 3, N, 16) and w3.dtype == torch.float16
+        assert w3.shape == (Kp // 16, 2, N, 16) and w3.dtype == torch.float16
         wp = torch.zeros(N, Kp); wp[:, :K] = Wt.cpu().t() * 2.0 ** w3.w_exp
         assert 2.0 ** 13 <= float(wp.abs().max()) < 2.0 ** 14
-        p0 = wp.half(); p1 = (wp - p0.float()).half(); p2 = (p0.float() / 2048).half()
-        host = torch.stack([p0, p1, p2], 0).reshape(3, N, Kp // 16, 16).permute(2, 0, 1, 3)
+        p0 = wp.half(); p1 = (wp - p0.float()).half()
+        host = torch.stack([p0, p1], 0).reshape(2, N, Kp // 16, 16).permute(2, 0, 1, 3)
         assert torch.equal(torch.Tensor(w3.cpu()).view(torch.int16), host.contiguous().view(torch.int16))
         back = p0.double() + p1.double()
         assert ((back - wp.double()).abs() <= 2.0 ** -23 * wp.double().abs() + 2.0 ** -25).all()
@@ -357,7 +356,7 @@ def test_gemm_split_plane_output_and_pair_transpose(ops):
     proj = (ln @ W.double().t() + bias.double()) * pm.double()[..., None]                     # (B, L, L, C)
     for transpose in (False, True):
         zsrc = Z.to(DEV).view(B_, LL, K)
-        planes = torch.zeros(B_, C_, (L_ + 15) // 16, 3, L_, 16, dtype=torch.int16, device=DEV)
+        planes = torch.zeros(B_, C_, (L_ + 15) // 16, 2, L_, 16, dtype=torch.int16, device=DEV)
         # gates / mask are indexed by the GEMM row (i.e. already in the transposed order when a_pair_transpose is used)
         pmv = (pm.transpose(1, 2) if transpose else pm).reshape(-1).contiguous().to(DEV)
         ops.gemm(zsrc, Wt, planes, bias=bias2, ln=(None, csum), rowscale=pmv, c_split_nA=64,
@@ -399,7 +398,7 @@ def test_gemm_split_glu_and_two_level_batch(ops):
     val = (ln @ Wv.double().t() + bv.double()) * torch.sigmoid(ln @ Wg.double().t() + bg.double()) * pm.double()[..., None]   # (B,L,L,C)
     KT = (L_ + 15) // 16
     for transpose in (False, True):
-        planes = torch.zeros(B_, C_, KT, 3, L_, 16, dtype=torch.int16, device=DEV)
+        planes = torch.zeros(B_, C_, KT, 2, L_, 16, dtype=torch.int16, device=DEV)
         ops.gemm(Z.to(DEV).view(B_, LL, K), Wt, planes, bias=bias2, ln=(None, csum), rowscale=pm.reshape(-1).contiguous().to(DEV),
                  glu=True, B3=w3, a_pair_transpose=L_ if transpose else 0, c_split_nA=128)
         pc = planes.cpu()
@@ -408,7 +407,7 @@ def test_gemm_split_glu_and_two_level_batch(ops):
         e = float((got - want).abs().max() / want.abs().max())
         assert e < 3e-6, (transpose, e)
         # the same GEMM with its rows in (8 i x 16 k) block order (AbxGemm.c_split_tile: what the model runs): identical images
-        planes_t = torch.zeros(B_, C_, KT, 3, L_, 16, dtype=torch.int16, device=DEV)
+        planes_t = torch.zeros(B_, C_, KT, 2, L_, 16, dtype=torch.int16, device=DEV)
         ops.gemm(Z.to(DEV).view(B_, LL, K), Wt, planes_t, bias=bias2, ln=(None, csum), rowscale=pm.reshape(-1).contiguous().to(DEV),
                  glu=True, B3=w3, a_pair_transpose=L_ if transpose else 0, c_split_nA=128, c_split_tile=True, pair=(L_, L_), a_pair=True)
         assert torch.equal(planes_t, planes), 'tile-ordered rows changed the plane images'

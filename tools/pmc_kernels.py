@@ -38,14 +38,14 @@ elif which == 'glu':
     z3, Wv, Wg = r(Bc, LL, 192), r(192, 256) / 14, r(192, 256) / 14
     W, b = ops.pack_glu_weights(Wv, Wg, r(256), r(256))
     W3 = ops.split_weights(W)
-    lrp = torch.zeros(Bc, 256, (L + 15) // 16, 3, L, 16, dtype=torch.int16, device=DEV)
+    lrp = torch.zeros(Bc, 256, (L + 15) // 16, 2, L, 16, dtype=torch.int16, device=DEV)
     pm = torch.ones(Bc * LL, device=DEV)
     for _ in range(REPS):
         ops.gemm(z3, W, lrp, bias=b, ln=(None, W.sum(0).contiguous()), B3=W3, rowscale=pm, glu=True, exact=2, c_split_nA=128,
                  c_split_tile=True, pair=(L, L), a_pair=True)
 elif which == 'contract':
     KT = (L + 15) // 16
-    lrp = (torch.randn(Bc, 256, KT, 3, L, 16, device=DEV) * 100).to(torch.int16)
+    lrp = (torch.randn(Bc, 256, KT, 2, L, 16, device=DEV) * 100).to(torch.int16)
     tz = torch.empty(Bc * 128, L, L, device=DEV)
     for _ in range(REPS):
         ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz, exact=2)

@@ -111,7 +111,7 @@ W2 = r(768, 192) / 28
 C2, W23 = torch.empty(M2, 192, device=DEV), ops.split_weights(W2)
 run('gemm3 128x192 N=192 K=768 (trans2)', lambda: ops.gemm(C, W2, C2, bias=None, resid=z, B3=W23, exact=2, clock_probe=acc), acc, 2.0 * M2 * 192 * 768)
 KT = (L + 15) // 16
-lrp = (torch.randn(Bc, 256, KT, 3, L, 16, device=DEV) * 100).to(torch.int16)
+lrp = (torch.randn(Bc, 256, KT, 2, L, 16, device=DEV) * 100).to(torch.int16)
 tz = torch.empty(Bc * 128, L, L, device=DEV)
 run('gemm3 contraction (planes)', lambda: ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz, exact=2, clock_probe=acc), acc, 2.0 * Bc * 128 * L * L * L)
 del lrp, tz

@@ -31,7 +31,7 @@ elif which == 'qkvg_exact':
     flops = 2.0 * M2 * 192 * 768
 elif which == 'contract':
     KT = (L + 15) // 16
-    lrp = (torch.randn(Bc, 256, KT, 3, L, 16, device=DEV) * 100).to(torch.int16)
+    lrp = (torch.randn(Bc, 256, KT, 2, L, 16, device=DEV) * 100).to(torch.int16)
     tz = torch.empty(Bc * 128, L, L, device=DEV)
     fn = lambda: ops.gemm(lrp[:, 0:128], lrp[:, 128:256], tz, exact=2)
     flops = 2.0 * Bc * 128 * L * L * L
