@@ -219,10 +219,11 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 // Same (b, row s, head h) decomposition, online softmax and swapped S^T product as tri_attn_kernel, with every fp32 product evaluated
 // from 3 exact f16 products (v_mfma_f32_16x16x32_f16, fp32 accumulate): keys / values are the plane side (16 k, 16 v as p0, p1,
 // p2 = p0 2^-11), queries and softmax weights the two-piece side (q / 16, P / 16 as a0, a1), so the products need no rescale.
-//   K, V of the row are split ONCE, while they are staged, in chunks of 128 keys, DOUBLE BUFFERED: the global loads of chunk
+//   K, V of the row are split ONCE, while they are staged, in chunks of 192 / 128 keys (p0, p1; p2 = p0 2^-11 is derived at the
+//   fragment: two planes per operand leave room for 192-key chunks, i.e. two chunks and two barriers at L = 352), DOUBLE BUFFERED: the global loads of chunk
 //   c + 1 are issued before the wave computes on chunk c and are split + written afterwards, ONE barrier per chunk.
-//     K planes [3][key][48 d] f16 (96-byte rows)   -> A operand of S^T = K Q^T          (lane: key, 8 consecutive d; ds_read_b128)
-//     V planes [3][key][48 d] f16 (same image)     -> A operand of O^T += V^T P         (lane: d, 8 keys) through the transposing
+//     K planes [2][key][48 d] f16 (96-byte rows)   -> A operand of S^T = K Q^T          (lane: key, 8 consecutive d; ds_read_b128)
+//     V planes [2][key][48 d] f16 (same image)     -> A operand of O^T += V^T P         (lane: d, 8 keys) through the transposing
 //                                                     LDS read ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 d] block
 //                                                     and lane n receives its column n; no transposed staging writes
 //   Q is split per query tile in registers; P per key tile in registers: the S^T accumulators of two 16-key sub-blocks (lane:
@@ -280,7 +281,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
 template <int MAXQ, int KC4, bool DB, int NTH, bool PROD>
 __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     constexpr int PLN = KC4 * RST;           // bytes per plane
-    constexpr int BUF4 = 6 * PLN;            // K planes + V planes of one chunk
+    constexpr int BUF4 = 4 * PLN;            // K planes + V planes (p0, p1 each; p2 = p0 2^-11 is derived at the fragment) of one chunk
     constexpr int NIT = (KC4 * (TD / 4) + NTH - 1) / NTH;     // staging items per thread and chunk
     // PROD: the last wave is a PRODUCER - it alone stages the next chunk (loads, splits, LDS writes) while the other NCW waves
     // compute.  Vector-memory results return in issue order, so a consumer that also carried staging loads (HBM latency) waited for
@@ -353,22 +354,20 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     };
     auto stage_write = [&](int c0, int buf, int idx) {
         char* Kp = lds + buf * BUF4;
-        char* Vp = Kp + 3 * PLN;
+        char* Vp = Kp + 2 * PLN;
         const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
         if (kk >= KC4) return;
-        unsigned a0, a1, a2, b0, b1, b2;
-        split2w(kreg[0], kreg[1], a0, a1, a2);
-        split2w(kreg[2], kreg[3], b0, b1, b2);
+        unsigned a0, a1, b0, b1;
+        split2b(kreg[0], kreg[1], a0, a1);
+        split2b(kreg[2], kreg[3], b0, b1);
         char* kd = Kp + kk * RST + c4 * 8;
         *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
-        *reinterpret_cast<u32x2*>(kd + 2 * PLN) = u32x2{a2, b2};
-        split2w(vreg[0], vreg[1], a0, a1, a2);
-        split2w(vreg[2], vreg[3], b0, b1, b2);
+        split2b(vreg[0], vreg[1], a0, a1);
+        split2b(vreg[2], vreg[3], b0, b1);
         char* vd = Vp + kk * RST + c4 * 8;
         *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
         *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
-        *reinterpret_cast<u32x2*>(vd + 2 * PLN) = u32x2{a2, b2};
     };
     // (key-mask clamps are applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit by
     // finfo.min: every finite logit is >= finfo.min, so min() is that replacement), -inf beyond L)
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
             __syncthreads();
         }
         const char* Kp = lds + buf * BUF4;
-        const char* Vp = Kp + 3 * PLN;
+        const char* Vp = Kp + 2 * PLN;
         const float* Ms = Msb + buf * KC4;
         const bool masked_chunk = any_masked;                   // (per sample: a masked key anywhere -> clamp every tile)
 
@@ -484,11 +483,13 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
                     const char* kr = Kp + (k0 + sub * 16 + lq) * RST + g * 16;
                     f16x8 ka[2][3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < 2; ++p) {
                         ka[0][p] = *reinterpret_cast<const f16x8*>(kr + p * PLN);
                         // d 32..47: lane groups 0, 1 read d 32 + 8g; groups 2, 3 re-read a valid address and are multiplied by Q = 0
                         ka[1][p] = *reinterpret_cast<const f16x8*>(kr + p * PLN + 64 - (g >> 1) * 32);
                     }
+                    ka[0][2] = __builtin_bit_cast(f16x8, f16x8_lo(__builtin_bit_cast(u32x4, ka[0][0])));
+                    ka[1][2] = __builtin_bit_cast(f16x8, f16x8_lo(__builtin_bit_cast(u32x4, ka[1][0])));
                     f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int term = 0; term < T::N; ++term)
@@ -560,11 +561,12 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
                     for (int d = 0; d < 3; ++d) {
                         f16x8 vb[3];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
+                        for (int p = 0; p < 2; ++p) {
                             const s16x4 lo = lds_tr16(vr + p * PLN + d * 32);
                             const s16x4 hi = lds_tr16(vr + p * PLN + d * 32 + 16 * RST);
                             vb[p] = __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
                         }
+                        vb[2] = __builtin_bit_cast(f16x8, f16x8_lo(__builtin_bit_cast(u32x4, vb[0])));
 #pragma unroll
                         for (int term = 0; term < T::N; ++term)
                             oo[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[T::B[term]], pa[T::A[term]], oo[d], 0, 0, 0);
@@ -782,8 +784,9 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
             hipLaunchKernelGGL(kern, grid, block, lds4, st, aa);
             return abx_check_launch("abx_tri_attn_fwd");
         };
-        auto lds_of = [](int kc, bool db) { return (size_t)(db ? 2 : 1) * (6 * kc * RST + kc * sizeof(float)); };
-        if (prod) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, true>, lds_of(128, true));
+        auto lds_of = [](int kc, bool db) { return (size_t)(db ? 2 : 1) * (4 * kc * RST + kc * sizeof(float)); };
+        if (prod && (a.tune & 2)) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, true>, lds_of(128, true));   // benchmarking
+        if (prod) return launch(&tri_attn4_kernel<2, 192, true, TRI_THREADS, true>, lds_of(192, true));
         return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, false>, lds_of(128, true));
     }
     const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);

@@ -362,7 +362,7 @@ def tri_attn_kernel_name(L, exact=None):
     nqt = (L + 15) // 16
     parts = (nqt + 23) // 24
     prod = (nqt + parts - 1) // parts <= 22
-    return f"tri_attn4_kernel<2, 128, true, 768, {'true' if prod else 'false'}>"
+    return 'tri_attn4_kernel<2, 192, true, 768, true>' if prod else 'tri_attn4_kernel<2, 128, true, 768, false>'
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):

@@ -195,11 +195,11 @@ typedef struct AbxTriAttn {
     float* out; long long ob, os, ol;               /* out (b,s,l,h*D+d) */
     int B, S, L, H, D;                              /* D must be 48 */
     float scale;
-    int exact;                                      /* 0: split-f16 matrix-core kernel (see AbxGemm: keys / values staged as B-side planes (p2 kept in LDS) with
+    int exact;                                      /* 0: split-f16 matrix-core kernel (see AbxGemm: keys / values staged as B-side planes with
                                                        e = 4, |k|, |v| < 4095; queries and softmax weights as A-side pieces; any L);
                                                        1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
     unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernel) */
-    int tune;                                       /* 0 = library default; bit 0: never the producer-wave variant (benchmarking;
+    int tune;                                       /* 0 = library default; bit 0: never the producer-wave variant, bit 1: its 128-key chunks (benchmarking;
                                                        all variants give bit-identical results) */
     int q_parts, row_groups;                        /* filled by the library */
 } AbxTriAttn;
