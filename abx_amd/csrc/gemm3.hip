@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
 // row does not depend on the batch (one instantiation for every size).
 constexpr int IT_C = 256;
 constexpr int IT_ASTR = IT_C * 4 + 16;                                      // bytes per activation row in LDS
-constexpr int IT_RING = 3;
+constexpr int IT_RING = 4;
 constexpr int IT_OPER = IT_RING * (4096 + 2 * IT_C * 32);                   // main-loop stages: A 3 x 4 KB (padded) + weights 3 x 16 KB
 constexpr int IT_LDS = IT_OPER + 2 * 32 * IT_ASTR + 2 * 4 * 32 * 4;
 
