@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-O=gpurun_out/r03h; mkdir -p $O
+O=gpurun_out/r03i; mkdir -p $O
 python bench.py --steps 4 --warmup 2 > $O/bench_L352.json 2> $O/bench_L352.err
 python bench.py --samples 12 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b12.json 2>> $O/bench.err
 python bench.py --samples 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b1.json 2>> $O/bench.err
@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/prof
 python tools/probes/clock_probe.py 3 > $O/clock.txt 2>&1
-bash tools/pmc_run.sh tri r03h_tri; python tools/pmc_reduce.py gpurun_out/r03h_tri tri_attn4 > $O/pmc_triattn4.txt
-bash tools/pmc_run.sh contract r03h_contract; python tools/pmc_reduce.py gpurun_out/r03h_contract gemm3_kernel > $O/pmc_contract.txt
-rm -rf gpurun_out/r03h_tri_* gpurun_out/r03h_contract_*
+bash tools/pmc_run.sh tri r03i_tri; python tools/pmc_reduce.py gpurun_out/r03i_tri tri_attn4 > $O/pmc_triattn4.txt
+bash tools/pmc_run.sh contract r03i_contract; python tools/pmc_reduce.py gpurun_out/r03i_contract gemm3_kernel > $O/pmc_contract.txt
+rm -rf gpurun_out/r03i_tri_* gpurun_out/r03i_contract_*
 ls -la $O
