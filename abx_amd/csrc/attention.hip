@@ -451,7 +451,6 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
             if (!PROD && sl < NIT && more) stage_load(c0 + KC4, tid + sl * NTH);
             if (qt < nqt) {
             // ---- Q fragments (B operand of the swapped product), pre-scaled, split: lane holds Q[q][dbase + 8g .. +7]
-            const int qrow = qt * 16 + lq;
             f16x8 qf[2][2];
             q_load(qt);
             {
