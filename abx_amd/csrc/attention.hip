@@ -235,6 +235,16 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 //   L = 352) stays in that XCD's L2 instead of being re-fetched from HBM by every row.
 constexpr int RST = 96;                  // bytes per key row of a plane: 32 * odd -> 16-byte fragment reads of 16 consecutive rows hit 64 banks
 
+// two-piece split of a pre-scaled pair without the 2^11 lift of the remainder (tri_attn8_kernel: operands scaled so that it stays a
+// normal float16 where it matters): x = p0 + p1 (+ <= 2^-24 |x|, or 2^-25 absolute below |x| = 2^-2)
+__device__ __forceinline__ void split2h_ns(float a, float b, unsigned& p0, unsigned& p1) {
+    const f32x2 x = {a, b};
+    const f16x2 h0 = __builtin_convertvector(x, f16x2);
+    const f32x2 r = x - __builtin_convertvector(h0, f32x2);
+    p0 = __builtin_bit_cast(unsigned, h0);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -610,6 +620,373 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     probe.finish();
 }
 
+// ---- triangle attention, paired query tiles (split-f16) ----------------------------------------------------------------------
+// Same decomposition, LDS image, staging and producer wave as tri_attn4_kernel; what changes is the work of a computing wave:
+//   * its two query tiles (2w and 2w + 1 of the row's <= 22) are walked TOGETHER over the key tiles, so every K / V fragment (LDS
+//     read + the p2 = p0 2^-11 derivation) serves two S^T / O^T tiles: half the LDS fragment traffic and half the v_pk_mul_f16 per
+//     product, and two independent accumulator chains per wave for the matrix pipe (a wave whose second tile lies beyond the row
+//     computes it on the clamped last query row and drops it: one code path);
+//   * the Q fragments of both tiles are loaded and split ONCE per row (tri_attn4 re-read and re-split them at every key chunk);
+//   * the pair bias is the INITIAL VALUE of the S^T accumulators (logits = bias log2 e + q.k): the loads of the next key tile's bias
+//     go into the registers the softmax weights of this tile have just left, under the PV matrix work - no bias registers beside
+//     the logits, no on-demand L2 round trip in front of the softmax;
+//   * the 48-wide head is 32 + 16 channels: the second k-step carries BOTH plane terms of channels 32..47 (lane groups 0, 1 read
+//     p0, groups 2, 3 read p1 of the same 16 channels, the query piece a0 is held twice), so a 16-key sub-block costs 5 matrix
+//     instructions instead of 6 and 3 fragment reads instead of 4 (the a1 p2 term of those channels: a1 is zero in groups 2, 3);
+//   * a last key tile with <= 32 keys runs half a tile (2 of 4 sub-blocks, 1 of 2 PV steps).
+// Rows with more than 22 query tiles are dealt to q_parts workgroups.
+// BVEC: the bias rows are key-contiguous, 16-byte aligned and padded to a multiple of 4 floats (what model/forward.py passes): one
+// 16-byte load per sub-block; otherwise (any strides, or no bias) the generic element loads
+template <int KC4, int NTH, bool BVEC>
+__global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
+    constexpr int PLN = KC4 * RST;           // bytes per plane
+    constexpr int BUF4 = 4 * PLN;            // K planes + V planes (p0, p1) of one chunk
+    constexpr int NIT = (KC4 * (TD / 4) + NTH - 1) / NTH;
+    constexpr int NCW = NTH / 64 - 1;        // computing waves; the last wave is the producer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    float* Msb = reinterpret_cast<float*>(lds + 2 * BUF4);       // [2][KC4] key-mask clamps of the chunks in flight
+    const int L = a.L;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int G = a.row_groups, rows_g = (a.S + G - 1) / G;
+    const int per_vp = rows_g * a.q_parts, sp = slot % per_vp;
+    const int vp = (slot / per_vp) * 8 + xcd;
+    const int bh = vp / G, s = (sp / a.q_parts) * G + vp % G, part = sp % a.q_parts;
+    if (bh >= a.B * a.H || s >= a.S) return;
+    const ClockProbe probe(a.clock_probe);
+#ifdef TRI8_STAMP
+    // diagnostic build: shader-clock stamps of wave 0 (slots 0..15) and of the producer wave (16..31) of the first 4096 workgroups
+    unsigned long long* st_buf = a.clock_probe ? a.clock_probe + 16 + (size_t)(blockIdx.x & 4095) * 32 : nullptr;
+    int st_n = 0;
+#define STAMP() { if (st_buf && (threadIdx.x & 63) == 0 && st_n < 16) st_buf[(threadIdx.x >= NCW * 64 ? 16 : 0) + st_n] = __builtin_amdgcn_s_memtime(); ++st_n; }
+#else
+#define STAMP() {}
+#endif
+    const int b = bh / a.H, h = bh % a.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave == 0) STAMP()
+    const int lq = lane & 15, g = lane >> 4;
+    const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
+    const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
+    const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
+    const int nqt_row = (L + 15) / 16, tpp = (nqt_row + a.q_parts - 1) / a.q_parts;
+    const int qt0 = part * tpp, nqt = min(nqt_row, qt0 + tpp);
+    const int bias_row = (int)a.bias_sq;
+    // scales (powers of two: exact): keys / values are staged as 16 x (planes p0, p1 = f16(x'), f16(x' - p0)); queries enter as
+    // q scale log2(e) 2^3, so the S^T accumulators hold 2^7 x the base-2 logits; softmax weights as P 2^8.  With these scales the
+    // second piece of a query / weight, f16(x' - f16(x')), needs no 2^11 lift (a float16 subnormal only below |x'| = 2^-2, where its
+    // 2^-25 absolute error is far below the rounding of the neighbouring products), so the three product terms a1 p0 + a0 p1 + a0 p0
+    // use the stored planes as they are: no p2 = p0 2^-11 derivation (56 v_pk_mul_f16 per tile pair in the first form of this kernel)
+    const float qscale = a.scale * LOG2E * 8.0f;
+    constexpr float SCL = 128.0f, ISCL = 1.0f / 128.0f, PEXP = 8.0f;
+    bool any_masked = false;
+    if (km) {
+        for (int j = lane; j < L; j += 64) any_masked |= km[j] == 0.f;
+        any_masked = __any(any_masked);
+    }
+
+    // ---- staging (all waves stage chunk 0; afterwards the producer wave alone)
+    auto stage_load = [&](int c0, int idx, f32x4& kreg, f32x4& vreg) __attribute__((always_inline)) {
+        const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
+        kreg = (f32x4){0.f, 0.f, 0.f, 0.f};
+        vreg = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kk < KC4 && c0 + kk < L) {
+            const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
+            kreg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.k + off));
+            vreg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.v + off));
+        }
+    };
+    auto stage_mask = [&](int c0, int buf, int t) __attribute__((always_inline)) {
+        Msb[buf * KC4 + t] = (c0 + t < L) ? ((!km || km[c0 + t] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+    };
+    auto stage_write = [&](int buf, int idx, const f32x4& kreg, const f32x4& vreg) __attribute__((always_inline)) {
+        char* Kp = lds + buf * BUF4;
+        char* Vp = Kp + 2 * PLN;
+        const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
+        if (kk >= KC4) return;
+        unsigned a0, a1, b0, b1;
+        split2b(kreg[0], kreg[1], a0, a1);
+        split2b(kreg[2], kreg[3], b0, b1);
+        char* kd = Kp + kk * RST + c4 * 8;
+        *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
+        split2b(vreg[0], vreg[1], a0, a1);
+        split2b(vreg[2], vreg[3], b0, b1);
+        char* vd = Vp + kk * RST + c4 * 8;
+        *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
+        *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
+    };
+    // chunk 0: every thread's NIT items requested at once (one memory round trip in front of the first barrier, not NIT)
+    f32x4 kreg0[NIT], vreg0[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) stage_load(0, tid + it * NTH, kreg0[it], vreg0[it]);
+    const int nchunk = (L + KC4 - 1) / KC4;
+
+    if (wave == NCW) {
+        // ---- producer wave: the whole next chunk while the others compute; NPF (key, 4-channel) items per lane in flight - with the
+        // computing waves walking two tiles at a time a chunk is consumed in about the time of four memory round trips
+        // (the last-dispatched wave of the workgroup loses every VALU / LDS issue arbitration against the older computing waves of
+        // its SIMD, and it is the one the chunk barrier waits for: static priority)
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) stage_write(0, tid + it * NTH, kreg0[it], vreg0[it]);
+        if (tid < KC4) stage_mask(0, 0, tid);
+        STAMP()
+        __syncthreads();
+        STAMP()
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int c0 = ch * KC4, buf = ch & 1;
+            if (ch + 1 < nchunk) {
+                constexpr int NPI = KC4 * (TD / 4) / 64;            // items per lane
+                constexpr int NPF = NPI / 4;                       // 9 (192-key chunks) / 6: four rounds, no spills
+                static_assert(NPI % NPF == 0, "producer rounds");
+                f32x4 kr[NPF], vr[NPF];
+                for (int j0 = 0; j0 < NPI; j0 += NPF) {
+#pragma unroll
+                    for (int j = 0; j < NPF; ++j) stage_load(c0 + KC4, lane + (j0 + j) * 64, kr[j], vr[j]);
+#pragma unroll
+                    for (int j = 0; j < NPF; ++j) stage_write(buf ^ 1, lane + (j0 + j) * 64, kr[j], vr[j]);
+                }
+                for (int t = lane; t < KC4; t += 64) stage_mask(c0 + KC4, buf ^ 1, t);
+            }
+            STAMP()
+            __syncthreads();
+            STAMP()
+        }
+        probe.finish();
+        return;
+    }
+
+    // ---- computing wave: its two query tiles.  Q fragments (B operand of the swapped product), pre-scaled, split once per row.
+    // qf[X][0], [1]: pieces a0, a1 of channels 8g .. 8g+7 (first k-step); qf[X][2]: a0 of channels 32 + 8(g&1) .. (second k-step:
+    // held by groups g and g + 2, against p0 | p1); qf[X][3]: a1 of the same channels in groups 0, 1, zero in groups 2, 3
+    const int qtA = qt0 + 2 * wave;
+    const bool has_tile = qtA < nqt;                              // (a wave without tiles still joins the barriers)
+    f16x8 qf[2][4];
+    const float* brow[2];
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const int qrow = min((qtA + X) * 16 + lq, L - 1);         // beyond the row: the last query row again (never stored)
+        const float* qp = a.q + base + (long long)qrow * a.sl;
+        brow[X] = biasb ? biasb + (long long)qrow * a.bias_sq : nullptr;
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp + g * 8);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(qp + g * 8 + 4);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(qp + 32 + (g & 1) * 8);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(qp + 32 + (g & 1) * 8 + 4);
+        unsigned p0[4], p1[4];
+        split2h_ns(q0[0] * qscale, q0[1] * qscale, p0[0], p1[0]);
+        split2h_ns(q0[2] * qscale, q0[3] * qscale, p0[1], p1[1]);
+        split2h_ns(q1[0] * qscale, q1[1] * qscale, p0[2], p1[2]);
+        split2h_ns(q1[2] * qscale, q1[3] * qscale, p0[3], p1[3]);
+        qf[X][0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+        qf[X][1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
+        split2h_ns(q2[0] * qscale, q2[1] * qscale, p0[0], p1[0]);
+        split2h_ns(q2[2] * qscale, q2[3] * qscale, p0[1], p1[1]);
+        split2h_ns(q3[0] * qscale, q3[1] * qscale, p0[2], p1[2]);
+        split2h_ns(q3[2] * qscale, q3[3] * qscale, p0[3], p1[3]);
+        qf[X][2] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+        qf[X][3] = g < 2 ? __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]}) : __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) stage_write(0, tid + it * NTH, kreg0[it], vreg0[it]);
+    if (tid < KC4) stage_mask(0, 0, tid);
+    float mr[2] = {-INFINITY, -INFINITY}, lr[2] = {0.f, 0.f};
+    f32x4 oo[2][3];
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) oo[X][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // logits of the key tile in flight: bias -> bias log2 e + S^T -> softmax weights P / 16 -> (the next tile's bias)
+    f32x4 sc[2][4];
+    // bias of sub-blocks [S0, S1) of the key tile that starts at key k_abs of the row, into sc
+    auto bias_issue = [&](int k_abs, auto s0_, auto s1_) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
+#pragma unroll
+        for (int X = 0; X < 2; ++X)
+#pragma unroll
+            for (int sub = S0; sub < S1; ++sub) {
+                const int kq = k_abs + sub * 16 + g * 4;
+                if (BVEC) {
+                    // keys beyond the padded row read the row's last four floats: replaced by the -inf clamp
+                    sc[X][sub] = *reinterpret_cast<const f32x4*>(brow[X] + min(kq, bias_row - 4));
+                } else if (!biasb) {
+                    sc[X][sub] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[X][sub][r] = brow[X][(long long)min(kq + r, L - 1) * a.bias_sk];
+                }
+            }
+    };
+    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    if (has_tile) bias_issue(0, I0{}, I4{});
+    if (wave == 0) STAMP()
+    __syncthreads();
+    if (wave == 0) STAMP()
+
+    const int koff0 = lq * RST + g * 16;                                  // K fragment, channels 8g .. (plane p: + p PLN)
+    const int koffc = lq * RST + (g >> 1) * PLN + 64 + (g & 1) * 16;      // channels 32 + 8(g&1) .. of plane g >> 1
+    const int voff = (4 * g + (lq >> 2)) * RST + (lq & 3) * 8;            // transposing V reads (see tri_attn4_kernel)
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c0 = ch * KC4, buf = ch & 1;
+        const int nkeys = min(KC4, L - c0);
+        const int nkt = (nkeys + 63) / 64;
+        const bool more = ch + 1 < nchunk;
+        const char* Kp = lds + buf * BUF4;
+        const char* Vp = Kp + 2 * PLN;
+        const float* Ms = Msb + buf * KC4;
+        if (has_tile)
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int k0 = kt * 64;
+            const bool full = nkeys - k0 > 32;                  // otherwise: sub-blocks 0, 1 and the first PV step only
+            // next key tile of this row (its bias is requested under the PV work below): first key, or -1
+            const int k_next = kt + 1 < nkt ? c0 + k0 + 64 : (more ? c0 + KC4 : -1);
+            if (BVEC || biasb) {
+#pragma unroll
+                for (int X = 0; X < 2; ++X)
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[X][sub][r] *= LOG2E * SCL;
+            }
+            // ---- S^T tiles (accumulators start from the bias)
+            auto qk = [&](auto sub_) __attribute__((always_inline)) {
+                constexpr int sub = decltype(sub_)::value;
+                const char* kr = Kp + (k0 + sub * 16) * RST;
+                const f16x8 r0 = *reinterpret_cast<const f16x8*>(kr + koff0);
+                const f16x8 r1 = *reinterpret_cast<const f16x8*>(kr + koff0 + PLN);
+                const f16x8 rc = *reinterpret_cast<const f16x8*>(kr + koffc);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0, qf[X][1], sc[X][sub], 0, 0, 0);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rc, qf[X][3], sc[X][sub], 0, 0, 0);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1, qf[X][0], sc[X][sub], 0, 0, 0);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rc, qf[X][2], sc[X][sub], 0, 0, 0);
+#pragma unroll
+                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0, qf[X][0], sc[X][sub], 0, 0, 0);
+            };
+            qk(I0{});
+            qk(std::integral_constant<int, 1>{});
+            if (full) {
+                qk(I2{});
+                qk(std::integral_constant<int, 3>{});
+            } else {
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    sc[X][2] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    sc[X][3] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                }
+            }
+            // ---- key clamps (masked / padded keys), online softmax (base 2) of this lane's query columns
+            if (any_masked || k0 + 64 > nkeys) {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
+#pragma unroll
+                    for (int X = 0; X < 2; ++X)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc[X][sub][r] = vmin(sc[X][sub][r], mk[r]);
+                }
+            }
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                const float m0 = vmax3(sc[X][0][0], sc[X][0][1], sc[X][0][2]), m1 = vmax3(sc[X][0][3], sc[X][1][0], sc[X][1][1]);
+                const float m2 = vmax3(sc[X][1][2], sc[X][1][3], sc[X][2][0]), m3 = vmax3(sc[X][2][1], sc[X][2][2], sc[X][2][3]);
+                const float m4 = vmax3(sc[X][3][0], sc[X][3][1], sc[X][3][2]);
+                const float mx = quad_max(vmax(vmax3(m0, m1, m2), vmax3(m3, m4, sc[X][3][3])));
+                const float m_new = vmax(mr[X], mx);
+                const float alpha = __builtin_amdgcn_exp2f((mr[X] - m_new) * ISCL);
+                const float m_sh = PEXP - m_new * ISCL;
+                float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sc[X][sub][r], ISCL, m_sh));     // P 2^8
+                        sc[X][sub][r] = p;
+                        rs4[r] += p;
+                    }
+                const float rs = quad_sum((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
+                lr[X] = lr[X] * alpha + rs;
+                mr[X] = m_new;
+                if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) oo[X][d][r] *= alpha;
+                }
+            }
+            // ---- O^T += V^T P: one step contracts the 32 keys of two sub-blocks; the bias of the next tile goes into the
+            // registers the weights leave
+            auto pv = [&](auto m_) __attribute__((always_inline)) {
+                constexpr int m = decltype(m_)::value;
+                f16x8 pa[2][2];
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    unsigned p0[4], p1[4];
+                    split2h_ns(sc[X][2 * m][0], sc[X][2 * m][1], p0[0], p1[0]);
+                    split2h_ns(sc[X][2 * m][2], sc[X][2 * m][3], p0[1], p1[1]);
+                    split2h_ns(sc[X][2 * m + 1][0], sc[X][2 * m + 1][1], p0[2], p1[2]);
+                    split2h_ns(sc[X][2 * m + 1][2], sc[X][2 * m + 1][3], p0[3], p1[3]);
+                    pa[X][0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+                    pa[X][1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
+                }
+                if (k_next >= 0) bias_issue(k_next, std::integral_constant<int, 2 * m>{}, std::integral_constant<int, 2 * m + 2>{});
+                const char* vr = Vp + (k0 + m * 32) * RST + voff;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    f16x8 vb[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const s16x4 lo = lds_tr16(vr + p * PLN + d * 32);
+                        const s16x4 hi = lds_tr16(vr + p * PLN + d * 32 + 16 * RST);
+                        vb[p] = __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                    }
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0], pa[X][1], oo[X][d], 0, 0, 0);
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[1], pa[X][0], oo[X][d], 0, 0, 0);
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0], pa[X][0], oo[X][d], 0, 0, 0);
+                }
+            };
+            pv(I0{});
+            if (full) pv(std::integral_constant<int, 1>{});
+        }
+        if (wave == 0) STAMP()
+        __syncthreads();
+        if (wave == 0) STAMP()
+    }
+    // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
+#pragma unroll
+    for (int X = 0; X < 2; ++X) {
+        const int qrow = (qtA + X) * 16 + lq;
+        if (qtA + X >= nqt || qrow >= L) continue;
+        const float inv = 0.0625f / lr[X];                       // O^T accumulated (16 v) (P 2^8), lr = sum P 2^8
+        const long long go = base + (long long)qrow * a.sl;
+        float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int dd = d * 16 + g * 4;
+            f32x4 v = oo[X][d];
+            if (a.gate) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * sigmoidf_(gv[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= inv;
+            }
+            *reinterpret_cast<f32x4*>(op + dd) = v;
+        }
+    }
+    if (wave == 0) STAMP()
+#undef STAMP
+    probe.finish();
+}
+
 // ---- sequence attention with pair bias (seqformer.py:314-356): 32 heads x 17 channels, bias (b, h, q, k) ---------------------------
 // The bias stream (L^2 floats per (b, h): 1.6 GB per launch at B = 100, L = 352) is the only real traffic, so the kernel is laid
 // out around reading it coalesced: a wave takes 4 queries at a time and its LANES ARE KEYS (key = lane + 64 m), each bias row is
@@ -771,7 +1148,8 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         // (Every query's arithmetic is the same in all variants: results are bit-identical.)  tune bit 0: never the producer wave.
         AbxTriAttn aa = a;
         const int nqt = (a.L + 15) / 16, nw = TRI_THREADS / 64;
-        aa.q_parts = (nqt + 2 * nw - 1) / (2 * nw);
+        const bool paired = !(a.tune & 4);                   // tri_attn8_kernel: 11 computing waves x 2 query tiles walked together
+        aa.q_parts = paired ? (nqt + 2 * (nw - 1) - 1) / (2 * (nw - 1)) : (nqt + 2 * nw - 1) / (2 * nw);
         const int tpp = (nqt + aa.q_parts - 1) / aa.q_parts;
         const bool prod = tpp <= 2 * (nw - 1) && !(a.tune & 1);
         aa.row_groups = ((long long)a.B * a.H) % 8 == 0 ? 1 : 2;
@@ -784,6 +1162,15 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
             return abx_check_launch("abx_tri_attn_fwd");
         };
         auto lds_of = [](int kc, bool db) { return (size_t)(db ? 2 : 1) * (4 * kc * RST + kc * sizeof(float)); };
+        if (paired) {
+            const float* bb = a.bias;
+            const bool bvec = bb && a.bias_sk == 1 && a.bias_sq % 4 == 0 && a.bias_sq >= 4 && a.bias_sb % 4 == 0 && a.bias_sh % 4 == 0 && al16(bb);
+            if (a.tune & 2)              // 128-key chunks (benchmarking)
+                return bvec ? launch(&tri_attn8_kernel<128, TRI_THREADS, true>, lds_of(128, true))
+                            : launch(&tri_attn8_kernel<128, TRI_THREADS, false>, lds_of(128, true));
+            return bvec ? launch(&tri_attn8_kernel<192, TRI_THREADS, true>, lds_of(192, true))
+                        : launch(&tri_attn8_kernel<192, TRI_THREADS, false>, lds_of(192, true));
+        }
         if (prod && (a.tune & 2)) return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, true>, lds_of(128, true));   // benchmarking
         if (prod) return launch(&tri_attn4_kernel<2, 192, true, TRI_THREADS, true>, lds_of(192, true));
         return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, false>, lds_of(128, true));

@@ -355,14 +355,11 @@ def transpose_last2(x, out, transpose=True):
     return out
 
 
-def tri_attn_kernel_name(L, exact=None):
+def tri_attn_kernel_name(L, exact=None, bias_vec=True):
     """Name of the kernel abx_tri_attn_fwd launches (mirror of the selection in csrc/attention.hip), for per-kernel aggregation."""
     if GEMM_EXACT if exact is None else exact:
         return 'tri_attn_kernel'
-    nqt = (L + 15) // 16
-    parts = (nqt + 23) // 24
-    prod = (nqt + parts - 1) // parts <= 22
-    return 'tri_attn4_kernel<2, 192, true, 768, true>' if prod else 'tri_attn4_kernel<2, 128, true, 768, false>'
+    return 'tri_attn8_kernel<192, 768, %s>' % ('true' if bias_vec else 'false')
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):

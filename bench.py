@@ -519,7 +519,7 @@ def main():
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
         if name.startswith('ipa_') and name != 'ipa_tail_kernel':
             roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
-        elif name.startswith('gemm3_') or name.startswith('tri_attn3') or name.startswith('tri_attn4'):
+        elif name.startswith('gemm3_') or name.startswith('tri_attn4') or name.startswith('tri_attn8'):
             # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs three f16 MFMA
             # products, so the ceiling is the dense f16 peak / 3
             roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_SPLIT_PEAK_TF, 'unit': 'TFLOP/s',

@@ -1,5 +1,6 @@
-"""Triangle attention variants (AbxTriAttn.tune): 0 = library choice (L <= 352: 11 computing waves + 1 producer wave that stages the next
-key chunk), 2 = the same on 128-key chunks instead of 192, 1 = 12 computing waves that share the staging (128-key chunks).  Usage: kb_tri.py [Bc] [L] [m = mask the last 7 keys]"""
+"""Triangle attention variants (AbxTriAttn.tune): 0 = library choice (tri_attn8: 11 computing waves walk two query tiles together + 1
+producer wave), 2 = the same on 128-key chunks instead of 192, 4 = the round-3 kernel tri_attn4 (one query tile at a time; producer
+wave), 5 = tri_attn4 with 12 computing waves that share the staging.  Usage: kb_tri.py [Bc] [L] [m = mask the last 7 keys]"""
 import sys
 import torch
 sys.path.insert(0, '/root/repo')
@@ -13,13 +14,14 @@ x, bT, mask = r(M2, 768), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV)
 if len(sys.argv) > 3: mask[:, L - 7:] = 0
 outs = {}
 for per_row in (True, False):
-    for tune in (0, 2, 1):
+    for tune in (0, 2, 4, 5):
         o = torch.empty(M2, 192, device=DEV)
         ops.tri_attn(x, bT, mask, o, Bc, L, per_row, bias_is_qk=True, tune=tune)
         outs[(per_row, tune)] = o
         ms = timeit(lambda: ops.tri_attn(x, bT, mask, o, Bc, L, per_row, bias_is_qk=True, tune=tune), reps=7)
         print(f'per_row={per_row} tune={tune}: {ms:7.3f} ms  {4.0 * Bc * L * 4 * LL * 48 / ms / 1e9:6.1f} TFLOP/s', flush=True)
-    print('   bit-identical across variants:', all(torch.equal(outs[(per_row, 0)], outs[(per_row, t)]) for t in (2, 1)))
+    print('   bit-identical 0 vs 2:', torch.equal(outs[(per_row, 0)], outs[(per_row, 2)]), ' 4 vs 5:', torch.equal(outs[(per_row, 4)], outs[(per_row, 5)]),
+          ' max |tri_attn8 - tri_attn4|', float((outs[(per_row, 0)] - outs[(per_row, 4)]).abs().max()))
 if L <= 389:
     oe = torch.empty(M2, 192, device=DEV)
     ops.tri_attn(x, bT, mask, oe, Bc, L, True, bias_is_qk=True, exact=True)
