@@ -14,6 +14,8 @@
 // abx_seq_attn_fwd — sequence attention with 32-head pair bias (seqformer.py:314-356, split_first=False :278-281):
 // lanes are keys so that the bias rows are read coalesced, K/V of the (b, h) pair in LDS.
 #include <stdlib.h>
+
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -238,11 +240,11 @@ constexpr int RST = 96;                  // bytes per key row of a plane: 32 * o
 // two-piece split of a pre-scaled pair without the 2^11 lift of the remainder (tri_attn8_kernel: operands scaled so that it stays a
 // normal float16 where it matters): x = p0 + p1 (+ <= 2^-24 |x|, or 2^-25 absolute below |x| = 2^-2)
 __device__ __forceinline__ void split2h_ns(float a, float b, unsigned& p0, unsigned& p1) {
-    const f32x2 x = {a, b};
-    const f16x2 h0 = __builtin_convertvector(x, f16x2);
-    const f32x2 r = x - __builtin_convertvector(h0, f32x2);
-    p0 = __builtin_bit_cast(unsigned, h0);
-    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    // p0 = (f16(a), f16(b)); p1 = (f16(a - p0.lo), f16(b - p0.hi)): the differences are exact in fp32, so the mixed-precision FMA
+    // (f16 source, f32 addend, f16 result: one rounding) gives the bits of convert - subtract - convert in 3 instructions instead of 5
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, f16x2));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(p0), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p1) : "v"(p0), "v"(b));
 }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -621,368 +623,426 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
 }
 
 // ---- triangle attention, paired query tiles (split-f16) ----------------------------------------------------------------------
-// Same decomposition, LDS image, staging and producer wave as tri_attn4_kernel; what changes is the work of a computing wave:
-//   * its two query tiles (2w and 2w + 1 of the row's <= 22) are walked TOGETHER over the key tiles, so every K / V fragment (LDS
-//     read + the p2 = p0 2^-11 derivation) serves two S^T / O^T tiles: half the LDS fragment traffic and half the v_pk_mul_f16 per
-//     product, and two independent accumulator chains per wave for the matrix pipe (a wave whose second tile lies beyond the row
-//     computes it on the clamped last query row and drops it: one code path);
-//   * the Q fragments of both tiles are loaded and split ONCE per row (tri_attn4 re-read and re-split them at every key chunk);
-//   * the pair bias is the INITIAL VALUE of the S^T accumulators (logits = bias log2 e + q.k): the loads of the next key tile's bias
-//     go into the registers the softmax weights of this tile have just left, under the PV matrix work - no bias registers beside
-//     the logits, no on-demand L2 round trip in front of the softmax;
+// Same (b, row, head) decomposition and LDS image as tri_attn4_kernel (K / V of a row staged in key chunks as two f16 planes each,
+// swapped S^T = K Q^T, transposing V reads, online base-2 softmax per query column).  What is different:
+//   * PERSISTENT workgroups: the grid is one workgroup per CU, workgroup j of XCD x walks the slots j, j + 32, ... of that XCD's
+//     (b, h, row) list (so the 32 CUs of an XCD still work on neighbouring rows of ONE (b, h) pair: its bias stays in that L2), and
+//     the PRODUCER wave streams key chunks across row boundaries: while the 11 computing waves work on the last chunk of a row it
+//     stages the first chunk of the next one.  One workgroup owns a CU (99 / 147 KB of LDS), so in the one-row-per-workgroup form
+//     nothing ran under a row's prologue (K / V of chunk 0 from HBM, first barrier) and under the dispatch of the next workgroup:
+//     a third of the kernel.
+//   * a computing wave walks its TWO query tiles (2w, 2w + 1 of the row's <= 22) together over the key tiles: every K / V fragment
+//     read serves two S^T / O^T tiles (half the LDS fragment traffic per product) and the matrix pipe sees two independent
+//     accumulator chains (a wave whose second tile lies beyond the row computes it on the clamped last query row and drops it);
+//   * the Q fragments of both tiles are loaded and split ONCE per row;
+//   * the pair bias is the INITIAL VALUE of the S^T accumulators: the loads of the next key tile's bias go into the registers the
+//     softmax weights of this tile have just left, under the PV matrix work;
+//   * operand scales chosen so that the second piece of a query / softmax weight needs no 2^11 lift: the three product terms use the
+//     stored planes p0, p1 as they are (no p2 = p0 2^-11 derivation);
 //   * the 48-wide head is 32 + 16 channels: the second k-step carries BOTH plane terms of channels 32..47 (lane groups 0, 1 read
-//     p0, groups 2, 3 read p1 of the same 16 channels, the query piece a0 is held twice), so a 16-key sub-block costs 5 matrix
-//     instructions instead of 6 and 3 fragment reads instead of 4 (the a1 p2 term of those channels: a1 is zero in groups 2, 3);
-//   * a last key tile with <= 32 keys runs half a tile (2 of 4 sub-blocks, 1 of 2 PV steps).
-// Rows with more than 22 query tiles are dealt to q_parts workgroups.
+//     p0, groups 2, 3 read p1 of the same 16 channels, the query piece a0 is held twice): 5 matrix instructions per 16-key
+//     sub-block instead of 6, 3 fragment reads instead of 4;
+//   * a last key tile with <= 32 keys runs half a tile.
+// The kernel is instruction-issue bound (one paired tile step: 76 MFMA + ~300 VALU + 36 LDS per wave, three waves per SIMD).
+// Rows with more than 22 query tiles are dealt to q_parts slots.
 // BVEC: the bias rows are key-contiguous, 16-byte aligned and padded to a multiple of 4 floats (what model/forward.py passes): one
 // 16-byte load per sub-block; otherwise (any strides, or no bias) the generic element loads
 template <int KC4, int NTH, bool BVEC>
 __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
     constexpr int PLN = KC4 * RST;           // bytes per plane
     constexpr int BUF4 = 4 * PLN;            // K planes + V planes (p0, p1) of one chunk
-    constexpr int NIT = (KC4 * (TD / 4) + NTH - 1) / NTH;
     constexpr int NCW = NTH / 64 - 1;        // computing waves; the last wave is the producer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
     float* Msb = reinterpret_cast<float*>(lds + 2 * BUF4);       // [2][KC4] key-mask clamps of the chunks in flight
     const int L = a.L;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int G = a.row_groups, rows_g = (a.S + G - 1) / G;
-    const int per_vp = rows_g * a.q_parts, sp = slot % per_vp;
-    const int vp = (slot / per_vp) * 8 + xcd;
-    const int bh = vp / G, s = (sp / a.q_parts) * G + vp % G, part = sp % a.q_parts;
-    if (bh >= a.B * a.H || s >= a.S) return;
     const ClockProbe probe(a.clock_probe);
 #ifdef TRI8_STAMP
-    // diagnostic build: shader-clock stamps of wave 0 (slots 0..15) and of the producer wave (16..31) of the first 4096 workgroups
-    unsigned long long* st_buf = a.clock_probe ? a.clock_probe + 16 + (size_t)(blockIdx.x & 4095) * 32 : nullptr;
-    int st_n = 0;
-#define STAMP() { if (st_buf && (threadIdx.x & 63) == 0 && st_n < 16) st_buf[(threadIdx.x >= NCW * 64 ? 16 : 0) + st_n] = __builtin_amdgcn_s_memtime(); ++st_n; }
+    // diagnostic build: shader-clock stamps of wave 0 (slots 0..15) and of the producer wave (16..31) while the workgroup is on its
+    // FOURTH row (steady state), one record per workgroup
+    unsigned long long* st_buf = a.clock_probe ? a.clock_probe + 16 + (size_t)blockIdx.x * 32 : nullptr;
+    int st_n = 0, st_row = 0;
+#define STAMP() { if (st_buf && st_row == 3 && (threadIdx.x & 63) == 0 && st_n < 16) st_buf[(threadIdx.x >= NCW * 64 ? 16 : 0) + st_n] = __builtin_amdgcn_s_memtime(); if (st_row == 3) ++st_n; }
 #else
 #define STAMP() {}
 #endif
-    const int b = bh / a.H, h = bh % a.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wave == 0) STAMP()
     const int lq = lane & 15, g = lane >> 4;
-    const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
-    const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
-    const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
-    const int nqt_row = (L + 15) / 16, tpp = (nqt_row + a.q_parts - 1) / a.q_parts;
-    const int qt0 = part * tpp, nqt = min(nqt_row, qt0 + tpp);
-    const int bias_row = (int)a.bias_sq;
-    // scales (powers of two: exact): keys / values are staged as 16 x (planes p0, p1 = f16(x'), f16(x' - p0)); queries enter as
-    // q scale log2(e) 2^3, so the S^T accumulators hold 2^7 x the base-2 logits; softmax weights as P 2^8.  With these scales the
-    // second piece of a query / weight, f16(x' - f16(x')), needs no 2^11 lift (a float16 subnormal only below |x'| = 2^-2, where its
-    // 2^-25 absolute error is far below the rounding of the neighbouring products), so the three product terms a1 p0 + a0 p1 + a0 p0
-    // use the stored planes as they are: no p2 = p0 2^-11 derivation (56 v_pk_mul_f16 per tile pair in the first form of this kernel)
-    const float qscale = a.scale * LOG2E * 8.0f;
-    constexpr float SCL = 128.0f, ISCL = 1.0f / 128.0f, PEXP = 8.0f;
-    bool any_masked = false;
-    if (km) {
-        for (int j = lane; j < L; j += 64) any_masked |= km[j] == 0.f;
-        any_masked = __any(any_masked);
-    }
-
-    // ---- staging (all waves stage chunk 0; afterwards the producer wave alone)
-    auto stage_load = [&](int c0, int idx, f32x4& kreg, f32x4& vreg) __attribute__((always_inline)) {
-        const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
-        kreg = (f32x4){0.f, 0.f, 0.f, 0.f};
-        vreg = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kk < KC4 && c0 + kk < L) {
-            const long long off = base + (long long)(c0 + kk) * a.sl + c4 * 4;
-            kreg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.k + off));
-            vreg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.v + off));
-        }
+    // ---- the slots of this workgroup: XCD x = blockIdx & 7 owns the virtual pairs x, x + 8, ...; a slot is (pair, row, part)
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, NW = gridDim.x >> 3;
+    const int G = a.row_groups, rows_g = (a.S + G - 1) / G;
+    const int per_vp = rows_g * a.q_parts;
+    const int nvp = a.B * a.H * G;
+    const long long nslots = (long long)((nvp - xcd + 7) / 8) * per_vp;          // slots of this XCD
+    struct Row { long long base; const float* km; const float* biasb; int b, h, s, part; };
+    auto decode = [&](long long slot, Row& r) __attribute__((always_inline)) -> bool {
+        const int sp = (int)(slot % per_vp), vp = (int)(slot / per_vp) * 8 + xcd;
+        const int bh = vp / G;
+        r.s = (sp / a.q_parts) * G + vp % G;
+        r.part = sp % a.q_parts;
+        if (r.s >= a.S) return false;                                              // (ragged last row group)
+        r.b = bh / a.H;
+        r.h = bh % a.H;
+        r.base = (long long)r.b * a.sb + (long long)r.s * a.ss + (long long)r.h * TD;
+        r.km = a.keymask ? a.keymask + (long long)r.b * a.km_sb : nullptr;
+        r.biasb = a.bias ? a.bias + (long long)r.b * a.bias_sb + (long long)r.h * a.bias_sh : nullptr;
+        return true;
     };
-    auto stage_mask = [&](int c0, int buf, int t) __attribute__((always_inline)) {
-        Msb[buf * KC4 + t] = (c0 + t < L) ? ((!km || km[c0 + t] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+    auto next_slot = [&](long long slot, Row& r) __attribute__((always_inline)) -> long long {       // first valid slot >= slot, or -1
+        for (; slot < nslots; slot += NW)
+            if (decode(slot, r)) return slot;
+        return -1;
     };
-    auto stage_write = [&](int buf, int idx, const f32x4& kreg, const f32x4& vreg) __attribute__((always_inline)) {
-        char* Kp = lds + buf * BUF4;
-        char* Vp = Kp + 2 * PLN;
-        const int kk = idx / (TD / 4), c4 = idx % (TD / 4);
-        if (kk >= KC4) return;
-        unsigned a0, a1, b0, b1;
-        split2b(kreg[0], kreg[1], a0, a1);
-        split2b(kreg[2], kreg[3], b0, b1);
-        char* kd = Kp + kk * RST + c4 * 8;
-        *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
-        *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
-        split2b(vreg[0], vreg[1], a0, a1);
-        split2b(vreg[2], vreg[3], b0, b1);
-        char* vd = Vp + kk * RST + c4 * 8;
-        *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
-        *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
-    };
-    // chunk 0: every thread's NIT items requested at once (one memory round trip in front of the first barrier, not NIT)
-    f32x4 kreg0[NIT], vreg0[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) stage_load(0, tid + it * NTH, kreg0[it], vreg0[it]);
     const int nchunk = (L + KC4 - 1) / KC4;
+    const int nqt_row = (L + 15) / 16, tpp = (nqt_row + a.q_parts - 1) / a.q_parts;
 
     if (wave == NCW) {
-        // ---- producer wave: the whole next chunk while the others compute; NPF (key, 4-channel) items per lane in flight - with the
-        // computing waves walking two tiles at a time a chunk is consumed in about the time of four memory round trips
+        // ================= producer wave: K / V of the chunk after the one being computed, across row boundaries ==============
         // (the last-dispatched wave of the workgroup loses every VALU / LDS issue arbitration against the older computing waves of
         // its SIMD, and it is the one the chunk barrier waits for: static priority)
         __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) stage_write(0, tid + it * NTH, kreg0[it], vreg0[it]);
-        if (tid < KC4) stage_mask(0, 0, tid);
-        STAMP()
-        __syncthreads();
-        STAMP()
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int c0 = ch * KC4, buf = ch & 1;
-            if (ch + 1 < nchunk) {
-                constexpr int NPI = KC4 * (TD / 4) / 64;            // items per lane
-                constexpr int NPF = NPI / 4;                       // 9 (192-key chunks) / 6: four rounds, no spills
-                static_assert(NPI % NPF == 0, "producer rounds");
+        auto stage = [&](const Row& r, int c0, int buf) __attribute__((always_inline)) {
+            constexpr int NPI = KC4 * (TD / 4) / 64;            // (key, 4-channel) items per lane
+            constexpr int NPF = NPI / 4;                        // in flight per lane: 9 (192-key chunks) / 6, four rounds
+            char* Kp = lds + buf * BUF4;
+            char* Vp = Kp + 2 * PLN;
+            for (int j0 = 0; j0 < NPI; j0 += NPF) {
                 f32x4 kr[NPF], vr[NPF];
-                for (int j0 = 0; j0 < NPI; j0 += NPF) {
 #pragma unroll
-                    for (int j = 0; j < NPF; ++j) stage_load(c0 + KC4, lane + (j0 + j) * 64, kr[j], vr[j]);
-#pragma unroll
-                    for (int j = 0; j < NPF; ++j) stage_write(buf ^ 1, lane + (j0 + j) * 64, kr[j], vr[j]);
+                for (int j = 0; j < NPF; ++j) {
+                    const int idx = lane + (j0 + j) * 64, kk = idx / (TD / 4), c4 = idx % (TD / 4);
+                    kr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    vr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (c0 + kk < L) {
+                        const long long off = r.base + (long long)(c0 + kk) * a.sl + c4 * 4;
+                        // read once per launch: non-temporal, so that the K / V stream does not push the pair's bias out of the L2
+                        kr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.k + off));
+                        vr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.v + off));
+                    }
                 }
-                for (int t = lane; t < KC4; t += 64) stage_mask(c0 + KC4, buf ^ 1, t);
+#pragma unroll
+                for (int j = 0; j < NPF; ++j) {
+                    const int idx = lane + (j0 + j) * 64, kk = idx / (TD / 4), c4 = idx % (TD / 4);
+                    unsigned a0, a1, b0, b1;
+                    split2b(kr[j][0], kr[j][1], a0, a1);
+                    split2b(kr[j][2], kr[j][3], b0, b1);
+                    char* kd = Kp + kk * RST + c4 * 8;
+                    *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
+                    *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
+                    split2b(vr[j][0], vr[j][1], a0, a1);
+                    split2b(vr[j][2], vr[j][3], b0, b1);
+                    char* vd = Vp + kk * RST + c4 * 8;
+                    *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
+                    *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
+                }
+            }
+            // key clamps, applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit by
+            // finfo.min: every finite logit is >= finfo.min), -inf beyond L
+            for (int t = lane; t < KC4; t += 64)
+                Msb[buf * KC4 + t] = (c0 + t < L) ? ((!r.km || r.km[c0 + t] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+        };
+        Row cur, nxt;
+        long long slot = next_slot(wg, cur);
+        int cc = 0;                                             // chunks staged so far: chunk cc goes to buffer cc & 1
+        if (slot >= 0) stage(cur, 0, 0);
+        __syncthreads();
+        while (slot >= 0) {
+            const long long slot2 = next_slot(slot + NW, nxt);
+            for (int ch = 0; ch < nchunk; ++ch) {
+                ++cc;
+                STAMP()
+                if (ch + 1 < nchunk) stage(cur, (ch + 1) * KC4, cc & 1);
+                else if (slot2 >= 0) stage(nxt, 0, cc & 1);
+                STAMP()
+                __syncthreads();
             }
             STAMP()
-            __syncthreads();
-            STAMP()
+#ifdef TRI8_STAMP
+            ++st_row;
+#endif
+            slot = slot2;
+            cur = nxt;
         }
         probe.finish();
         return;
     }
 
-    // ---- computing wave: its two query tiles.  Q fragments (B operand of the swapped product), pre-scaled, split once per row.
-    // qf[X][0], [1]: pieces a0, a1 of channels 8g .. 8g+7 (first k-step); qf[X][2]: a0 of channels 32 + 8(g&1) .. (second k-step:
-    // held by groups g and g + 2, against p0 | p1); qf[X][3]: a1 of the same channels in groups 0, 1, zero in groups 2, 3
-    const int qtA = qt0 + 2 * wave;
-    const bool has_tile = qtA < nqt;                              // (a wave without tiles still joins the barriers)
-    f16x8 qf[2][4];
-    const float* brow[2];
-#pragma unroll
-    for (int X = 0; X < 2; ++X) {
-        const int qrow = min((qtA + X) * 16 + lq, L - 1);         // beyond the row: the last query row again (never stored)
-        const float* qp = a.q + base + (long long)qrow * a.sl;
-        brow[X] = biasb ? biasb + (long long)qrow * a.bias_sq : nullptr;
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp + g * 8);
-        const f32x4 q1 = *reinterpret_cast<const f32x4*>(qp + g * 8 + 4);
-        const f32x4 q2 = *reinterpret_cast<const f32x4*>(qp + 32 + (g & 1) * 8);
-        const f32x4 q3 = *reinterpret_cast<const f32x4*>(qp + 32 + (g & 1) * 8 + 4);
-        unsigned p0[4], p1[4];
-        split2h_ns(q0[0] * qscale, q0[1] * qscale, p0[0], p1[0]);
-        split2h_ns(q0[2] * qscale, q0[3] * qscale, p0[1], p1[1]);
-        split2h_ns(q1[0] * qscale, q1[1] * qscale, p0[2], p1[2]);
-        split2h_ns(q1[2] * qscale, q1[3] * qscale, p0[3], p1[3]);
-        qf[X][0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
-        qf[X][1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
-        split2h_ns(q2[0] * qscale, q2[1] * qscale, p0[0], p1[0]);
-        split2h_ns(q2[2] * qscale, q2[3] * qscale, p0[1], p1[1]);
-        split2h_ns(q3[0] * qscale, q3[1] * qscale, p0[2], p1[2]);
-        split2h_ns(q3[2] * qscale, q3[3] * qscale, p0[3], p1[3]);
-        qf[X][2] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
-        qf[X][3] = g < 2 ? __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]}) : __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) stage_write(0, tid + it * NTH, kreg0[it], vreg0[it]);
-    if (tid < KC4) stage_mask(0, 0, tid);
-    float mr[2] = {-INFINITY, -INFINITY}, lr[2] = {0.f, 0.f};
-    f32x4 oo[2][3];
-#pragma unroll
-    for (int X = 0; X < 2; ++X)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) oo[X][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // logits of the key tile in flight: bias -> bias log2 e + S^T -> softmax weights P / 16 -> (the next tile's bias)
-    f32x4 sc[2][4];
-    // bias of sub-blocks [S0, S1) of the key tile that starts at key k_abs of the row, into sc
-    auto bias_issue = [&](int k_abs, auto s0_, auto s1_) __attribute__((always_inline)) {
-        constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
-#pragma unroll
-        for (int X = 0; X < 2; ++X)
-#pragma unroll
-            for (int sub = S0; sub < S1; ++sub) {
-                const int kq = k_abs + sub * 16 + g * 4;
-                if (BVEC) {
-                    // keys beyond the padded row read the row's last four floats: replaced by the -inf clamp
-                    sc[X][sub] = *reinterpret_cast<const f32x4*>(brow[X] + min(kq, bias_row - 4));
-                } else if (!biasb) {
-                    sc[X][sub] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[X][sub][r] = brow[X][(long long)min(kq + r, L - 1) * a.bias_sk];
-                }
-            }
-    };
-    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
-    if (has_tile) bias_issue(0, I0{}, I4{});
-    if (wave == 0) STAMP()
-    __syncthreads();
-    if (wave == 0) STAMP()
-
+    // ================= computing waves ======================================================================================
+    // scales (powers of two: exact): keys / values are staged as 16 x (planes p0, p1 = f16(x'), f16(x' - p0)); queries enter as
+    // q scale log2(e) 2^3, so the S^T accumulators hold 2^7 x the base-2 logits; softmax weights as P 2^8.  With these scales the
+    // second piece of a query / weight, f16(x' - f16(x')), needs no 2^11 lift (a float16 subnormal only below |x'| = 2^-2, where its
+    // 2^-25 absolute error is far below the rounding of the neighbouring products), so the three product terms a1 p0 + a0 p1 + a0 p0
+    // use the stored planes as they are
+    const float qscale = a.scale * LOG2E * 8.0f;
+    constexpr float SCL = 128.0f, ISCL = 1.0f / 128.0f, PEXP = 8.0f;
     const int koff0 = lq * RST + g * 16;                                  // K fragment, channels 8g .. (plane p: + p PLN)
     const int koffc = lq * RST + (g >> 1) * PLN + 64 + (g & 1) * 16;      // channels 32 + 8(g&1) .. of plane g >> 1
     const int voff = (4 * g + (lq >> 2)) * RST + (lq & 3) * 8;            // transposing V reads (see tri_attn4_kernel)
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
 
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int c0 = ch * KC4, buf = ch & 1;
-        const int nkeys = min(KC4, L - c0);
-        const int nkt = (nkeys + 63) / 64;
-        const bool more = ch + 1 < nchunk;
-        const char* Kp = lds + buf * BUF4;
-        const char* Vp = Kp + 2 * PLN;
-        const float* Ms = Msb + buf * KC4;
-        if (has_tile)
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int k0 = kt * 64;
-            const bool full = nkeys - k0 > 32;                  // otherwise: sub-blocks 0, 1 and the first PV step only
-            // next key tile of this row (its bias is requested under the PV work below): first key, or -1
-            const int k_next = kt + 1 < nkt ? c0 + k0 + 64 : (more ? c0 + KC4 : -1);
-            if (BVEC || biasb) {
+    Row cur;
+    long long slot = next_slot(wg, cur);
+    int cc = 0;                                                 // chunks consumed so far
+    __syncthreads();                                            // the first chunk of the first row is staged
+    while (slot >= 0) {
+        const int qt0 = cur.part * tpp, nqt = min(nqt_row, qt0 + tpp);
+        const int qtA = qt0 + 2 * wave;
+        const bool has_tile = qtA < nqt;                        // (a wave without tiles still joins the barriers)
+        if (wave == 0) STAMP()
+        bool any_masked = false;                                // wave-uniform: does this sample mask any key?
+        if (cur.km) {
+            for (int j = lane; j < L; j += 64) any_masked |= cur.km[j] == 0.f;
+            any_masked = __any(any_masked);
+        }
+        // ---- Q fragments (B operand of the swapped product), pre-scaled, split once per row.
+        // qf[X][0], [1]: pieces a0, a1 of channels 8g .. 8g+7 (first k-step); qf[X][2]: a0 of channels 32 + 8(g&1) .. (second k-step:
+        // held by groups g and g + 2, against p0 | p1); qf[X][3]: a1 of the same channels in groups 0, 1, zero in groups 2, 3
+        f16x8 qf[2][4];
+        unsigned boff[2];                                        // byte offset of (query row, key 4g) inside the pair's bias (< 4 GB)
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int qrow = min((qtA + X) * 16 + lq, L - 1);     // beyond the row: the last query row again (never stored)
+            const float* qp = a.q + cur.base + (long long)qrow * a.sl;
+            boff[X] = (unsigned)(((long long)qrow * a.bias_sq + g * 4) * 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp + g * 8);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qp + g * 8 + 4);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(qp + 32 + (g & 1) * 8);
+            const f32x4 q3 = *reinterpret_cast<const f32x4*>(qp + 32 + (g & 1) * 8 + 4);
+            unsigned p0[4], p1[4];
+            split2h_ns(q0[0] * qscale, q0[1] * qscale, p0[0], p1[0]);
+            split2h_ns(q0[2] * qscale, q0[3] * qscale, p0[1], p1[1]);
+            split2h_ns(q1[0] * qscale, q1[1] * qscale, p0[2], p1[2]);
+            split2h_ns(q1[2] * qscale, q1[3] * qscale, p0[3], p1[3]);
+            qf[X][0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+            qf[X][1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
+            split2h_ns(q2[0] * qscale, q2[1] * qscale, p0[0], p1[0]);
+            split2h_ns(q2[2] * qscale, q2[3] * qscale, p0[1], p1[1]);
+            split2h_ns(q3[0] * qscale, q3[1] * qscale, p0[2], p1[2]);
+            split2h_ns(q3[2] * qscale, q3[3] * qscale, p0[3], p1[3]);
+            qf[X][2] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+            qf[X][3] = g < 2 ? __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]}) : __builtin_bit_cast(f16x8, u32x4{0u, 0u, 0u, 0u});
+        }
+        // running maximum (in accumulator units) and the running sum of the softmax weights: the sums come off the MATRIX pipe as a
+        // 49th output channel (A operand = ones: every row of ls is the column sum of the weight pieces the PV product uses) - 8 MFMA
+        // issue slots per tile pair instead of the 48 VALU ones of the add tree + the four-lane reduction; the kernel is issue bound
+        float mr[2] = {-INFINITY, -INFINITY};
+        f32x4 ls[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 oo[2][3];
+#pragma unroll
+        for (int X = 0; X < 2; ++X)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) oo[X][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // logits of the key tile in flight: bias -> 2^7 (bias log2 e + S^T) -> softmax weights P 2^8 -> (the next tile's bias)
+        f32x4 sc[2][4];
+        __amdgpu_buffer_rsrc_t brsrc;
+        {
+            const unsigned long long bu = reinterpret_cast<unsigned long long>(cur.biasb);
+            // (readfirstlane returns int: through unsigned, or a low half with bit 31 set sign-extends into the high half)
+            const unsigned long long bu_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bu >> 32)) << 32) |
+                                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bu);
+            brsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bu_u), 0,
+                                                      __builtin_amdgcn_readfirstlane((int)(L * a.bias_sq * 4)), 0x00020000);
+        }
+        // bias of sub-blocks [S0, S1) of the key tile that starts at key k_abs of the row, into sc
+        auto bias_issue = [&](int k_abs, auto s0_, auto s1_) __attribute__((always_inline)) {
+            constexpr int S0 = decltype(s0_)::value, S1 = decltype(s1_)::value;
+            if (BVEC) {
+                // buffer loads: the pair's (L, Lp) bias as the resource (wave-uniform descriptor), (query row, key) in the per-lane 32-bit
+                // offset, the sub-block as immediate: no 64-bit vector address arithmetic.  Keys beyond the padded row read the next row's
+                // floats (beyond the matrix: the range check returns 0): replaced by the -inf clamp
+                // (the tile's first key goes into the per-lane offset, not the scalar one: only the former is range-checked)
+#pragma unroll
+                for (int X = 0; X < 2; ++X) {
+                    const unsigned vo = boff[X] + (unsigned)k_abs * 4u;
+#pragma unroll
+                    for (int sub = S0; sub < S1; ++sub)
+                        sc[X][sub] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, vo + sub * 64, 0, 0));
+                }
+            } else {
 #pragma unroll
                 for (int X = 0; X < 2; ++X)
 #pragma unroll
-                    for (int sub = 0; sub < 4; ++sub)
+                    for (int sub = S0; sub < S1; ++sub) {
+                        const int kq = k_abs + sub * 16 + g * 4;
+                        const float* brow = cur.biasb ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(cur.biasb) + boff[X]) - g * 4 : nullptr;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sc[X][sub][r] *= LOG2E * SCL;
+                        for (int r = 0; r < 4; ++r)
+                            sc[X][sub][r] = brow ? brow[(long long)min(kq + r, L - 1) * a.bias_sk] : 0.f;
+                    }
             }
-            // ---- S^T tiles (accumulators start from the bias)
-            auto qk = [&](auto sub_) __attribute__((always_inline)) {
-                constexpr int sub = decltype(sub_)::value;
-                const char* kr = Kp + (k0 + sub * 16) * RST;
-                const f16x8 r0 = *reinterpret_cast<const f16x8*>(kr + koff0);
-                const f16x8 r1 = *reinterpret_cast<const f16x8*>(kr + koff0 + PLN);
-                const f16x8 rc = *reinterpret_cast<const f16x8*>(kr + koffc);
-#pragma unroll
-                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0, qf[X][1], sc[X][sub], 0, 0, 0);
-#pragma unroll
-                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rc, qf[X][3], sc[X][sub], 0, 0, 0);
-#pragma unroll
-                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1, qf[X][0], sc[X][sub], 0, 0, 0);
-#pragma unroll
-                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rc, qf[X][2], sc[X][sub], 0, 0, 0);
-#pragma unroll
-                for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0, qf[X][0], sc[X][sub], 0, 0, 0);
-            };
-            qk(I0{});
-            qk(std::integral_constant<int, 1>{});
-            if (full) {
-                qk(I2{});
-                qk(std::integral_constant<int, 3>{});
-            } else {
-#pragma unroll
-                for (int X = 0; X < 2; ++X) {
-                    sc[X][2] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                    sc[X][3] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                }
-            }
-            // ---- key clamps (masked / padded keys), online softmax (base 2) of this lane's query columns
-            if (any_masked || k0 + 64 > nkeys) {
-#pragma unroll
-                for (int sub = 0; sub < 4; ++sub) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
+        };
+        if (has_tile) bias_issue(0, I0{}, I4{});
+        if (wave == 0) STAMP()
+
+        for (int ch = 0; ch < nchunk; ++ch, ++cc) {
+            const int c0 = ch * KC4, buf = cc & 1;
+            const int nkeys = min(KC4, L - c0);
+            const int nkt = (nkeys + 63) / 64;
+            const bool more = ch + 1 < nchunk;
+            const char* Kp = lds + buf * BUF4;
+            const char* Vp = Kp + 2 * PLN;
+            const float* Ms = Msb + buf * KC4;
+            if (has_tile)
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int k0 = kt * 64;
+                const bool full = nkeys - k0 > 32;              // otherwise: sub-blocks 0, 1 and the first PV step only
+                // next key tile of this row (its bias is requested under the PV work below): first key, or -1
+                const int k_next = kt + 1 < nkt ? c0 + k0 + 64 : (more ? c0 + KC4 : -1);
+                if (BVEC || cur.biasb) {
 #pragma unroll
                     for (int X = 0; X < 2; ++X)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sc[X][sub][r] = vmin(sc[X][sub][r], mk[r]);
+                        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sc[X][sub][r] *= LOG2E * SCL;
                 }
-            }
+                // ---- S^T tiles (accumulators start from the bias): terms a1 p0, a0 p1, a0 p0, smallest first
+                auto qk = [&](auto sub_) __attribute__((always_inline)) {
+                    constexpr int sub = decltype(sub_)::value;
+                    const char* kr = Kp + (k0 + sub * 16) * RST;
+                    const f16x8 r0 = *reinterpret_cast<const f16x8*>(kr + koff0);
+                    const f16x8 r1 = *reinterpret_cast<const f16x8*>(kr + koff0 + PLN);
+                    const f16x8 rc = *reinterpret_cast<const f16x8*>(kr + koffc);
 #pragma unroll
-            for (int X = 0; X < 2; ++X) {
-                const float m0 = vmax3(sc[X][0][0], sc[X][0][1], sc[X][0][2]), m1 = vmax3(sc[X][0][3], sc[X][1][0], sc[X][1][1]);
-                const float m2 = vmax3(sc[X][1][2], sc[X][1][3], sc[X][2][0]), m3 = vmax3(sc[X][2][1], sc[X][2][2], sc[X][2][3]);
-                const float m4 = vmax3(sc[X][3][0], sc[X][3][1], sc[X][3][2]);
-                const float mx = quad_max(vmax(vmax3(m0, m1, m2), vmax3(m3, m4, sc[X][3][3])));
-                const float m_new = vmax(mr[X], mx);
-                const float alpha = __builtin_amdgcn_exp2f((mr[X] - m_new) * ISCL);
-                const float m_sh = PEXP - m_new * ISCL;
-                float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0, qf[X][1], sc[X][sub], 0, 0, 0);
 #pragma unroll
-                for (int sub = 0; sub < 4; ++sub)
+                    for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rc, qf[X][3], sc[X][sub], 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sc[X][sub][r], ISCL, m_sh));     // P 2^8
-                        sc[X][sub][r] = p;
-                        rs4[r] += p;
+                    for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r1, qf[X][0], sc[X][sub], 0, 0, 0);
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rc, qf[X][2], sc[X][sub], 0, 0, 0);
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) sc[X][sub] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r0, qf[X][0], sc[X][sub], 0, 0, 0);
+                };
+                qk(I0{});
+                qk(I1{});
+                if (full) {
+                    qk(I2{});
+                    qk(I3{});
+                } else {
+#pragma unroll
+                    for (int X = 0; X < 2; ++X) {
+                        sc[X][2] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                        sc[X][3] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                     }
-                const float rs = quad_sum((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
-                lr[X] = lr[X] * alpha + rs;
-                mr[X] = m_new;
-                if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                    for (int d = 0; d < 3; ++d)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) oo[X][d][r] *= alpha;
                 }
-            }
-            // ---- O^T += V^T P: one step contracts the 32 keys of two sub-blocks; the bias of the next tile goes into the
-            // registers the weights leave
-            auto pv = [&](auto m_) __attribute__((always_inline)) {
-                constexpr int m = decltype(m_)::value;
-                f16x8 pa[2][2];
+                // ---- key clamps (masked / padded keys), online softmax (base 2) of this lane's query columns
+                if (any_masked || k0 + 64 > nkeys) {
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) {
+                        const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
+#pragma unroll
+                        for (int X = 0; X < 2; ++X)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sc[X][sub][r] = vmin(sc[X][sub][r], mk[r]);
+                    }
+                }
 #pragma unroll
                 for (int X = 0; X < 2; ++X) {
-                    unsigned p0[4], p1[4];
-                    split2h_ns(sc[X][2 * m][0], sc[X][2 * m][1], p0[0], p1[0]);
-                    split2h_ns(sc[X][2 * m][2], sc[X][2 * m][3], p0[1], p1[1]);
-                    split2h_ns(sc[X][2 * m + 1][0], sc[X][2 * m + 1][1], p0[2], p1[2]);
-                    split2h_ns(sc[X][2 * m + 1][2], sc[X][2 * m + 1][3], p0[3], p1[3]);
-                    pa[X][0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
-                    pa[X][1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
-                }
-                if (k_next >= 0) bias_issue(k_next, std::integral_constant<int, 2 * m>{}, std::integral_constant<int, 2 * m + 2>{});
-                const char* vr = Vp + (k0 + m * 32) * RST + voff;
+                    const float m0 = vmax3(sc[X][0][0], sc[X][0][1], sc[X][0][2]), m1 = vmax3(sc[X][0][3], sc[X][1][0], sc[X][1][1]);
+                    const float m2 = vmax3(sc[X][1][2], sc[X][1][3], sc[X][2][0]), m3 = vmax3(sc[X][2][1], sc[X][2][2], sc[X][2][3]);
+                    const float m4 = vmax3(sc[X][3][0], sc[X][3][1], sc[X][3][2]);
+                    const float mx = quad_max(vmax(vmax3(m0, m1, m2), vmax3(m3, m4, sc[X][3][3])));
+                    const float m_new = vmax(mr[X], mx);
+                    const float alpha = __builtin_amdgcn_exp2f((mr[X] - m_new) * ISCL);
+                    const float m_sh = PEXP - m_new * ISCL;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    f16x8 vb[2];
+                    for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const s16x4 lo = lds_tr16(vr + p * PLN + d * 32);
-                        const s16x4 hi = lds_tr16(vr + p * PLN + d * 32 + 16 * RST);
-                        vb[p] = __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                        for (int r = 0; r < 4; ++r) sc[X][sub][r] = __builtin_amdgcn_exp2f(fmaf(sc[X][sub][r], ISCL, m_sh));     // P 2^8
+                    mr[X] = m_new;
+                    if (!__all(alpha == 1.0f)) {                    // O^T columns are the queries: lane-local rescale
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) oo[X][d][r] *= alpha;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ls[X][r] *= alpha;
                     }
-#pragma unroll
-                    for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0], pa[X][1], oo[X][d], 0, 0, 0);
-#pragma unroll
-                    for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[1], pa[X][0], oo[X][d], 0, 0, 0);
-#pragma unroll
-                    for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0], pa[X][0], oo[X][d], 0, 0, 0);
                 }
-            };
-            pv(I0{});
-            if (full) pv(std::integral_constant<int, 1>{});
-        }
-        if (wave == 0) STAMP()
-        __syncthreads();
-        if (wave == 0) STAMP()
-    }
-    // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
+                // ---- O^T += V^T P: one step contracts the 32 keys of two sub-blocks; the bias of the next tile goes into the
+                // registers the weights leave
+                auto pv = [&](auto m_) __attribute__((always_inline)) {
+                    constexpr int m = decltype(m_)::value;
+                    f16x8 pa[2][2];
 #pragma unroll
-    for (int X = 0; X < 2; ++X) {
-        const int qrow = (qtA + X) * 16 + lq;
-        if (qtA + X >= nqt || qrow >= L) continue;
-        const float inv = 0.0625f / lr[X];                       // O^T accumulated (16 v) (P 2^8), lr = sum P 2^8
-        const long long go = base + (long long)qrow * a.sl;
-        float* op = a.out + (long long)b * a.ob + (long long)s * a.os + (long long)qrow * a.ol + h * TD;
+                    for (int X = 0; X < 2; ++X) {
+                        unsigned p0[4], p1[4];
+                        split2h_ns(sc[X][2 * m][0], sc[X][2 * m][1], p0[0], p1[0]);
+                        split2h_ns(sc[X][2 * m][2], sc[X][2 * m][3], p0[1], p1[1]);
+                        split2h_ns(sc[X][2 * m + 1][0], sc[X][2 * m + 1][1], p0[2], p1[2]);
+                        split2h_ns(sc[X][2 * m + 1][2], sc[X][2 * m + 1][3], p0[3], p1[3]);
+                        pa[X][0] = __builtin_bit_cast(f16x8, u32x4{p0[0], p0[1], p0[2], p0[3]});
+                        pa[X][1] = __builtin_bit_cast(f16x8, u32x4{p1[0], p1[1], p1[2], p1[3]});
+                    }
+                    if (k_next >= 0) bias_issue(k_next, std::integral_constant<int, 2 * m>{}, std::integral_constant<int, 2 * m + 2>{});
+                    {
+                        const _Float16 one = (_Float16)1.0f;
+                        const f16x8 ones = {one, one, one, one, one, one, one, one};
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int dd = d * 16 + g * 4;
-            f32x4 v = oo[X][d];
-            if (a.gate) {
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
+                        for (int X = 0; X < 2; ++X) ls[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pa[X][1], ls[X], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * sigmoidf_(gv[r]);
-            } else {
+                        for (int X = 0; X < 2; ++X) ls[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pa[X][0], ls[X], 0, 0, 0);
+                    }
+                    const char* vr = Vp + (k0 + m * 32) * RST + voff;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= inv;
+                    for (int d = 0; d < 3; ++d) {
+                        f16x8 vb[2];
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const s16x4 lo = lds_tr16(vr + p * PLN + d * 32);
+                            const s16x4 hi = lds_tr16(vr + p * PLN + d * 32 + 16 * RST);
+                            vb[p] = __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                        }
+#pragma unroll
+                        for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0], pa[X][1], oo[X][d], 0, 0, 0);
+#pragma unroll
+                        for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[1], pa[X][0], oo[X][d], 0, 0, 0);
+#pragma unroll
+                        for (int X = 0; X < 2; ++X) oo[X][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vb[0], pa[X][0], oo[X][d], 0, 0, 0);
+                    }
+                };
+                pv(I0{});
+                if (full) {
+                    pv(I1{});
+                } else if (k_next >= 0) {
+                    bias_issue(k_next, I2{}, I4{});             // (a half tile is the last of its row: not reached)
+                }
             }
-            *reinterpret_cast<f32x4*>(op + dd) = v;
+            if (wave == 0) STAMP()
+            __syncthreads();
+            if (wave == 0) STAMP()
         }
+        // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            const int qrow = (qtA + X) * 16 + lq;
+            if (qtA + X >= nqt || qrow >= L) continue;
+            const float inv = 0.0625f / ls[X][0];               // O^T accumulated (16 v) (P 2^8), ls = sum P 2^8 (every row)
+            const long long go = cur.base + (long long)qrow * a.sl;
+            float* op = a.out + (long long)cur.b * a.ob + (long long)cur.s * a.os + (long long)qrow * a.ol + cur.h * TD;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int dd = d * 16 + g * 4;
+                f32x4 v = oo[X][d];
+                if (a.gate) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(a.gate + go + dd);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * inv * sigmoidf_(gv[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= inv;
+                }
+                *reinterpret_cast<f32x4*>(op + dd) = v;
+            }
+        }
+        if (wave == 0) STAMP()
+#ifdef TRI8_STAMP
+        ++st_row;
+#endif
+        slot = next_slot(slot + NW, cur);
     }
-    if (wave == 0) STAMP()
 #undef STAMP
     probe.finish();
 }
@@ -1155,7 +1215,21 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         aa.row_groups = ((long long)a.B * a.H) % 8 == 0 ? 1 : 2;
         const long long nvp8 = ((long long)a.B * a.H * aa.row_groups + 7) / 8 * 8, rows_g = (a.S + aa.row_groups - 1) / aa.row_groups;
         ABX_REQUIRE(nvp8 * rows_g * aa.q_parts < (1LL << 31), "abx_tri_attn_fwd: grid too large");
-        const dim3 grid((unsigned)(nvp8 * rows_g * aa.q_parts)), block(TRI_THREADS);
+        // tri_attn4: one workgroup per (b, h, row, part) slot; tri_attn8: persistent, one workgroup per CU (8 XCDs x CUs / 8), each
+        // walking the slots of its XCD with a stride of the workgroups per XCD
+        static int n_cu = 0;
+        if (paired && n_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+                abx_set_error("abx_tri_attn_fwd: hipGetDeviceProperties failed");
+                return ABX_ERR_ARG;
+            }
+            n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+        }
+        const long long slots_xcd = nvp8 / 8 * rows_g * aa.q_parts;
+        const unsigned wg_xcd = paired ? (unsigned)std::min<long long>(n_cu / 8, slots_xcd) : 0;
+        const dim3 grid(paired ? 8 * wg_xcd : (unsigned)(nvp8 * rows_g * aa.q_parts)), block(TRI_THREADS);
         auto launch = [&](auto kern, size_t lds4) -> int {
             if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds4, "abx_tri_attn_fwd")) return rc;
             hipLaunchKernelGGL(kern, grid, block, lds4, st, aa);
@@ -1165,7 +1239,10 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         if (paired) {
             const float* bb = a.bias;
             const bool bvec = bb && a.bias_sk == 1 && a.bias_sq % 4 == 0 && a.bias_sq >= 4 && a.bias_sb % 4 == 0 && a.bias_sh % 4 == 0 && al16(bb);
-            if (a.tune & 2)              // 128-key chunks (benchmarking)
+            // key chunks of 192 unless 128 gives the same number of chunks (then: less LDS to fill before the first tile, a less ragged
+            // last chunk; L = 231: 2.52 vs 2.79 ms at 20 samples, L = 352: 21.2 vs 19.2 ms at 100).  tune bit 1 flips the choice.
+            const bool kc128 = (((a.L + 127) / 128 == (a.L + 191) / 192) != ((a.tune & 2) != 0));
+            if (kc128)
                 return bvec ? launch(&tri_attn8_kernel<128, TRI_THREADS, true>, lds_of(128, true))
                             : launch(&tri_attn8_kernel<128, TRI_THREADS, false>, lds_of(128, true));
             return bvec ? launch(&tri_attn8_kernel<192, TRI_THREADS, true>, lds_of(192, true))

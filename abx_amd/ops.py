@@ -359,7 +359,8 @@ def tri_attn_kernel_name(L, exact=None, bias_vec=True):
     """Name of the kernel abx_tri_attn_fwd launches (mirror of the selection in csrc/attention.hip), for per-kernel aggregation."""
     if GEMM_EXACT if exact is None else exact:
         return 'tri_attn_kernel'
-    return 'tri_attn8_kernel<192, 768, %s>' % ('true' if bias_vec else 'false')
+    kc = 128 if (L + 127) // 128 == (L + 191) // 192 else 192
+    return 'tri_attn8_kernel<%d, 768, %s>' % (kc, 'true' if bias_vec else 'false')
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):

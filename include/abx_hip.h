@@ -195,12 +195,17 @@ typedef struct AbxTriAttn {
     float* out; long long ob, os, ol;               /* out (b,s,l,h*D+d) */
     int B, S, L, H, D;                              /* D must be 48 */
     float scale;
-    int exact;                                      /* 0: split-f16 matrix-core kernel (see AbxGemm: keys / values staged as B-side planes with
-                                                       e = 4, |k|, |v| < 4095; queries and softmax weights as A-side pieces; any L);
+    int exact;                                      /* 0: split-f16 matrix-core kernel (csrc/attention.hip tri_attn8_kernel; any L): keys / values
+                                                       staged as two float16 planes of 16 x (|k|, |v| < 4095; 2^-29 absolute below 2^-6),
+                                                       queries as two pieces of q * scale * log2(e) * 8 (|q * scale| < 5600), softmax weights
+                                                       as two pieces of P * 2^8: 3 exact float16 products per fp32 product, fp32 accumulate;
+                                                       an operand beyond its range gives NaN in its output rows, never a wrong number;
                                                        1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
-    unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernel) */
-    int tune;                                       /* 0 = library default; bit 0: never the producer-wave variant, bit 1: its 128-key chunks (benchmarking;
-                                                       all variants give bit-identical results) */
+    unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernels) */
+    int tune;                                       /* 0 = library default (persistent workgroups, two query tiles per wave walked together);
+                                                       bit 1: the other key-chunk size (128 <-> 192; bit-identical results); bit 2: the round-3
+                                                       kernel tri_attn4 (one workgroup per row, one query tile at a time; with bit 0: without
+                                                       its producer wave) - benchmarking and cross-checks: its accumulation order differs */
     int q_parts, row_groups;                        /* filled by the library */
 } AbxTriAttn;
 int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);

@@ -1,5 +1,5 @@
 """Triangle attention variants (AbxTriAttn.tune): 0 = library choice (tri_attn8: 11 computing waves walk two query tiles together + 1
-producer wave), 2 = the same on 128-key chunks instead of 192, 4 = the round-3 kernel tri_attn4 (one query tile at a time; producer
+producer wave), 2 = the same with the other key-chunk size (128 <-> 192), 4 = the round-3 kernel tri_attn4 (one query tile at a time; producer
 wave), 5 = tri_attn4 with 12 computing waves that share the staging.  Usage: kb_tri.py [Bc] [L] [m = mask the last 7 keys]"""
 import sys
 import torch
