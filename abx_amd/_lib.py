@@ -49,6 +49,7 @@ class AbxGemm(C.Structure):
         ('exact', I),
         ('b_f16', I), ('b_exp', I), ('b2_exp', I),
         ('tune', I),
+        ('range_flag', c_f), ('range_tag', I),
         ('clock_probe', c_f),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
         ('c_vec_ok', I), ('g_vec_ok', I), ('r_vec_ok', I), ('rs_vec_ok', I),
@@ -70,6 +71,7 @@ class AbxIpaTail(C.Structure):
         ('W_aff', c_f), ('b_aff', c_f),
         ('fixed', c_f), ('init_q', c_f), ('init_t', c_f),
         ('cur_q', c_f), ('cur_t', c_f), ('cur_R', c_f), ('delta_q', c_f), ('pscale', F),
+        ('range_flag', c_f), ('range_tag', I),
     ]
 
 
@@ -84,6 +86,7 @@ class AbxTriAttn(C.Structure):
         ('scale', F),
         ('exact', I),
         ('clock_probe', c_f),
+        ('range_flag', c_f), ('range_tag', I),
         ('tune', I),
         ('q_parts', I), ('row_groups', I),
     ]

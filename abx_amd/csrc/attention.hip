@@ -595,6 +595,20 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
         }
         if (DB) __syncthreads();
     }
+    if (a.range_flag) {                                         // range safety, see tri_attn8_kernel
+        float z = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < MAXQ; ++sl) {
+            const int qt = qt0 + wave + sl * NCW;
+            const bool live = wave < NCW && qt < nqt && qt * 16 + lq < L;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z = fmaf(live ? o[sl][d][r] : 0.f, 0.f, z);
+            z = fmaf(live ? l_run[sl] : 0.f, 0.f, z);
+        }
+        if (__any(z != z) && lane == 0) atomicOr(a.range_flag, a.range_tag);
+    }
     // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
 #pragma unroll
     for (int sl = 0; sl < MAXQ; ++sl) {
@@ -1014,6 +1028,7 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
             __syncthreads();
             if (wave == 0) STAMP()
         }
+        bool bad = false;           // range safety (AbxTriAttn.range_flag): a key / value / query / gate beyond the split ranges, or not finite
         // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
@@ -1034,9 +1049,12 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= inv;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad |= __builtin_amdgcn_classf(v[r], 0x207);
                 *reinterpret_cast<f32x4*>(op + dd) = v;
             }
         }
+        if (a.range_flag && __any(bad) && lane == 0) atomicOr(a.range_flag, a.range_tag);
         if (wave == 0) STAMP()
 #ifdef TRI8_STAMP
         ++st_row;

@@ -101,6 +101,10 @@ __device__ __forceinline__ float sigmoidf_(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 
+// ReLU that keeps a NaN (fmaxf / v_max_f32 return the other operand): an accumulator that an out-of-range split-f16 operand has
+// turned into NaN must reach the output and the range probe, not become a silent 0
+__device__ __forceinline__ float relu_keep_nan(float x) { return x < 0.f ? 0.f : x; }
+
 // Diagnostics (AbxGemm.clock_probe / AbxTriAttn.clock_probe): shader-clock and constant-100-MHz ticks a workgroup was resident for
 struct ClockProbe {
     unsigned long long c0, r0;

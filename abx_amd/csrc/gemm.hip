@@ -269,7 +269,7 @@ __device__ __forceinline__ void gemm_block(const AbxGemm& g, float* smem, int mt
             __syncthreads();
         }
     }
-    gemm_epilogue<BM, BN, WM, WN, EDGE, TS>(g, st_lds, smem + 2 * BM, acc, m0, n0, b, stats);
+    gemm_epilogue<BM, BN, WM, WN, EDGE, TS, false, false>(g, st_lds, smem + 2 * BM, acc, m0, n0, b, stats);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool AKC, bool BNC, bool TS, int MINW>
@@ -461,6 +461,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
         int rc = 0;
         if (!abx_gemm3_dispatch(g, st, &rc)) return rc;
     }
+    g.range_flag = nullptr;                 // exact fp32 products from here on: no operand range, a non-finite result is the input's
     ABX_REQUIRE(g.A && g.B, "abx_gemm: split-f16 operands given but the problem does not qualify for the split kernels "
                             "(K % 16, alignment, size) and no fp32 operands were passed for the exact kernel");
     ABX_REQUIRE(g.a_pair_transpose <= 0 && g.pair_Lp == 0, "abx_gemm: pair-row remapping is served by the split-f16 kernels only");

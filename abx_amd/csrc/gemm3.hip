@@ -372,7 +372,7 @@ __device__ __forceinline__ bool gemm3_row_stats(const AbxGemm& g, float* st_lds,
     return gstats != nullptr || ln_inline;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false>
+template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false, bool PROBE = true>
 __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN];
@@ -381,7 +381,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
     float* st_lds = smem;                                   // [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     __syncthreads();
-    gemm_epilogue<BM, BN, WM, WN, EDGE, TS, OLN>(g, st_lds, smem + 2 * BM, acc, mt * BM, nt * BN, b, stats);
+    gemm_epilogue<BM, BN, WM, WN, EDGE, TS, OLN, PROBE>(g, st_lds, smem + 2 * BM, acc, mt * BM, nt * BN, b, stats);
 }
 
 // Dual GEMM (the TriangleMultiplication tail, seqformer.py:496-503): out = epi(A' B) * sigmoid(LN(A2) B2 + bias2) (+ resid).
@@ -435,8 +435,9 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     const ClockProbe probe(g.clock_probe);
-    if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS>(g, smem, mt, nt, b);
-    else gemm3_block<BM, BN, WM, WN, AMODE, true, TS>(g, smem, mt, nt, b);
+    constexpr bool PROBE = !(BM == 128 && BN == 128 && MINW >= 4);      // (no register for it at four blocks per CU: gemm_epilogue.h)
+    if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS, false, PROBE>(g, smem, mt, nt, b);
+    else gemm3_block<BM, BN, WM, WN, AMODE, true, TS, false, PROBE>(g, smem, mt, nt, b);
     probe.finish();
 }
 
@@ -563,7 +564,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = rstd * (acc1[0][j][8 * s2 + 4 * q + e] - dmean * cs[e]) + bi[e];
-                            x = fmaxf(x, 0.f);
+                            x = relu_keep_nan(x);
                             v[4 * q + e] = (hc + e < g.N) ? x : 0.f;
                         }
                     }
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = acc[0][j][4 * q + e] + bi[e];
-                x[j][4 * q + e] = relu ? fmaxf(v, 0.f) : v;
+                x[j][4 * q + e] = relu ? relu_keep_nan(v) : v;
             }
         });
     };
@@ -750,6 +751,14 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[j][r] += res[j][r];
     layer_norm(a.ln2_w, a.ln2_b);
+    if (a.range_flag) {                                         // range safety (AbxGemm.range_flag): a row that left the split range is NaN by now
+        float z = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z = fmaf(x[j][r], 0.f, z);
+        if (__any(z != z) && lane == 0) atomicOr(a.range_flag, a.range_tag);
+    }
     to_lds(act[1]);
     __syncthreads();
     for (int idx = threadIdx.x; idx < BM * (IT_C / 4); idx += 256) {

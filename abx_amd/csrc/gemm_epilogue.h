@@ -6,7 +6,10 @@
 #include "common.h"
 #include "abx_hip.h"
 
-template <int BM, int BN, int WM, int WN, bool EDGE, bool TS, bool OLN = false>
+// PROBE: the range probe (AbxGemm.range_flag) is compiled in.  Off for the exact fp32 kernels (no operand range) and for the 128 x 128
+// split tiles at four blocks per CU, whose 128 registers have no room for it: their outputs (q | k | v | gate, gated projections) are
+// operands of kernels that carry the probe (triangle attention, contraction), so a NaN row made there is reported one kernel later.
+template <int BM, int BN, int WM, int WN, bool EDGE, bool TS, bool OLN = false, bool PROBE = true>
 __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __restrict__ st_lds, float* __restrict__ scratch,
                                               f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats,
                                               f32x16 (*acc2)[WM / 32][WN / 32] = nullptr, const float* __restrict__ st2_lds = nullptr) {
@@ -19,6 +22,10 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
     const float* gt = g.gate ? g.gate + (long long)b * g.sGb : nullptr;
     const float* rd = g.resid ? g.resid + (long long)b * g.sRb : nullptr;
     const bool c_vec = g.c_vec_ok != 0, g_vec = g.g_vec_ok != 0, r_vec = g.r_vec_ok != 0, gsig = g.gate_sigmoid != 0;
+    // range safety (AbxGemm.range_flag): an operand beyond the split-f16 ranges has become inf - inf = NaN in the accumulators of its
+    // row / column, and NaN survives everything this epilogue does (relu_keep_nan, gates, residual, LayerNorm), so the probe looks at
+    // the values on their way to memory: v_cmp_class per stored value, OR-ed as lane masks in SGPRs (no vector registers)
+    bool bad = false;
     float bias[TN], csum[TN], bias2[TN], csum2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -33,7 +40,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
     auto epi1 = [&](float v, int ml, int j) -> float {
         if (stats) v = st_lds[2 * ml + 1] * (v - st_lds[2 * ml] * csum[j]);
         v = (v + bias[j]) * g.alpha;
-        if (g.act == 1) v = fmaxf(v, 0.f);
+        if (g.act == 1) v = relu_keep_nan(v);
         else if (g.act == 2) v = sigmoidf_(v);
         return v;
     };
@@ -62,6 +69,10 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             const f32x4 rv = load4(rd + off_r, r_vec, cnt);
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] += rv[c];
+        }
+        if constexpr (PROBE) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bad |= __builtin_amdgcn_classf(v[c], 0x207) && c < cnt;
         }
         if (g.C_split) {
             // output as the pre-split f16 operand image of the next contraction, two planes per channel: channels below c_split_nA are
@@ -283,5 +294,8 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    }
+    if constexpr (PROBE) {
+        if (g.range_flag && __any(bad) && lane == 0) atomicOr(g.range_flag, g.range_tag);
     }
 }

@@ -62,6 +62,8 @@ class ScoreNetwork(nn.Module):
         self._engine_key = None
         self._engine_serial = 0
         self._bufs = {}
+        self.range_log = []              # passes that left the split-f16 operand ranges and were repeated on the exact kernels
+        self._n_calls = 0
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         """The ESM2 module of a reference checkpoint belongs to the external embedding provider, not to this module."""
@@ -127,6 +129,7 @@ class ScoreNetwork(nn.Module):
             batch['_static'] = hit
         self._static = hit[1]
         num_recycle = self._model_conf.num_recycle
+        self._n_calls += 1
         with torch.no_grad():
             batch.update(is_recycling=True)
             for _ in range(num_recycle):
@@ -197,8 +200,31 @@ class ScoreNetwork(nn.Module):
         from abx_amd import ops
         ops.timestep_embedding(st['t64'], c.index_embed_size, st['temb'])
         chunk = max(1, min(self.max_chunk, B)) if self.max_chunk else self._auto_chunk(B, L, device)
+        # Range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag): the kernels OR a bit into the device's range word
+        # when an accumulator is not finite - what an activation beyond their operand ranges becomes (the reference's plain fp32
+        # contractions have no such range: seqformer.py:260-312, 443-504).  The word is read once per pass (the inputs of a pass, the
+        # previous pass's buffers, are still intact then) and a flagged pass is repeated on the exact fp32-MFMA kernels, so a caller never
+        # sees the contract: results are the reference's either way.  Inside a hipGraph capture the word only accumulates
+        # (abx_amd.graph checks it after each replay).
+        word = ops.range_word(device) if ops.RANGE_CHECK and not ops.GEMM_EXACT else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        if word is not None and not capturing:
+            word.zero_()
         for b0 in range(0, B, chunk):
             eng.run_chunk(st, b0, min(B, b0 + chunk), final)
+        if word is not None and not capturing:
+            bits = int(word.item())
+            if bits:
+                self.range_log.append({'call': self._n_calls, 'ops': ops.range_names(bits), 'L': L, 'B': B})
+                if L > 389 and (bits & ops.RANGE_TAGS['tri_attn']):
+                    raise FloatingPointError(f'triangle attention operands left the split-f16 range (|k|, |v| < 4095, |q| scale < 5600) or are not '
+                                             f'finite, and the exact fp32 kernel serves L <= 389 only (L = {L})')
+                ops.GEMM_EXACT = True
+                try:
+                    for b0 in range(0, B, chunk):
+                        eng.run_chunk(st, b0, min(B, b0 + chunk), final)
+                finally:
+                    ops.GEMM_EXACT = False
         folding = {
             'rot_score': st['rot_score'], 'trans_score': st['trans_score'], 'rigids': st['rigids'],
             'final_atom14_positions': st['atom14'], 'final_atom_positions': st['atom37'],

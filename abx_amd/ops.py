@@ -27,6 +27,31 @@ def _f32(t):
 
 GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 
+# ---- range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag) ----------------------------------------------
+# Every split-f16 launch made through this module carries the address of one device word per GPU and a bit that names its call-site
+# class; a kernel whose accumulators are not finite - what an operand beyond the split ranges turns into - ORs its bit into the word.
+# abx_amd.model.abx.ScoreNetwork clears the word before a network pass, reads it after, and repeats the pass on the exact fp32-MFMA
+# kernels when it is set, so the range contract of the fast path never reaches a caller as a wrong or non-finite result.
+RANGE_TAGS = {'gemm': 1, 'contraction': 2, 'plane_projection': 4, 'tri_mul_tail': 8, 'pair_transition': 16, 'ipa_pair_init': 32,
+              'tri_attn': 64, 'ipa_tail': 128}
+RANGE_CHECK = not bool(__import__('os').environ.get('ABX_NO_RANGE_CHECK'))     # (A / B measurements of the probe's cost)
+_range_words = {}
+
+
+def range_word(device):
+    """The int32 [1] range word of a device (created on first use, zero)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    w = _range_words.get(idx)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=torch.device('cuda', idx))
+        _range_words[idx] = w
+    return w
+
+
+def range_names(bits):
+    return [n for n, b in RANGE_TAGS.items() if bits & b]
+
 
 GEMM_EXACT = False   # True: every GEMM on the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32); default: large problems on the
                      # split-f16 kernels of csrc/gemm3.hip (fp32-accurate, see DESIGN.md)
@@ -262,6 +287,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
         g.b_f16, g.b_exp = 1, B3.w_exp
     g.tune = GEMM_TUNE if tune is None else tune
+    if RANGE_CHECK and g.exact != 1:
+        g.range_flag = range_word(Cout.device).data_ptr()
+        g.range_tag = RANGE_TAGS['pair_transition' if mlp is not None else 'tri_mul_tail' if dual is not None else 'ipa_pair_init' if out_ln is not None
+                                 else 'plane_projection' if c_planes else 'contraction' if a_planes else 'gemm']
     if dual is not None:
         A2, B32, csum2, bias2 = dual
         if A2.dim() == 2:
@@ -390,6 +419,8 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.scale = float(D ** (-0.5))
     a.exact = int(GEMM_EXACT if exact is None else exact)
     a.tune = int(tune)
+    if RANGE_CHECK and not a.exact:
+        a.range_flag, a.range_tag = range_word(out.device).data_ptr(), RANGE_TAGS['tri_attn']
     if clock_probe is not None:
         assert clock_probe.dtype == torch.int64 and clock_probe.numel() >= 2
         a.clock_probe = _p(clock_probe)
@@ -440,6 +471,8 @@ def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5, affine=None
         a.W_aff, a.b_aff, a.fixed = _p(_f32(wa)), _p(_f32(ba)), _p(fixed)
         a.init_q, a.init_t, a.cur_q, a.cur_t, a.cur_R, a.delta_q = [_p(_f32(t)) for t in (init_q, init_t, cur_q, cur_t, cur_R, delta_q)]
         a.pscale = float(pscale)
+    if RANGE_CHECK:
+        a.range_flag, a.range_tag = range_word(s.device).data_ptr(), RANGE_TAGS['ipa_tail']
     check(_lib.load().abx_ipa_tail(C.byref(a), _stream()), 'abx_ipa_tail')
     return s
 

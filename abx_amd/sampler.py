@@ -93,22 +93,29 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
             if mode == 'trajectory' or k == len(steps) - 1:
                 traj.append({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in rec.items()})
                 if on_record is not None:
+                    check_finite(traj[-1]['rigids_t'], traj[-1]['atom14_results'], what=f'step {k} (t = {float(t):.4f})')   # before any file is written
                     on_record(traj[-1])
             if on_step is not None:
                 on_step(k, t, batch, out)
+    if not traj:
+        raise ValueError(f'no grid point to sample: optimize step t = {float(batch["t"][0]):.4f} lies below min_t = {min_t} '
+                         f'(grid of {num_t} points on [{min_t}, 1])')
     check_finite(batch['rigids_t'], traj[-1]['atom14_results'])
+    log = getattr(model, 'range_log', None)
+    if log:
+        traj[-1]['range_fallbacks'] = list(log)         # passes repeated on the exact kernels (which call, which op classes)
     return traj
 
 
-def check_finite(*tensors):
-    """One reduction + host sync at the end of a trajectory.  The split-f16 contractions turn an operand beyond their range
-    (include/abx_hip.h, "Split-f16 operands": |x| >= 2^20, 4095 for attention keys / values and the right tri-mul operand) into NaN
-    rows instead of wrong numbers; this is where that becomes an error, with the remedy."""
+def check_finite(*tensors, what='the end of the trajectory'):
+    """One reduction + host sync.  The split-f16 contractions turn an operand beyond their range (include/abx_hip.h, "Split-f16
+    operands") into NaN rows instead of wrong numbers, the network repeats such a pass on the exact kernels by itself
+    (model/abx.py, AbxGemm.range_flag); what is still not finite here comes from the inputs or the weights."""
     ok = torch.stack([torch.isfinite(t).all() for t in tensors if t is not None and t.numel() > 0] or [torch.tensor(True)]).all()
     if not bool(ok):
-        raise FloatingPointError('non-finite frames / coordinates at the end of the trajectory: an activation left the range of the '
-                                 'split-f16 kernels (or the inputs / weights are not finite).  Re-run with the exact fp32-MFMA '
-                                 'kernels: abx_amd.ops.GEMM_EXACT = True (design.py --exact_gemm)')
+        raise FloatingPointError(f'non-finite frames / coordinates at {what}: the inputs or the weights are not finite (an activation '
+                                 'beyond the range of the split-f16 kernels is handled inside ScoreNetwork: the pass is repeated on the '
+                                 'exact fp32-MFMA kernels, see ScoreNetwork.range_log)')
 
 
 # -------------------------------------------------------------------------------------------------------------------

@@ -135,6 +135,11 @@ typedef struct AbxGemm {
     /* float16 weight planes: see "Split-f16 operands" above.  b_exp / b2_exp: exponents of B_split / B2_split (|.| <= 100) */
     int b_f16, b_exp, b2_exp;
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
+    int* range_flag; int range_tag;                /* range safety of the split-f16 kernels, optional DEVICE [1]: a workgroup whose accumulators
+                                                      are not finite - what an operand beyond the split ranges above turns into, inf - inf,
+                                                      and what a non-finite input gives too - ORs range_tag into *range_flag (one atomic per
+                                                      wave, only then).  The caller clears the word, gives every call site its own bit, reads
+                                                      it after a pass and repeats the pass with exact = 1 (abx_amd/model/abx.py does) */
     unsigned long long* clock_probe;               /* diagnostics, optional DEVICE [2]: every workgroup of the split-f16 kernels adds
                                                       its elapsed shader-clock ticks (s_memtime) to [0] and its elapsed constant
                                                       100 MHz ticks (s_memrealtime) to [1]: 100 MHz * [0] / [1] = the shader clock
@@ -167,6 +172,7 @@ typedef struct AbxIpaTail {
     const float* W_aff; const float* b_aff;
     const int* fixed; const float* init_q; const float* init_t;
     float* cur_q; float* cur_t; float* cur_R; float* delta_q; float pscale;
+    int* range_flag; int range_tag;                /* see AbxGemm.range_flag: set when the layer's output rows are not finite */
 } AbxIpaTail;
 int abx_ipa_tail(const AbxIpaTail* desc, hipStream_t stream);
 /* diagnostics: resident workgroups per CU of the main split-f16 GEMM instantiations (0: 128x192, 1: 128x128,
@@ -202,6 +208,7 @@ typedef struct AbxTriAttn {
                                                        an operand beyond its range gives NaN in its output rows, never a wrong number;
                                                        1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
     unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernels) */
+    int* range_flag; int range_tag;                 /* see AbxGemm.range_flag: set when a query row's output is not finite (split-f16 kernels) */
     int tune;                                       /* 0 = library default (persistent workgroups, two query tiles per wave walked together);
                                                        bit 1: the other key-chunk size (128 <-> 192; bit-identical results); bit 2: the round-3
                                                        kernel tri_attn4 (one workgroup per row, one query tile at a time; with bit 0: without

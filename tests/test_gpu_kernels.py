@@ -500,6 +500,81 @@ def test_gemm_small_n_and_relu_input(ops):
     assert float(wide[:, :100].abs().max()) == 0 and float(wide[:, 164:].abs().max()) == 0
 
 
+def test_range_word_names_the_op_that_left_the_split_range(ops):
+    """Range safety at the source (include/abx_hip.h, AbxGemm.range_flag; the reference's plain fp32 contractions have no operand range,
+    seqformer.py:260-312, 443-504): every split-f16 kernel ORs the bit of its call-site class into the device's range word when an
+    accumulator is not finite.  An in-range problem leaves the word clear; an A element beyond 2^20, a key / value beyond 4095, a query
+    beyond 5600 / scale, and a pair row beyond 2^20 in front of the fused transition (whose hidden ReLU must not swallow the NaN) set
+    the bit of THEIR op, turn exactly the affected rows into NaN and leave every other row bit-identical."""
+    word = ops.range_word(DEV)
+    T = ops.RANGE_TAGS
+    # ---- weight GEMM
+    M, N, K = 4096, 192, 192
+    A = torch.randn(M, K, generator=g(801)).to(DEV)
+    Wt = (torch.randn(N, K, generator=g(802)) / K ** 0.5).t().contiguous().to(DEV)
+    w3 = ops.split_weights(Wt)
+    o0, o1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    word.zero_()
+    ops.gemm(A, Wt, o0, B3=w3, exact=2)
+    assert int(word.item()) == 0 and torch.isfinite(o0).all()
+    A2 = A.clone(); A2[77, 5] = 2.0 ** 20 * 1.5
+    ops.gemm(A2, Wt, o1, B3=w3, exact=2)
+    assert int(word.item()) == T['gemm']
+    bad = ~torch.isfinite(o1).all(1)
+    assert bad[77] and int(bad.sum()) == 1 and torch.equal(o1[~bad], o0[~bad])
+    # the exact kernel never touches the word
+    word.zero_()
+    ops.gemm(A2, Wt, o1, exact=True)
+    assert int(word.item()) == 0 and torch.isfinite(o1).all()
+    # ---- fused pair transition: LayerNorm -> 768 -> ReLU -> 192 + residual (the NaN must survive the hidden ReLU)
+    M = 128 * 300
+    z = torch.randn(M, 192, generator=g(803)).to(DEV)
+    W1 = (torch.randn(192, 768, generator=g(804)) / 14).to(DEV); W2 = (torch.randn(768, 192, generator=g(805)) / 28).to(DEV)
+    b1, b2, cs = torch.randn(768, generator=g(806)).to(DEV), torch.randn(192, generator=g(807)).to(DEV), W1.sum(0).contiguous()
+    W13, W23 = ops.split_weights(W1), ops.split_weights(ops.permute_k16(W2))
+    r0 = torch.empty_like(z); r1 = torch.empty_like(z)
+    word.zero_()
+    ops.gemm(z, W1, r0, bias=b1, ln=(None, cs), B3=W13, act=1, resid=z, exact=2, mlp=(W23, b2))
+    assert int(word.item()) == 0
+    z2 = z.clone(); z2[1000, 17] = 3e6
+    ops.gemm(z2, W1, r1, bias=b1, ln=(None, cs), B3=W13, act=1, resid=z2, exact=2, mlp=(W23, b2))
+    assert int(word.item()) == T['pair_transition']
+    bad = ~torch.isfinite(r1).all(1)
+    assert bad[1000] and int(bad.sum()) == 1 and torch.equal(r1[~bad], r0[~bad])
+    # ---- triangle attention: key, value, query
+    B, L, H, D = 1, 96, 4, 48
+    C = H * D
+    x = torch.randn(B * L * L, 4 * C, generator=g(808)).to(DEV)
+    bT = torch.randn(B, H, L, L, generator=g(809)).to(DEV)
+    mask = torch.ones(B, L, device=DEV)
+    ref = torch.empty(B * L * L, C, device=DEV)
+    word.zero_()
+    ops.tri_attn(x, bT, mask, ref, B, L, True)
+    assert int(word.item()) == 0 and torch.isfinite(ref).all()
+    row = lambda s_, l_: s_ * L + l_
+    for what, col, val in (('key', C + 1 * D + 7, 5000.0), ('value', 2 * C + 2 * D + 40, -4500.0), ('query', 3 * D + 3, 1e5)):
+        x2 = x.clone(); x2[row(5, 9), col] = val
+        o = torch.empty_like(ref)
+        word.zero_()
+        ops.tri_attn(x2, bT, mask, o, B, L, True)
+        assert int(word.item()) == T['tri_attn'], what
+        nanmask = ~torch.isfinite(o)
+        h = (col % C) // D
+        expect = torch.zeros_like(nanmask)
+        if what == 'query':
+            expect[row(5, 9), h * D:(h + 1) * D] = True                  # that query only
+        elif what == 'key':
+            expect.view(L, L, C)[5, :, h * D:(h + 1) * D] = True         # every query of row 5, head h
+        else:
+            expect.view(L, L, C)[5, :, col % C] = True                   # one output channel of row 5
+        assert torch.equal(nanmask, expect), what
+        assert torch.equal(o[~nanmask], ref[~nanmask]), what
+        oe = torch.empty_like(ref)
+        word.zero_()
+        ops.tri_attn(x2, bT, mask, oe, B, L, True, exact=True)
+        assert int(word.item()) == 0 and torch.isfinite(oe).all(), what
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('exact', [False, True])
 @pytest.mark.parametrize('L,per_row', [(40, True), (40, False), (64, True), (97, False), (200, True), (212, False), (261, True), (300, False)])

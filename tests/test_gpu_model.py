@@ -241,6 +241,65 @@ def test_split_f16_contraction_path_vs_oracle(gpu_model, params, cfg, oracle_dif
     assert not torch.equal(ret['representations']['pair'], rex['representations']['pair']), 'both runs took the same kernels'
 
 
+def test_out_of_range_activations_fall_back_to_the_exact_kernels(params, cfg, oracle_diffuser, gpu_model):
+    """No range contract reaches the caller (the reference's fp32 contractions have none, seqformer.py:260-312, 443-504):
+    with one key channel of the starting-node triangle attention and one right-operand channel of the outgoing triangle
+    multiplication rescaled beyond 4095 (the plane range of the split-f16 kernels), a network call still returns the oracle's numbers: the kernels flag the op at the source (ops.range_word), ScoreNetwork repeats the flagged passes on the exact
+    fp32-MFMA kernels and logs which op classes left the range."""
+    from collections import OrderedDict
+    from oracle import abx_oracle as O
+    from abx_amd import sampler, ops
+    from abx_amd.model.abx import ScoreNetwork
+    _, D = gpu_model
+    big = OrderedDict((k, v.clone()) for k, v in params.items())
+    blk = 'impl.seqformer.seqformer.blocks.0.'
+    # one key channel per head x 6000 with its query channel / 6000, one right tri-mul channel x 5000 with its left channel / 5000:
+    # the network computes the same function (logits and products unchanged), but those key / right-operand values pass 4095
+    ta, tm = blk + 'triangle_attention_starting_node.attn.', blk + 'triangle_multiplication_outgoing.'
+    for h in range(4):
+        big[ta + 'proj_k.weight'][h * 48 + 3] *= 6000.0
+        big[ta + 'proj_q.weight'][h * 48 + 3] /= 6000.0
+    big[tm + 'right_proj.weight'][5] *= 5000.0
+    big[tm + 'left_proj.weight'][5] /= 5000.0
+    for side, fac in (('right', 5000.0), ('left', 1 / 5000.0)):
+        if big.get(tm + side + '_proj.bias') is not None:
+            big[tm + side + '_proj.bias'][5] *= fac
+    model = ScoreNetwork(cfg.model, D)
+    model.load_state_dict(big, strict=True)
+    model = model.to(DEV).eval()
+    w = dict(L_heavy=50, L_light=44, L_antigen=26, cdr=(30, 39))
+    B = 3
+    b = _synthetic_batch(D, w, B=B)
+    t_ = torch.full((B,), 0.4040404040404041, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+    cpu = _cpu_copy(b)
+    cp = lambda d: {k: (cp(v) if isinstance(v, dict) else v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    ret = cp(model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}))
+    assert len(model.range_log) >= 1, 'the scaled projections did not leave the split range: the test does not test'
+    seen = set(sum((e['ops'] for e in model.range_log), []))
+    assert 'tri_attn' in seen and ('contraction' in seen or 'tri_mul_tail' in seen), model.range_log
+    ops.GEMM_EXACT = True
+    try:
+        rex = cp(model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}))
+    finally:
+        ops.GEMM_EXACT = False
+    ref = O.score_network(big, cpu, cfg, oracle_diffuser)
+    f, fe, fr = ret['heads']['folding'], rex['heads']['folding'], ref['heads']['folding']
+    assert torch.isfinite(f['rigids']).all() and torch.isfinite(ret['representations']['pair']).all()
+    # the flagged passes ran on the exact kernels in both runs (a pass that stayed in range kept the split kernels: not the same bits)
+    close(f['rigids'], fe['rigids'], 1e-4, 1e-4, 'rigids vs forced exact')
+    close(ret['representations']['pair'], rex['representations']['pair'], 3e-4, 1e-4, 'pair vs forced exact')
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'], rex['heads']['sequence_module']['seq_0'])
+    assert (ret['heads']['sequence_module']['seq_0'].cpu() == ref['heads']['sequence_module']['seq_0']).all()
+    close(f['rigids'], fr['rigids'], 2e-4, 1e-4, 'rigids')
+    close(ret['heads']['sequence_module']['logits'], ref['heads']['sequence_module']['logits'], 3e-4, 1e-4, 'logits')
+    # and the in-range model of the other tests logs nothing
+    m0, _ = gpu_model
+    n0 = len(m0.range_log)
+    m0({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
+    assert len(m0.range_log) == n0 == 0, m0.range_log
+
+
 def test_split_f16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_diffuser):
     """Driver-level parity with the split-f16 kernels active (L = 112, 3 samples: every GEMM, the plane contraction and the
     triangle attention run on the float16 matrix cores), TEACHER-FORCED (SURVEY §7 hard part 1a): the warm-up call and every grid
