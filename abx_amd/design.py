@@ -76,6 +76,16 @@ def read_model_features(path):
     return 'H3', []
 
 
+def _write_designs(out_dir, cname, rows):
+    """<out_dir>/<complex>_designs.tsv: (sample id, mean pLDDT, designed antibody sequence) per sample."""
+    tsv = os.path.join(out_dir, f'{cname}_designs.tsv')
+    with open(tsv, 'w') as f:
+        f.write('sample\tmean_pLDDT\tantibody_sequence\n')
+        for i, pl, toks in rows:
+            f.write(f'{i}\t{pl:.3f}\t{index_to_str_seq(toks)}\n')
+    return tsv
+
+
 def _relaunch_on_gpus(gpu_list, argv):
     """--gpu_list a b c ... outside torch.distributed.run: one rank per listed GPU on 127.0.0.1."""
     import socket
@@ -117,6 +127,12 @@ def main(argv=None):
     ap.add_argument('--gpu_list', type=int, nargs='+', default=None, help='GPUs to use, one rank each (default: the launcher\'s ranks / GPU 0)')
     ap.add_argument('--batch_size', type=int, default=1, help='accepted for compatibility (complexes per batch upstream); ignored')
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--min_block', type=int, default=50, help='set-level schedule: samples per work unit (a complex is split into '
+                    'num_samples // min_block blocks)')
+    ap.add_argument('--shard_samples', action='store_true', help='several complexes on several ranks: shard the samples of EVERY complex over '
+                    'the ranks (one gather per complex) instead of dealing (complex, sample block) units to the ranks')
+    ap.add_argument('--force_collective', action='store_true', help='single rank: still initialise RCCL and run the final gather through a '
+                    '1-rank all_gather (exercises the collective path on a 1-GPU box; same results)')
     ap.add_argument('--exact_gemm', action='store_true', help='exact fp32-MFMA kernels instead of the split-f16 ones (slower; the remedy when '
                     'the sampler reports non-finite frames: an activation beyond the split kernels\' range)')
     a = ap.parse_args(argv)
@@ -133,7 +149,11 @@ def main(argv=None):
         ap.error('--name_idx needs --data_dir')
     opt_steps = [a.optimize_steps]
     if a.model_features:
-        a.generate_area, steps = read_model_features(a.model_features)
+        area, steps = read_model_features(a.model_features)
+        if area != a.generate_area and a.generate_area != ap.get_default('generate_area'):
+            import warnings
+            warnings.warn(f'--generate_area {a.generate_area} is overridden by the make_diffuser_features entry of --model_features ({area})')
+        a.generate_area = area
         if a.mode == 'optimize' and steps:
             opt_steps = steps
 
@@ -148,10 +168,15 @@ def main(argv=None):
     dev = torch.device(a.device if a.device else ('cuda:0' if a.debug_one_gpu else f'cuda:{local_rank}'))
     torch.cuda.set_device(dev)
     group = None
-    if world > 1:
+    if world > 1 or a.force_collective:
         import torch.distributed as dist
         if not dist.is_initialized():
-            dist.init_process_group('gloo' if a.debug_one_gpu else 'nccl', rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29577')
+            if a.debug_one_gpu:
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+            else:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # "nccl" is RCCL on ROCm
 
     cfg = load_config(a.model_config) if a.model_config else default_config()
     diffuser = FullDiffuser.get(cfg.diffuser).to(dev)
@@ -168,9 +193,7 @@ def main(argv=None):
         from .guidance import ViolationGuidance
         guide = ViolationGuidance(scale_trans=a.guidance_scale[0], scale_rot=a.guidance_scale[1])
     N = a.num_samples
-    ids = sampler.shard_sample_ids(N, rank, world)             # the global sample ids this rank runs, for every complex
-    n = len(ids)
-    # jobs: (kind, reference to the complex, output directory, optimize step, inference.py layout?)
+    # jobs: (kind, reference to the complex, output directory, optimize step, inference.py layout?, directory of the ground-truth copy)
     jobs = []
     if a.name_idx:
         with open(a.name_idx) as f:
@@ -178,50 +201,90 @@ def main(argv=None):
         root = os.path.join(a.output_dir, a.mode)
         for step in (opt_steps if a.mode == 'optimize' else [None]):
             out = os.path.join(root, f'OPT-{step}') if a.mode == 'optimize' else root
-            jobs += [('npz', nm, out, step, True) for nm in names]
+            # inference.py:321-322, 354-355: the ground truth goes to <output_dir>/<mode>/reference/ in every mode (in optimize mode it
+            # is re-written, unchanged, for every step: once is enough)
+            jobs += [('npz', nm, out, step, True, os.path.join(root, 'reference') if step == opt_steps[0] or a.mode != 'optimize' else None)
+                     for nm in names]
     else:
         for step in (opt_steps if a.mode == 'optimize' else [None]):
             out = os.path.join(a.output_dir, f'OPT-{step}') if (a.mode == 'optimize' and len(opt_steps) > 1) else a.output_dir
-            jobs += [('pdb' if path is not None else 'synthetic', path, out, step, False)
+            jobs += [('pdb' if path is not None else 'synthetic', path, out, step, False, None)
                      for path in (complex_list(a.pdb_file, a.pdb_list, a.pdb_dir) or [None])]
     os.makedirs(a.output_dir, exist_ok=True)
     files = []
     import time
     del TIMINGS[:]
-    for kind, path, out_dir, opt_step, ref_layout in jobs:
+
+    loaded = {}
+
+    def load_job(ji):
+        """The complex of job ji (host tensors, read once per complex): dict(cb, cname, L, Lab, kind)."""
+        kind, path = jobs[ji][0], jobs[ji][1]
+        key = (kind, path)
+        if key not in loaded:
+            if kind in ('pdb', 'npz'):
+                from .data.antibody import load_complex, load_complex_npz
+                cb = load_complex(path, seed=a.seed) if kind == 'pdb' else load_complex_npz(a.data_dir, path, seed=a.seed)
+                one = {k: v for k, v in cb.items() if torch.is_tensor(v)}
+                loaded[key] = dict(cb=cb, one=one, cname=cb['name'][0], L=one['seq'].shape[1], Lab=one['anchor_flag'].shape[1])
+            else:
+                w = synthetic.WORKLOADS[a.workload]
+                cx = synthetic.make_complex(seed=a.seed + 1, **w)
+                loaded[key] = dict(cb=None, one={k: v[None] for k, v in cx.items()}, cname=f'{a.workload}_H_L_A', L=cx['seq'].shape[0],
+                                   Lab=cx['anchor_flag'].shape[0], w=w, seq=cx['seq'].tolist())
+        return loaded[key]
+
+    # ---- who runs what.  One complex, or fewer (complex, 50-sample block) units than ranks: the samples of every complex are sharded
+    # over the ranks and gathered per complex.  A set of complexes (BASELINE configs 3 / 4): whole units are dealt to the ranks
+    # longest-first (cost ~ L^3 x samples), each GPU runs batches of >= 50 samples (0.98 of the 100-sample rate per GPU instead of the
+    # 0.91 of 12-13-sample shards, DESIGN.md section 5), and ONE gather of the designs table closes the set.  Per-sample noise keys make
+    # a sample's trajectory independent of where and with whom it runs, so both schemes write the same files.
+    plan = None
+    if (world > 1 or a.force_collective) and len(jobs) >= 2 and not a.shard_samples:
+        plan = sampler.plan_work_units([float(load_job(ji)['L']) ** 3 for ji in range(len(jobs))], N, world, min_block=a.min_block, force=a.force_collective)
+    if plan is None:
+        work = [(ji, sampler.shard_sample_ids(N, rank, world)) for ji in range(len(jobs))]
+    else:
+        work = plan[rank]
+        if a.verbose or rank == 0:
+            print(f'set-level schedule: {sum(len(p) for p in plan)} units of >= {min(a.min_block, N)} samples over {world} ranks; '
+                  f'rank {rank} runs {[(jobs[ji][1], len(ids_)) for ji, ids_ in work]}')
+    set_rows = []                                               # set-level mode: (job, sample id, mean pLDDT, Lab, tokens...) rows of this rank
+    maxLab = max([load_job(ji)['Lab'] for ji in range(len(jobs))]) if plan is not None else 0
+
+    ref_written = set()
+    for ji, ids in work:
+        kind, path, out_dir, opt_step, ref_layout, ref_dir = jobs[ji]
+        n = len(ids)
         t_job = time.perf_counter()
         os.makedirs(out_dir, exist_ok=True)
+        J = load_job(ji)
+        cname, L, Lab = J['cname'], J['L'], J['Lab']
+        one = {k: v.to(dev) for k, v in J['one'].items()}
         if kind in ('pdb', 'npz'):
-            from .data.antibody import load_complex, load_complex_npz
-            cb = load_complex(path, seed=a.seed) if kind == 'pdb' else load_complex_npz(a.data_dir, path, seed=a.seed)
-            one = {k: v.to(dev) for k, v in cb.items() if torch.is_tensor(v)}
-            cname = cb['name'][0]
+            cb = J['cb']
             meta = {k: list(cb[k]) * n for k in ('str_heavy_seq', 'str_light_seq', 'antigen_origin_str_seq',
                                                  'antigen_origin_atom14_gt_positions', 'antigen_origin_atom14_gt_exists',
                                                  'antigen_origin_chain_ids')}
-            if ref_layout and rank == 0:
-                # inference.py:346-361: the "reference batch" = the ground-truth antibody with pLDDT 100, written once per complex
+            # the "reference batch" = the ground-truth antibody with pLDDT 100, once per complex: by rank 0 when the samples of the
+            # complex are sharded, by the rank that runs the complex's first block under the set-level schedule
+            first_block = bool(ids) and ids[0] == 0
+            if ref_layout and ref_dir is not None and (rank == 0 if plan is None else first_block) and (cname, ref_dir) not in ref_written:
                 from .io import postprocess_trajectory
-                Lab0 = one['anchor_flag'].shape[1]
+                ref_written.add((cname, ref_dir))
                 ref_meta = {k: list(cb[k]) for k in meta}
                 ref_meta['name'] = [cname]
-                files += postprocess_trajectory(ref_meta, [{'seq': one['seq'][:, :Lab0], 'atom14_results': one['atom14_gt_positions'][:, :Lab0],
-                                                            'pLDDT': torch.full((1, Lab0), 100.0), 'time': 0.0}],
-                                                os.path.join(out_dir, 'reference'))
+                files += postprocess_trajectory(ref_meta, [{'seq': one['seq'][:, :Lab], 'atom14_results': one['atom14_gt_positions'][:, :Lab],
+                                                            'pLDDT': torch.full((1, Lab), 100.0), 'time': 0.0}], ref_dir)
         else:
-            w = synthetic.WORKLOADS[a.workload]
-            cx = synthetic.make_complex(seed=a.seed + 1, **w)
-            one = {k: v[None].to(dev) for k, v in cx.items()}
+            w = J['w']
             nh, nl = w['L_heavy'], w['L_light']
-            seq = cx['seq'].tolist()
-            cname = f'{a.workload}_H_L_A'
-            meta = dict(str_heavy_seq=[index_to_str_seq(seq[:nh])] * n, str_light_seq=[index_to_str_seq(seq[nh:nh + nl])] * n)
+            meta = dict(str_heavy_seq=[index_to_str_seq(J['seq'][:nh])] * n, str_light_seq=[index_to_str_seq(J['seq'][nh:nh + nl])] * n)
         if ref_layout:                                      # inference.py:363-367: <k:04d>/<name>.pdb
             meta['name'] = [cname] * n
             meta['subdir'] = [f'{i:04d}' for i in ids]
         else:
             meta['name'] = sample_names(cname, ids, N)
-        L, Lab = one['seq'].shape[1], one['anchor_flag'].shape[1]
         if n > 0:
             raw = {k: v.expand(n, *v.shape[1:]).contiguous() for k, v in one.items()}
             batch = features.build_features(raw, diffuser, generate_area=a.generate_area,
@@ -240,23 +303,42 @@ def main(argv=None):
             files += new_files
             t_done = time.perf_counter()
             TIMINGS.append(dict(complex=cname, L=int(L), samples=n, mode=a.mode, opt_step=opt_step, read_and_featurise_s=t_feat - t_job,
-                                sampling_s=t_samp - t_feat, writer_tail_s=t_done - t_samp, files=len(new_files)))
+                                sampling_s=t_samp - t_feat, writer_tail_s=t_done - t_samp, files=len(new_files),
+                                range_fallbacks=len(traj[-1].get('range_fallbacks', []))))
             local = {'seq': traj[-1]['seq'], 'pLDDT': traj[-1]['pLDDT']}
         else:                                                   # more ranks than samples: join the gather with zero-row blocks
             local = {'seq': torch.zeros(0, Lab, dtype=torch.int64, device=dev), 'pLDDT': torch.zeros(0, Lab, device=dev)}
+        if plan is not None:
+            row = torch.zeros(n, 4 + maxLab, dtype=torch.float64)
+            row[:, 0], row[:, 1], row[:, 3] = ji, torch.tensor(ids, dtype=torch.float64), Lab
+            row[:, 2] = local['pLDDT'].double().mean(1).cpu()
+            row[:, 4:4 + Lab] = local['seq'].double().cpu()
+            set_rows.append(row)
+            continue
         if a.debug_one_gpu and world > 1:                       # gloo moves host tensors
             local = {k: v.cpu() for k, v in local.items()}
-        res = sampler.gather_results(local, N, rank, world, group)
+        res = sampler.gather_results(local, N, rank, world, group, force=a.force_collective)
         if rank == 0:
-            tsv = os.path.join(out_dir, f'{cname}_designs.tsv')
-            with open(tsv, 'w') as f:
-                f.write('sample\tmean_pLDDT\tantibody_sequence\n')
-                for i in range(N):
-                    f.write(f'{i}\t{float(res["pLDDT"][i].float().mean()):.3f}\t{index_to_str_seq(res["seq"][i].tolist())}\n')
-            files.append(tsv)
-    if world > 1:
+            files.append(_write_designs(out_dir, cname, [(i, float(res['pLDDT'][i].float().mean()), res['seq'][i].tolist()) for i in range(N)]))
+    if plan is not None:
+        # ---- the one collective of the set: every rank's rows of the designs table (counts known from the common plan)
+        table = torch.cat(set_rows, 0) if set_rows else torch.zeros(0, 4 + maxLab, dtype=torch.float64)
+        if not (a.debug_one_gpu and world > 1):
+            table = table.to(dev)
+        counts = [sum(len(ids_) for _, ids_ in p) for p in plan]
+        full = sampler.gather_rows(table, counts, rank, world, group, force=a.force_collective).cpu()
+        if rank == 0:
+            for ji in range(len(jobs)):
+                rows = full[full[:, 0] == ji]
+                rows = rows[torch.argsort(rows[:, 1])]
+                assert rows.shape[0] == N, (jobs[ji][1], rows.shape)
+                files.append(_write_designs(jobs[ji][2], load_job(ji)['cname'],
+                                            [(int(r[1]), float(r[2]), r[4:4 + int(r[3])].long().tolist()) for r in rows]))
+    if world > 1 or a.force_collective:
         import torch.distributed as dist
         dist.barrier()
+        if a.force_collective and world == 1:
+            dist.destroy_process_group()
     print(f'rank {rank}/{world}: {len(files)} files in {a.output_dir}')
     return files
 

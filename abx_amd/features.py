@@ -182,22 +182,30 @@ def make_diffuser_features(batch, generate_area, diffuser, diff_conf=None, opt_s
         cdrs = sorted(set(anchor_flag[anchor_flag > 0].tolist()))
     else:
         cdrs = [rc.cdr_str_to_enum[generate_area]]
-    # Anchors of a CDR come in (opening, closing) pairs along a row.  Diffused: strictly between them minus the last residue before the
-    # closing anchor (features.py:166: positions opening + 1 ... closing - 2); the structure-loss window runs from one residue before
-    # the opening anchor through the closing one and never takes the last antibody position (features.py:167).
-    Lab_ = anchor_flag.shape[1]
+    # Anchor positions of a CDR are paired in ROW-MAJOR order over the whole batch (features.py:159-161 walk a flat nonzero() list two
+    # entries at a time): entries 2p, 2p + 1 are the (opening, closing) pair p, applied to the row of the OPENING anchor; an unpaired
+    # last entry is dropped, and an odd count in one row of a batch makes the pairing run across rows - kept, it is what the
+    # reference feeds its network.  Diffused: columns opening + 1 ... closing - 2 (the last residue before the closing anchor stays
+    # fixed, :166); structure-loss window: opening - 1 ... closing, its end clipped with the TOTAL length of the complex (:167), so
+    # the last antibody position is left out only when no antigen follows it.
+    Lab_, Ltot = anchor_flag.shape[1], batch['mask'].shape[1]
     diffused = torch.zeros_like(batch['mask'], dtype=torch.int32)
     ab_loss_mask = torch.zeros_like(anchor_flag, dtype=torch.int32)
     struc_loss_mask = batch['mask'].to(torch.int32).clone()
+    cols = torch.arange(Lab_, device=dev)[None, :]
     for c in cdrs:
-        hit = anchor_flag == c
-        odd = torch.cumsum(hit, dim=1) % 2 == 1                   # from an opening anchor up to (not including) its closing anchor
-        closing, between = hit & ~odd, odd & ~hit
-        before_closing = F.pad(closing[:, 1:], [0, 1])
-        diffused[:, :Lab_] |= (between & ~before_closing).int()
-        span = odd | closing
-        ab_loss_mask |= (span | F.pad(span[:, 1:], [0, 1])).int()
-    ab_loss_mask[:, Lab_ - 1] = 0
+        pos = torch.nonzero(anchor_flag == c)                       # (n, 2) row-major
+        npair = pos.shape[0] // 2
+        if npair == 0:
+            continue
+        opening, closing = pos[0:2 * npair:2], pos[1:2 * npair:2]
+        rows, lo, hi = opening[:, 0], opening[:, 1:2], closing[:, 1:2]
+        dsel = (cols >= lo + 1) & (cols < hi - 1)
+        lsel = (cols >= torch.clamp(lo - 1, min=0)) & (cols < torch.clamp(hi + 1, max=Ltot - 1))
+        diffused[:, :Lab_].index_put_((rows,), dsel.int(), accumulate=True)
+        ab_loss_mask.index_put_((rows,), lsel.int(), accumulate=True)
+    diffused.clamp_(max=1)
+    ab_loss_mask.clamp_(max=1)
     struc_loss_mask[:, :Lab] = ab_loss_mask
     fixed_mask = 1 - diffused
     if opt_step is None:

@@ -19,13 +19,14 @@ _THREE_TO_ONE = {v: k for k, v in rc.restype_1to3.items()}
 
 
 class Residue:
-    __slots__ = ('resname', 'resseq', 'icode', 'het', 'atoms', '_occ', '_alt')
+    __slots__ = ('resname', 'resseq', 'icode', 'het', 'atoms', '_occ', '_alt', '_last_name')
 
     def __init__(self, resname, resseq, icode, het):
         self.resname, self.resseq, self.icode, self.het = resname, resseq, icode, het
         self.atoms = OrderedDict()          # name -> xyz
         self._occ = {}                      # name -> occupancy of the selected alternate location
         self._alt = None                    # other residue NAMES at this position (point-mutation disorder): name -> Residue
+        self._last_name = resname           # residue name of the last atom line read for this position
 
 
 class PdbFormatError(ValueError):
@@ -66,14 +67,18 @@ def read_pdb(path):
                 chains.setdefault(chain_id, []).append(res)
             elif resname != res.resname:
                 # point-mutation microheterogeneity: two residue NAMES share (het, number, insertion code).  Biopython keeps both in a
-                # DisorderedResidue and selects the one whose atoms were added last ... of the highest occupancy; here the alternative
-                # is collected on the side and _resolve_disorder() keeps the name with the higher total occupancy
+                # DisorderedResidue and every atom line SELECTS the child of its residue name (StructureBuilder.init_residue ->
+                # disordered_add / disordered_select), so the name of the LAST atom line of the residue is the one its iterators
+                # return; the alternatives are collected on the side and the loop below keeps that one
                 if res._alt is None:
                     res._alt = OrderedDict()
                 alt = res._alt.get(resname)
                 if alt is None:
                     alt = res._alt[resname] = Residue(resname, resseq, icode, het)
+                index[key]._last_name = resname
                 res = alt
+            else:
+                res._last_name = resname
             if name in res.atoms:
                 # alternate location of a known atom: keep the higher occupancy; a plain duplicate keeps the first
                 if altloc != ' ' and occ > res._occ[name]:
@@ -85,7 +90,7 @@ def read_pdb(path):
     for cid, residues in chains.items():
         for i, r in enumerate(residues):
             if r._alt:
-                best = max([r] + list(r._alt.values()), key=lambda x: sum(x._occ.values()) / max(len(x._occ), 1))
+                best = r if r._last_name == r.resname else r._alt[r._last_name]
                 best._alt = None
                 residues[i] = best
     return chains

@@ -129,11 +129,12 @@ def shard_sample_ids(num_samples, rank, world_size):
     return list(range(start, start + n))
 
 
-def gather_results(local, num_samples, rank, world_size, group=None):
+def gather_results(local, num_samples, rank, world_size, group=None, force=False):
     """All-gather of per-sample results {name: tensor (n_local, ...)} into tensors (num_samples, ...) ordered by sample id.
-    One collective per field on padded equal-size blocks (RCCL all_gather over xGMI; gloo in the CPU tests)."""
+    One collective per field on padded equal-size blocks (RCCL all_gather over xGMI; gloo in the CPU tests).
+    force: run the collective on a single rank too (exercises the RCCL path on a 1-GPU box; same values)."""
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force:
         return local
     nmax = -(-num_samples // world_size)
     out = {}
@@ -148,6 +149,46 @@ def gather_results(local, num_samples, rank, world_size, group=None):
             rows.append(parts[r][:n])
         out[name] = torch.cat(rows, dim=0)
     return out
+
+
+def plan_work_units(costs, num_samples, world_size, min_block=50, force=False):
+    """Set-level scheduling (BASELINE configs 3 / 4: a list of complexes x num_samples on several GPUs; the reference walks the
+    complexes one after the other, inference.py:296-373).  Work units = (complex, block of >= min_block samples; all samples when
+    there are fewer than 2 * min_block), cost = costs[complex] * block size (costs ~ L^3), dealt to the ranks longest-first onto the
+    least loaded rank.  Every rank computes the same plan from the same inputs: no communication.  Returns a list per rank of
+    (complex index, [global sample ids]) in complex order, or None when there are fewer units than ranks (then sharding the samples
+    of each complex keeps every GPU busy)."""
+    units = []
+    for j, c in enumerate(costs):
+        nb = max(1, num_samples // min_block)
+        for r in range(nb):
+            ids = shard_sample_ids(num_samples, r, nb)
+            if ids:
+                units.append((float(c) * len(ids), j, ids))
+    if (world_size <= 1 and not force) or len(units) < world_size:      # (force: the plan of a single rank, to exercise the path)
+        return None
+    load = [0.0] * world_size
+    plan = [[] for _ in range(world_size)]
+    for cost, j, ids in sorted(units, key=lambda u: (-u[0], u[1], u[2][0])):
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        load[r] += cost
+        plan[r].append((j, ids))
+    return [sorted(p, key=lambda u: (u[0], u[1][0])) for p in plan]
+
+
+def gather_rows(table, rows_per_rank, rank, world_size, group=None, force=False):
+    """ONE all-gather of a per-rank table (n_rank, W) whose row counts every rank already knows (rows_per_rank, from the common
+    plan): blocks padded to the largest count, the padding dropped on arrival.  Returns the (sum rows, W) table in rank order."""
+    import torch.distributed as dist
+    assert table.shape[0] == rows_per_rank[rank], (table.shape, rows_per_rank, rank)
+    if world_size == 1 and not force:
+        return table
+    nmax = max(max(rows_per_rank), 1)
+    pad = torch.zeros((nmax,) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
+    pad[:table.shape[0]] = table
+    parts = [torch.empty_like(pad) for _ in range(world_size)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([parts[r][:rows_per_rank[r]] for r in range(world_size)], dim=0)
 
 
 def design_samples(complex_feats, config, diffuser, model, num_samples, rank=0, world_size=1, mode='design', num_t=100,

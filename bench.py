@@ -351,6 +351,9 @@ def main():
     ap.add_argument('--no-op-profile', action='store_true')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the additional weak-scaling measurement')
     ap.add_argument('--launcher-selftest', action='store_true', help='CPU/gloo check of the multi-rank launch path, no GPU work')
+    ap.add_argument('--force-collective', action='store_true', help='--gpus 1: still initialise the RCCL process group and run the barrier, the '
+                    'MAX all_reduce and the final gather through 1-rank collectives on device tensors (exercises the multi-GPU code '
+                    'path on a 1-GPU box; same results)')
     ap.add_argument('--debug-one-gpu', action='store_true', help='debugging on a 1-GPU box: every rank uses cuda:0 and the gloo backend '
                                                                  '(exercises the whole multi-rank code path; the numbers mean nothing)')
     args = ap.parse_args()
@@ -368,9 +371,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    coll = world > 1 or args.force_collective        # collectives run (a 1-rank group under --force-collective)
+    if coll:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29578')
         if args.debug_one_gpu:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -401,7 +407,7 @@ def main():
     D.seed = 2024
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -453,7 +459,7 @@ def main():
                 out = one_step(warmup + k)
             barrier()
             elapsed = time.perf_counter() - t0
-        if world > 1:
+        if coll:
             tt_ = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
             elapsed = float(tt_)
@@ -468,26 +474,33 @@ def main():
 
     # ---- the one collective of the path: final results of all samples to every rank (after the timed loop)
     gather_ms, rccl_ranks = None, 1
-    if world > 1:
-        Lab = cx['anchor_flag'].shape[0]
-        if st['B'] > 0:
-            o, b_ = st['out'], st['batch']
-            local = {'rigids': b_['rigids_t'].double(), 'seq': torch.clamp(b_['seq_t'][:, :Lab], 0, 19).long(),
-                     'atom14': o['heads']['folding']['final_atom14_positions'][:, :Lab].contiguous(),
-                     'pLDDT': o['heads']['predicted_lddt']['pLDDT'][:, :Lab].contiguous()}
-        else:
-            local = {'rigids': torch.zeros(0, L, 7, dtype=torch.float64, device=dev), 'seq': torch.zeros(0, Lab, dtype=torch.int64, device=dev),
-                     'atom14': torch.zeros(0, Lab, 14, 3, device=dev), 'pLDDT': torch.zeros(0, Lab, device=dev)}
-        sampler.gather_results(local, total, rank, world)        # first call: communicator set-up
+    Lab = cx['anchor_flag'].shape[0]
+    if st['B'] > 0:
+        o, b_ = st['out'], st['batch']
+        local = {'rigids': b_['rigids_t'].double(), 'seq': torch.clamp(b_['seq_t'][:, :Lab], 0, 19).long(),
+                 'atom14': o['heads']['folding']['final_atom14_positions'][:, :Lab].contiguous(),
+                 'pLDDT': o['heads']['predicted_lddt']['pLDDT'][:, :Lab].contiguous()}
+    else:
+        local = {'rigids': torch.zeros(0, L, 7, dtype=torch.float64, device=dev), 'seq': torch.zeros(0, Lab, dtype=torch.int64, device=dev),
+                 'atom14': torch.zeros(0, Lab, 14, 3, device=dev), 'pLDDT': torch.zeros(0, Lab, device=dev)}
+    got = local
+    if coll:
+        sampler.gather_results(local, total, rank, world, force=args.force_collective)        # first call: communicator set-up
         barrier()
         g0 = time.perf_counter()
-        got = sampler.gather_results(local, total, rank, world)
+        got = sampler.gather_results(local, total, rank, world, force=args.force_collective)
         barrier()
         gather_ms = 1000.0 * (time.perf_counter() - g0)
         assert got['rigids'].shape[0] == total
         cnt = torch.ones(1, device=dev)
         dist.all_reduce(cnt)
         rccl_ranks = int(cnt)
+    # sha256 over the final state of all samples in sample order (what the gather returns): neither the placement of the samples nor
+    # the collective may change a bit of it
+    import hashlib
+    hd = hashlib.sha256()
+    for kk in ('rigids', 'seq', 'atom14', 'pLDDT'):
+        hd.update(got[kk].contiguous().cpu().numpy().tobytes())
 
     B0 = st['B']
     result = {
@@ -501,7 +514,7 @@ def main():
                                f'{total} samples of one complex over {world} GPU(s), 1 step = ScoreNetwork (3 passes) + get_prev '
                                '+ reverse, seeded random weights, ESM off', 'L': L, 'samples_total': total,
                    'samples_per_rank': per_rank, 'chunk': args.chunk or 'auto', 'parallelism': f'sample-shard x{world}, no collective in the step'},
-        'finite': st['finite'], 'rccl_ranks': rccl_ranks, 'gather_ms': gather_ms,
+        'finite': st['finite'], 'rccl_ranks': rccl_ranks, 'gather_ms': gather_ms, 'result_digest': hd.hexdigest(),
         # a T = 100 trajectory is 100 steps + the self-conditioning warm-up call; this is the rate with that call inside the wall
         'selfcond_warmup_call_ms': st.get('selfcond_call_ms'),
         'value_T100_trajectory_incl_warmup_call': (total * 100.0 / ((100.0 * elapsed / args.steps) + st['selfcond_call_ms'] / 1e3)
@@ -560,7 +573,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if coll:
         dist.barrier()
         dist.destroy_process_group()
 

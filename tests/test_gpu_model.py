@@ -840,7 +840,10 @@ def test_inference_style_driver_on_npz_entries(tmp_path):
     files = design.main(common[:2] + ['--data_dir', os.path.join(GOLDEN, 'npz'), '--model_features', str(feats), '--num_samples', '1', '--mode', 'optimize',
                                       '--output_dir', out2])
     rel = sorted(os.path.relpath(f, out2) for f in files if f.endswith('.pdb'))
-    assert rel == sorted([f'optimize/OPT-{st}/{d}/{n}.pdb' for st in (3, 5) for d in ('reference', '0000') for n in ('6ct7_H_L_S', '6qd7_X_Z_F|E')])
+    # inference.py:321-322: the ground truth goes to <output_dir>/optimize/reference/ (ref_dir is built from output_dir, not from the
+    # OPT-<step> directory), the samples of a step to optimize/OPT-<step>/<k:04d>/
+    names2 = ('6ct7_H_L_S', '6qd7_X_Z_F|E')
+    assert rel == sorted([f'optimize/reference/{n}.pdb' for n in names2] + [f'optimize/OPT-{st}/0000/{n}.pdb' for st in (3, 5) for n in names2])
 
 
 def test_guidance_off_is_bit_identical_and_on_follows_the_formula(gpu_model, cfg):
@@ -1090,12 +1093,14 @@ def test_reference_call_pattern_through_the_alias_packages(params, cfg, gpu_mode
 
 
 def test_design_driver_two_ranks_shard_the_samples(tmp_path):
-    """BASELINE config 3 shape (a list of complexes, samples sharded over ranks, final gather): `abx_amd.design` under
-    torch.distributed.run with 2 ranks on the two shipped complexes, 3 samples each: rank 0 takes samples 0-1, rank 1 sample 2,
-    every rank writes its own PDB files, rank 0 the gathered designs table.  Both ranks share cuda:0 here (gloo, --debug_one_gpu),
+    """BASELINE config 3 shape (a list of complexes on several ranks): `abx_amd.design` under torch.distributed.run with 2 ranks on the
+    two shipped complexes, 3 samples each, in both multi-rank schemes: --shard_samples (every complex's samples sharded: rank 0 takes
+    samples 0-1, rank 1 sample 2; one gather per complex) and the default SET-LEVEL schedule (--min_block 3: whole (complex, block)
+    units dealt longest-first, 6qd7 to rank 0 and 6ct7 to rank 1; one gather of the designs table at the end of the set).  Every rank
+    writes its own PDB files, rank 0 the designs tables.  Both ranks share cuda:0 here (gloo, --debug_one_gpu),
     which is plumbing only: two PROCESSES time-slicing one MI355X did not reproduce a solo run's last digits in 3 of 10 trials
     (any kernel, also the fp64 geometry ones; never with one process per GPU), so the files are compared
-    for structure, and bit-for-bit shard invariance is asserted in-process by test_device_rng_sampling_is_shard_invariant."""
+    for structure, and bit-for-bit placement invariance is asserted in-process by test_device_rng_sampling_is_shard_invariant."""
     import subprocess
     import sys
     from abx_amd import design
@@ -1109,25 +1114,63 @@ def test_design_driver_two_ranks_shard_the_samples(tmp_path):
     common = ['--pdb_list', str(lst), '--pdb_dir', pdbs, '--num_samples', '3', '--num_t', '3', '--mode', 'design']
     one = str(tmp_path / 'one')
     design.main(common + ['--output_dir', one])
-    two = str(tmp_path / 'two')
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29541', '-m', 'abx_amd.design', '--debug_one_gpu'] + common + ['--output_dir', two]
-    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    fa, fb = sorted(os.listdir(one)), sorted(os.listdir(two))
-    assert fa == fb and len([f for f in fa if f.endswith('.pdb')]) == 3 * len(names), (fa, fb)
-    for f in fa:
-        if f.endswith('.tsv'):
-            ra, rb = ([ln.split('\t') for ln in open(os.path.join(d, f)).read().splitlines()] for d in (one, two))
-            assert [x[0] for x in ra] == [x[0] for x in rb] == ['sample', '0', '1', '2']
-            assert [len(x[2]) for x in ra] == [len(x[2]) for x in rb]
-        else:
-            ca, cb2 = read_pdb(os.path.join(one, f)), read_pdb(os.path.join(two, f))
-            assert list(ca) == list(cb2), f
-            for c in ca:
-                fa_, fb_ = chain_feature(ca[c]), chain_feature(cb2[c])
-                assert len(fa_['str_seq']) == len(fb_['str_seq']) and np.isfinite(fb_['coords']).all(), (f, c)
+    for tag, extra in (('shard', ['--shard_samples']), ('set', ['--min_block', '3'])):
+        two = str(tmp_path / tag)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', '29541', '-m', 'abx_amd.design', '--debug_one_gpu'] + common + extra + ['--output_dir', two]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert ('set-level schedule: 2 units' in r.stdout) == (tag == 'set'), r.stdout[-2000:]
+        fa, fb = sorted(os.listdir(one)), sorted(os.listdir(two))
+        assert fa == fb and len([f for f in fa if f.endswith('.pdb')]) == 3 * len(names), (tag, fa, fb)
+        for f in fa:
+            if f.endswith('.tsv'):
+                ra, rb = ([ln.split('\t') for ln in open(os.path.join(d, f)).read().splitlines()] for d in (one, two))
+                assert [x[0] for x in ra] == [x[0] for x in rb] == ['sample', '0', '1', '2'], tag
+                assert [len(x[2]) for x in ra] == [len(x[2]) for x in rb], tag
+            else:
+                ca, cb_ = (read_pdb(os.path.join(d, f)) for d in (one, two))
+                assert sorted(ca) == sorted(cb_), (tag, f)
+                for ch in ca:
+                    assert len(chain_feature(ca[ch])['str_seq']) == len(chain_feature(cb_[ch])['str_seq']), (tag, f, ch)
+
+
+def test_rccl_collective_path_on_one_gpu(tmp_path):
+    """The one collective of the path on real hardware before the 8-GPU run (the reference only initialises NCCL,
+    inference.py:59-82): a 1-rank RCCL process group (`init_process_group('nccl', device_id=...)`), the padded all_gather of DEVICE
+    tensors in sampler.gather_results / gather_rows, the barrier and the MAX all_reduce of bench.py, through torch.distributed.run.
+    bench.py --force-collective reports rccl_ranks == 1 and the same result digest as the plain single-process run; the design driver
+    under the launcher with --force_collective writes the same files as without (set-level schedule on the two shipped complexes)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    launch = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29543']
+    args = ['--gpus', '1', '--steps', '1', '--warmup', '0', '--samples', '4', '--workload', 'L256', '--no-cpu-baseline', '--no-op-profile']
+    out = {}
+    for tag, cmd in (('plain', [sys.executable, 'bench.py'] + args), ('rccl', launch + ['bench.py'] + args + ['--force-collective'])):
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-4000:]
+        out[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['rccl']['rccl_ranks'] == 1 and out['rccl']['gather_ms'] is not None and out['plain']['gather_ms'] is None
+    assert out['rccl']['result_digest'] == out['plain']['result_digest'] and len(out['plain']['result_digest']) == 64
+    # the design driver: --gpu_list 0 through the launcher, RCCL initialised, set-level gather through a 1-rank all_gather
+    from conftest import GOLDEN
+    idx = tmp_path / 'test.idx'
+    idx.write_text('6ct7_H_L_S\n6qd7_X_Z_F|E\n')
+    common = ['--name_idx', str(idx), '--data_dir', os.path.join(GOLDEN, 'npz'), '--gpu_list', '0', '--num_samples', '2', '--num_t', '3', '--mode', 'design',
+              '--min_block', '1']
+    trees = {}
+    for tag, cmd in (('plain', [sys.executable, '-m', 'abx_amd.design'] + common), ('rccl', launch + ['-m', 'abx_amd.design'] + common + ['--force_collective'])):
+        od = str(tmp_path / tag)
+        r = subprocess.run(cmd + ['--output_dir', od], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-4000:]
+        trees[tag] = {os.path.relpath(os.path.join(dp, f), od): open(os.path.join(dp, f), 'rb').read() for dp, _, fs in os.walk(od) for f in fs}
+    assert 'set-level schedule' in r.stdout
+    assert sorted(trees['plain']) == sorted(trees['rccl']) and len(trees['plain']) == 2 * 3 + 2
+    assert trees['plain'] == trees['rccl'], [k for k in trees['plain'] if trees['plain'][k] != trees['rccl'][k]]
 
 
 def test_results_do_not_depend_on_stale_lds(gpu_model, cfg):

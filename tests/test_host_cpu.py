@@ -151,6 +151,66 @@ def test_gather_results_gloo_world2():
         assert out.stdout.count('OK') == 2
 
 
+def test_set_level_schedule_plan():
+    """sampler.plan_work_units (BASELINE configs 3 / 4: complexes x 100 samples on 8 GPUs; the reference walks the complexes one after
+    the other, inference.py:296-373): units of >= 50 samples, dealt longest-first, every sample of every complex exactly once, ranks
+    balanced to within the largest unit, the same plan on every rank; fewer units than ranks -> None (shard the samples instead)."""
+    from abx_amd.sampler import plan_work_units
+    Ls = [231, 259, 352, 198, 240, 305, 222, 270, 331, 210, 254, 287, 233, 246, 262, 219, 301, 275, 228]      # 19 complexes (config 3)
+    costs = [float(L) ** 3 for L in Ls]
+    plan = plan_work_units(costs, 100, 8)
+    assert plan is not None and len(plan) == 8 and plan == plan_work_units(list(costs), 100, 8)
+    seen = {}
+    for p_ in plan:
+        assert p_ == sorted(p_, key=lambda u: (u[0], u[1][0]))
+        for j, ids in p_:
+            assert len(ids) == 50
+            seen.setdefault(j, []).extend(ids)
+    assert sorted(seen) == list(range(19)) and all(sorted(v) == list(range(100)) for v in seen.values())
+    load = [sum(costs[j] * len(ids) for j, ids in p_) for p_ in plan]
+    assert max(load) - min(load) <= max(costs) * 50
+    assert max(load) <= 1.12 * sum(load) / 8                       # within 12 % of the ideal split for this set
+    # fewer samples than two blocks: whole complexes; fewer units than ranks: no plan
+    plan = plan_work_units(costs[:4], 60, 2)
+    assert sorted(len(ids) for p_ in plan for _, ids in p_) == [60] * 4
+    assert plan_work_units(costs[:2], 100, 8) is None and plan_work_units(costs, 100, 1) is None
+
+
+_ROWS_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from abx_amd.sampler import plan_work_units, gather_rows
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+costs, N = [3.0, 1.0, 2.0], 4
+plan = plan_work_units(costs, N, world, min_block=2)
+mine = plan[rank]
+table = torch.tensor([[j, i, 10.0 * j + i] for j, ids in mine for i in ids], dtype=torch.float64).reshape(-1, 3)
+counts = [sum(len(ids) for _, ids in p) for p in plan]
+full = gather_rows(table, counts, rank, world)
+assert full.shape == (len(costs) * N, 3), full.shape
+assert sorted((int(r[0]), int(r[1])) for r in full) == [(j, i) for j in range(3) for i in range(N)]
+assert all(float(r[2]) == 10.0 * int(r[0]) + int(r[1]) for r in full)
+one = gather_rows(table, counts[rank:rank + 1] if world == 1 else counts, rank, world)
+dist.barrier()
+dist.destroy_process_group()
+print('OK', rank, counts)
+'''
+
+
+def test_gather_rows_gloo_world2():
+    """The one collective of the set-level schedule (sampler.gather_rows): ranks hold different numbers of rows, known to all from the
+    common plan; one padded all_gather returns every row exactly once (gloo here, RCCL on the GPUs)."""
+    with tempfile.TemporaryDirectory() as d:
+        w = os.path.join(d, 'w.py')
+        open(w, 'w').write(_ROWS_WORKER)
+        out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                              '--master-addr', '127.0.0.1', '--master-port', '29545', w, ROOT],
+                             env=dict(os.environ), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count('OK') == 2
+
+
 def test_glu_weight_packing_and_kernel_name_mirror():
     """Host-side helpers of the split-f16 path (no GPU): the (value, gate) column interleave of a glu GEMM and the
     kernel-selection mirror that bench.py uses to label launches."""

@@ -473,3 +473,32 @@ def test_peptide_violation_terms_match_reference_cal_vio():
     args = (tt(z['6qd7.s0.pos']), tt(p['batch.atom14_gt_exists']), tt(p['batch.seq']), tt(p['batch.chain_id']))
     assert int(O.peptide_violation_terms(*args)['c_n_violation_mask'].sum()) == 1
     assert int(O.peptide_violation_terms(*args, residx=tt(p['batch.residx']))['c_n_violation_mask'].sum()) == 0
+
+
+def test_diffusion_masks_match_reference_on_edge_layouts():
+    """abx_amd.features.make_diffuser_features against the reference's own masks (tests/golden/make_golden_masks.py ran the unmodified
+    abx/model/features.py:130-212) on anchor layouts the shipped complexes do not reach: closing anchor on the last antibody residue
+    with / without an antigen (loss window clipped with the total length), an odd anchor count in a single row and in a batch of three
+    (flat row-major pairing), generate_area = 'cdr'."""
+    import numpy as np
+    from conftest import load_npz
+    from abx_amd import features
+    g = load_npz('masks_cases.npz')
+    names = sorted({k.split('.')[0] for k in g})
+    assert len(names) == 5
+
+    class NoDiffuser:                       # the masks do not depend on the noising: record what it is asked to diffuse
+        def sample_ref(self, n_samples, impute_rigids, impute_seq, diffuse_mask, noise=None):
+            return {'rigids_t': impute_rigids, 'seq_t': impute_seq}
+
+    for nm in names:
+        af = torch.as_tensor(g[nm + '.anchor_flag'])
+        B, Lab = af.shape
+        Ltot = int(g[nm + '.Ltot'])
+        rots = torch.eye(3)[None, None, None].expand(B, Ltot, 8, 3, 3).contiguous()
+        batch = dict(seq=torch.zeros(B, Ltot, dtype=torch.int64), mask=torch.ones(B, Ltot, dtype=torch.bool), anchor_flag=af,
+                     rigidgroups_gt_frames=(rots, torch.zeros(B, Ltot, 8, 3)))
+        out = features.make_diffuser_features(batch, str(g[nm + '.area']), NoDiffuser())
+        assert np.array_equal(out['fixed_mask'].numpy(), g[nm + '.fixed_mask']), nm
+        assert np.array_equal(out['struc_loss_mask'].numpy(), g[nm + '.struc_loss_mask']), nm
+

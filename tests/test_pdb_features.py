@@ -156,8 +156,9 @@ def test_model_features_json():
 
 
 def test_pdb_reader_error_context_and_resname_disorder(tmp_path):
-    """malformed records name the file and line; two residue names at one position (point-mutation disorder) keep the
-    one with the higher occupancy instead of merging their atoms."""
+    """malformed records name the file and line; two residue names at one position (point-mutation disorder) are
+    not merged: like Biopython's DisorderedResidue (every atom line selects the child of its residue name) the name of the LAST atom
+    line of the position is the one that is kept, whatever the occupancies."""
     from abx_amd.io.pdb_reader import read_pdb, chain_feature, PdbFormatError
     fmt = lambda i, name, resn, alt, x, occ: f"ATOM  {i:5d}  {name:<3s}{alt}{resn} A   5    {x:8.3f}{0.0:8.3f}{0.0:8.3f}{occ:6.2f}{10.0:6.2f}           {name[0]:>2s}  \n"
     p = tmp_path / 'dis.pdb'
@@ -166,6 +167,15 @@ def test_pdb_reader_error_context_and_resname_disorder(tmp_path):
     ch = read_pdb(str(p))
     f = chain_feature(ch['A'])
     assert f['str_seq'] == 'A' and abs(float(f['coords'][0, 1, 0]) - 2.1) < 1e-6 and int(f['coord_mask'].sum()) == 3
+    # the last name read wins also when it has the LOWER occupancy, and when the two names alternate line by line
+    p2 = tmp_path / 'dis2.pdb'
+    p2.write_text(fmt(1, 'N', 'ALA', 'A', 1.1, 0.7) + fmt(2, 'CA', 'ALA', 'A', 2.1, 0.7) + fmt(3, 'CB', 'ALA', 'A', 3.1, 0.7) +
+                  fmt(4, 'N', 'SER', 'B', 1.0, 0.3) + fmt(5, 'CA', 'SER', 'B', 2.0, 0.3) + fmt(6, 'OG', 'SER', 'B', 3.0, 0.3))
+    f2 = chain_feature(read_pdb(str(p2))['A'])
+    assert f2['str_seq'] == 'S' and abs(float(f2['coords'][0, 1, 0]) - 2.0) < 1e-6 and int(f2['coord_mask'].sum()) == 3
+    p3 = tmp_path / 'dis3.pdb'
+    p3.write_text(fmt(1, 'N', 'SER', 'A', 1.0, 0.5) + fmt(2, 'N', 'ALA', 'B', 1.1, 0.5) + fmt(3, 'CA', 'SER', 'A', 2.0, 0.5) + fmt(4, 'CA', 'ALA', 'B', 2.1, 0.5))
+    assert chain_feature(read_pdb(str(p3))['A'])['str_seq'] == 'A'
     bad = tmp_path / 'bad.pdb'
     bad.write_text(fmt(1, 'N', 'SER', ' ', 1.0, 1.0) + 'ATOM      2  CA  SER A   x       1.000\n')
     with pytest.raises(PdbFormatError, match=r'bad\.pdb:2'):
