@@ -425,8 +425,45 @@ int launch_main_variant(const AbxGemm& g, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
+// The mode table of include/abx_hip.h ("MODES"): which fused forms of the descriptor may be combined.
+extern "C" int abx_gemm_check_modes(const AbxGemm* gp) {
     ABX_REQUIRE(gp != nullptr, "abx_gemm: null descriptor");
+    const AbxGemm& g = *gp;
+    enum { GLU, MLP, DUAL, C_SPLIT, OUT_LN, A_SPLIT, PAIR, EXACT, NMODE };
+    static const char* const names[NMODE] = {"glu", "mlp", "dual (A2 / B2_split)", "c_split", "out_ln", "a_split", "pair-row maps", "exact = 1"};
+    const bool on[NMODE] = {g.glu != 0, g.mlp != 0, g.A2 != nullptr, g.C_split != nullptr, g.out_ln_w != nullptr, g.A_split != nullptr,
+                            g.pair_Lp > 0 || g.a_pair != 0 || g.c_pair != 0 || g.a_pair_transpose > 0, g.exact == 1};
+    // 1: the pair may be combined
+    static const unsigned char ok[NMODE][NMODE] = {
+        /* glu     */ {1, 0, 0, 1, 0, 0, 1, 0},
+        /* mlp     */ {0, 1, 0, 0, 0, 0, 0, 0},
+        /* dual    */ {0, 0, 1, 0, 0, 0, 1, 0},
+        /* c_split */ {1, 0, 0, 1, 0, 0, 1, 0},
+        /* out_ln  */ {0, 0, 0, 0, 1, 0, 0, 0},
+        /* a_split */ {0, 0, 0, 0, 0, 1, 0, 0},
+        /* pair    */ {1, 0, 1, 1, 0, 0, 1, 0},
+        /* exact   */ {0, 0, 0, 0, 0, 0, 0, 1},
+    };
+    static thread_local char msg[160];
+    for (int i = 0; i < NMODE; ++i)
+        for (int j = i + 1; j < NMODE; ++j)
+            if (on[i] && on[j] && !ok[i][j]) {
+                snprintf(msg, sizeof(msg), "abx_gemm: modes '%s' and '%s' are mutually exclusive (include/abx_hip.h, MODES)", names[i], names[j]);
+                abx_set_error(msg);
+                return ABX_ERR_ARG;
+            }
+    ABX_REQUIRE(!on[GLU] || (g.c_transposed && g.N % 128 == 0 && !g.gate), "abx_gemm: glu needs a transposed store, N % 128 == 0, no gate");
+    ABX_REQUIRE(!on[C_SPLIT] || g.c_transposed, "abx_gemm: c_split needs the transposed store (c_transposed)");
+    ABX_REQUIRE(!on[MLP] || (g.B2_split && g.act == 1 && g.ln_csum && !g.ln_stats && g.N2 > 0 && g.N2 <= 192 && !g.gate && !g.rowscale && !g.c_transposed),
+                "abx_gemm: mlp needs B2_split, act = 1, a folded LayerNorm (ln_csum, no ln_stats), 0 < N2 <= 192, no gate / rowscale / transposed store");
+    ABX_REQUIRE(!on[DUAL] || (g.B2_split && g.ln2_csum && !g.c_transposed), "abx_gemm: dual needs B2_split, ln2_csum and a plain store");
+    ABX_REQUIRE(!on[OUT_LN] || (g.out_ln_b && g.N <= 128 && !g.c_transposed), "abx_gemm: out_ln needs out_ln_b, N <= 128 and a plain store");
+    ABX_REQUIRE(!on[A_SPLIT] || (!g.ln_csum && !g.a_relu), "abx_gemm: a_split (plane x plane contraction) takes no LayerNorm and no relu-on-load");
+    return ABX_OK;
+}
+
+extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
+    if (int rc = abx_gemm_check_modes(gp)) return rc;
     AbxGemm g = *gp;
     ABX_REQUIRE((g.A || g.A_split) && (g.B || g.B_split) && (g.C || g.C_split), "abx_gemm: null operand");
     ABX_REQUIRE(!g.glu || (g.c_transposed && g.N % 128 == 0 && !g.gate), "abx_gemm: glu needs a transposed store, N % 128 == 0, no gate");

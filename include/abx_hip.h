@@ -43,6 +43,30 @@ int abx_debug_poison_lds(unsigned pattern, hipStream_t stream);
  *   LayerNorm over k is applied algebraically in the epilogue: pass B scaled by gamma (B[k][n] = gamma[k] W[n][k]),
  *   ln_csum[n] = sum_k B[k][n], bias[n] = sum_k beta[k] W[n][k] + b[n] and the row statistics:  ln(v) = rstd[m] (v - mean[m] csum[n])
  *   epi(v) = ((ln(v) + bias[n]) * alpha) -> act -> * rowscale[b][m] -> * (sigmoid?)(gate[b][m][n]) -> + resid[b][m][n]
+ *
+ * MODES.  Beside the plain GEMM the descriptor selects one of the fused forms below; abx_gemm_check_modes (called by abx_gemm first,
+ * callable on its own without a GPU) rejects every pair marked x with a negative code and a message that names both modes.
+ *   glu       glu = 1: (value, gate) column pairs -> value * sigmoid(gate)             (tri-mul projections, seqformer.py:480-485)
+ *   mlp       mlp = 1 + B2_split: relu(LN(A) B + b) B2 + b2 (+ resid), hidden on-chip   (pair Transition, seqformer.py:358-376)
+ *   dual      A2 + B2_split: epi(A B) * sigmoid(LN(A2) B2 + b2) (+ resid)               (tri-mul tail, seqformer.py:496-503)
+ *   c_split   C_split: output as the f16 operand image of the following contraction     (tri-mul projections)
+ *   out_ln    out_ln_w: LayerNorm over the OUTPUT row                                    (IpaScore pair init, score_network.py:117-120)
+ *   a_split   A_split (+ B_split of activations): plane x plane contraction             ('bikc,bjkc->bijc', seqformer.py:490-493)
+ *   pair      pair_Lp > 0 / a_pair / c_pair / a_pair_transpose: padded or transposed pair-row maps
+ *   exact     exact = 1: the exact fp32-MFMA kernels (plain epilogue only)
+ *
+ *              glu   mlp   dual  c_split out_ln a_split pair  exact
+ *   glu         .     x     x     ok      x      x      ok    x
+ *   mlp         x     .     x     x       x      x      x     x
+ *   dual        x     x     .     x       x      x      ok    x
+ *   c_split     ok    x     x     .       x      x      ok    x
+ *   out_ln      x     x     x     x       .      x      x     x
+ *   a_split     x     x     x     x       x      .      x     x
+ *   pair        ok    x     ok    ok      x      x      .     x
+ *   exact       x     x     x     x       x      x      x     .
+ * Further requirements of a single mode (also checked, same function): glu and c_split need c_transposed; glu: N % 128 == 0, no gate;
+ * mlp: act = 1, folded LayerNorm (ln_csum, no ln_stats), N2 <= 192, no gate / rowscale / c_transposed; dual: ln2_csum, no c_transposed;
+ * out_ln: N <= 128, out_ln_b, no c_transposed; a_split: no LayerNorm, no a_relu (there is no fp32 row to normalise).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct AbxGemm {
     const float* A; long long sAb, sAm, sAk;       /* one of sAm / sAk must be 1 */
@@ -148,6 +172,8 @@ typedef struct AbxGemm {
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
+/* the mode table above, without a launch: 0 or a negative code (abx_last_error_string names the offending pair / requirement) */
+int abx_gemm_check_modes(const AbxGemm* desc);
 /* fp32 weights W[n][k] -> out[Kp/16][2][N][16] float16 planes (p0, p1) of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
  * scale_exp = 14 - e with max|w| = m * 2^e, 0.5 <= m < 1 (so that max|w| * 2^scale_exp is in [2^13, 2^14)) */
 int abx_split_weights_f16(const float* w, long long s_n, long long s_k, int N, int K, int scale_exp, unsigned short* out, hipStream_t stream);
