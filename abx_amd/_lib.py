@@ -92,6 +92,22 @@ class AbxTriAttn(C.Structure):
     ]
 
 
+class AbxLinearPack(C.Structure):
+    _fields_ = [('Wt', c_f), ('csum', c_f), ('bias', c_f), ('planes', C.c_void_p), ('b_exp', I), ('K', I), ('N', I)]
+
+
+class AbxLinearSrc(C.Structure):
+    _fields_ = [('W', c_f), ('b', c_f), ('rows', I), ('glu', I)]
+
+
+class AbxTriMulPack(C.Structure):
+    _fields_ = [('glu', AbxLinearPack), ('out', AbxLinearPack), ('gate', AbxLinearPack)]
+
+
+class AbxTriAttnPack(C.Structure):
+    _fields_ = [('qkvg', AbxLinearPack), ('pair', AbxLinearPack), ('out', AbxLinearPack)]
+
+
 class AbxScoreArgs(C.Structure):
     _fields_ = [
         ('init_q', c_f), ('init_t', c_f), ('delta_q', c_f), ('cur_t', c_f), ('fixed_mask', c_f),
@@ -177,6 +193,15 @@ _PROTOS = {
     'abx_reverse_step': (I, [C.POINTER(AbxReverseArgs), _S]),
     'abx_clash_grad_workspace_bytes': (LL, [I, I]),
     'abx_clash_grad': (I, [C.POINTER(AbxGuidanceArgs), c_f, _S]),
+    'abx_pack_linear_bytes': (LL, [I, I]),
+    'abx_pack_linear': (I, [C.POINTER(AbxLinearSrc), I, I, c_f, c_f, I, c_f, C.POINTER(AbxLinearPack), _S]),
+    'abx_transition_workspace_bytes': (LL, [LL, I, I]),
+    'abx_transition_fwd': (I, [C.POINTER(AbxLinearPack), C.POINTER(AbxLinearPack), c_f, LL, I, c_f, c_f, I, _S]),
+    'abx_tri_mul_workspace_bytes': (LL, [I, I]),
+    'abx_tri_mul_workspace_init': (I, [c_f, I, I, _S]),
+    'abx_tri_mul_fwd': (I, [C.POINTER(AbxTriMulPack), c_f, c_f, c_f, I, I, I, c_f, c_f, I, _S]),
+    'abx_tri_attn_block_workspace_bytes': (LL, [I, I]),
+    'abx_tri_attn_block_fwd': (I, [C.POINTER(AbxTriAttnPack), c_f, c_f, I, I, I, I, c_f, c_f, I, _S]),
 }
 
 EXPORTED = tuple(_PROTOS)

@@ -39,8 +39,8 @@ def get_prev(batch, value, config):
     }
 
 
-# per-sample workspace of a pair-stack pass: w768 + w384 + bias/mask buffers + tri-mul plane operands ~ 6.6 KB per pair position
-_WORKSPACE_BYTES_PER_PAIR = 6600
+# per-sample workspace of a pair-stack pass: w768 + w384 + bias/mask buffers + tri-mul plane operands ~ 8.2 KB per pair position
+_WORKSPACE_BYTES_PER_PAIR = 8200      # (+ the op-group workspaces of csrc/blocks.hip: attention output, bias copies, tri-mul product)
 _MAX_CHUNK = 8192
 
 

@@ -111,6 +111,58 @@ class Packed:
             self._split_cache[ck] = ops.split_weights(ops.permute_k16(self.wt[key]))
         return self._split_cache[ck], self.b.get(key)
 
+    def block_packs(self):
+        """Weights of the three pair-stack op groups packed by abx_pack_linear (csrc/blocks.hip) for the op-group entry points of the
+        C ABI: {'pair_transition': (l1, l2), '<tri-mul name>': AbxTriMulPack, '<tri-attn name>': AbxTriAttnPack}; built once."""
+        if getattr(self, '_blocks', None) is None:
+            g = self.sd
+            W = lambda n: g[n + '.weight']
+            Bv = lambda n: g.get(n + '.bias')
+            ln = lambda n: (g[n + '.weight'], g[n + '.bias'])
+            blk = {}
+            pre = P_BLK + 'pair_transition.transition.'
+            blk['pair_transition'] = (ops.LinearPack([(W(pre + '1'), Bv(pre + '1'), 0)], 192, ln=ln(pre + '0')),
+                                      ops.LinearPack([(W(pre + '3'), Bv(pre + '3'), 0)], W(pre + '3').shape[1], permute_k16=True))
+            for tm in ('triangle_multiplication_outgoing', 'triangle_multiplication_incoming'):
+                pre = P_BLK + tm + '.'
+                glu = ops.LinearPack([(W(pre + 'left_proj'), Bv(pre + 'left_proj'), 1), (W(pre + 'right_proj'), Bv(pre + 'right_proj'), 1),
+                                      (W(pre + 'left_gate'), Bv(pre + 'left_gate'), 2), (W(pre + 'right_gate'), Bv(pre + 'right_gate'), 2)],
+                                     192, ln=ln(pre + 'norm'))
+                out = ops.LinearPack([(W(pre + 'proj_out'), Bv(pre + 'proj_out'), 0)], 128, ln=ln(pre + 'final_norm'))
+                gate = ops.LinearPack([(W(pre + 'final_gate'), Bv(pre + 'final_gate'), 0)], 192, ln=ln(pre + 'norm'))
+                blk[tm] = ops.tri_mul_pack(glu, out, gate)
+            for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
+                pre = P_BLK + ta + '.'
+                qkvg = ops.LinearPack([(W(pre + 'attn.proj_q'), Bv(pre + 'attn.proj_q'), 0), (W(pre + 'attn.proj_k'), Bv(pre + 'attn.proj_k'), 0),
+                                       (W(pre + 'attn.proj_v'), Bv(pre + 'attn.proj_v'), 0), (W(pre + 'attn.gate'), Bv(pre + 'attn.gate'), 0)],
+                                      192, ln=ln(pre + 'norm'))
+                pair = ops.LinearPack([(W(pre + 'proj_pair'), Bv(pre + 'proj_pair'), 0)], 192, ln=ln(pre + 'norm'))
+                out = ops.LinearPack([(W(pre + 'attn.proj_out'), Bv(pre + 'attn.proj_out'), 0)], 192)
+                blk[ta] = ops.tri_attn_pack(qkvg, pair, out)
+            self._blocks = blk
+            # ONE packing per weight: the descriptor-level path (the _ln_lin / _lin calls of Engine.run_chunk) reads the same buffers,
+            # so the two ways of issuing the op groups give the same bits
+            l1, l2 = blk['pair_transition']
+            pre = P_BLK + 'pair_transition.transition.'
+            self._ln_cache[(pre + '1', pre + '0')] = (l1.Wt, l1.csum, l1.bias, l1.planes)
+            self._split_cache[('mlp2', pre + '3')] = l2.planes
+            self.wt[pre + '3'], self.b[pre + '3'] = l2.Wt, l2.bias
+            self._split_cache[pre + '3'] = None                       # (its planes are k-permuted: never the operand of a plain GEMM)
+            for tm in ('triangle_multiplication_outgoing', 'triangle_multiplication_incoming'):
+                pre = P_BLK + tm + '.'
+                glu, out, gate = blk[tm]._keep
+                self._ln_cache[(pre + 'lr_glu', pre + 'norm')] = (glu.Wt, glu.csum, glu.bias, glu.planes)
+                self._ln_cache[(pre + 'proj_out', pre + 'final_norm')] = (out.Wt, out.csum, out.bias, out.planes)
+                self._ln_cache[(pre + 'final_gate', pre + 'norm')] = (gate.Wt, gate.csum, gate.bias, gate.planes)
+            for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
+                pre = P_BLK + ta + '.'
+                qkvg, pair, out = blk[ta]._keep
+                self._ln_cache[(pre + 'qkvg', pre + 'norm')] = (qkvg.Wt, qkvg.csum, qkvg.bias, qkvg.planes)
+                self._ln_cache[(pre + 'proj_pair', pre + 'norm')] = (pair.Wt, pair.csum, pair.bias, pair.planes)
+                self.wt[pre + 'attn.proj_out'], self.b[pre + 'attn.proj_out'] = out.Wt, out.bias
+                self._split_cache[pre + 'attn.proj_out'] = out.planes
+        return self._blocks
+
     def split_narrow(self, wt, key):
         """float16 weight planes of a skinny (N <= 32) weight matrix: the pair-stack bias projections stream their 9.5 GB A operand
         through the 128 x 32 tile of the split-f16 GEMM (DMA pipeline) instead of the exact kernel's register-staged loads."""
@@ -164,6 +216,12 @@ class Engine:
         self.P = packed
         self.dev = device
         self.ws = Workspace(device)
+        # True: the three pair-stack op groups (triangle multiplication x 2, triangle attention x 2, pair transition) run through the
+        # op-group entry points of the C ABI (abx_tri_mul_fwd / abx_tri_attn_block_fwd / abx_transition_fwd, csrc/blocks.hip) - the same
+        # kernels in the same order as the descriptor-level path below, which stays as the per-kernel view (bench.py's op profile, the
+        # exact-arithmetic tri-mul)
+        self.block_api = not bool(__import__('os').environ.get('ABX_NO_BLOCK_API'))
+        self._blk_ws = {}
         c = cfg_model.embeddings_and_seqformer
         pp = c.prev_pos
         # squared distogram breaks exactly as torch computes them on the host (common_modules.py:108-109)
@@ -251,6 +309,8 @@ class Engine:
         Bc = b1 - b0
         L, Lab = st['L'], st['Lab']
         P.gemm_mode = ops.gemm_mode(L)
+        packs = P.block_packs()          # (built once; both ways of issuing the op groups below read these buffers)
+        blocks = packs if self.block_api else None
         M1, M2, LL = Bc * L, Bc * L * L, L * L
         CS, CZ, E = c.seq_channel, c.pair_channel, c.index_embed_size
         WS_, WZ = CS + E, CZ + 2 * E
@@ -283,7 +343,15 @@ class Engine:
         s2 = seq_act.view(M1, WS_)
         z2 = pair_act.view(M2, WZ)
         z3 = pair_act.view(Bc, LL, WZ)
-        w768 = ws.get('w768', (M2, 768))
+        if self.block_api and (P.gemm_mode == 2 or L <= 389):
+            # the 768-wide scratch IS the q | k | v | gate region at the head of the triangle-attention block workspace (no second copy)
+            key = ('attn', Bc, L)
+            if key not in self._blk_ws:
+                self._blk_ws = {k: v for k, v in self._blk_ws.items() if k[0] != 'attn'}
+                self._blk_ws[key] = ops.tri_attn_block_workspace(Bc, L, self.dev)
+            w768 = self._blk_ws[key][:M2 * 768 * 4].view(torch.float32).view(M2, 768)
+        else:
+            w768 = ws.get('w768', (M2, 768))
         w384 = ws.get('w384', (M2 * 384,))
         pmask = ws.get('pmask', (M2,))
         ops.pair_mask(mask_f, pmask, Bc, L)
@@ -326,6 +394,16 @@ class Engine:
         pad = (L, Lp) if Lp != L else None
         for name, outgoing in (('triangle_multiplication_outgoing', True), ('triangle_multiplication_incoming', False)):
             pre = P_BLK + name + '.'
+            if blocks is not None and planes:
+                # one call of the C ABI per module: out-of-place (z3 -> the 768-wide workspace -> z3 for the two variants)
+                key = ('mul', Bc, L)
+                if key not in self._blk_ws:
+                    self._blk_ws = {k: v for k, v in self._blk_ws.items() if k[0] != 'mul'}
+                    self._blk_ws[key] = ops.tri_mul_workspace(Bc, L, self.dev)
+                zb = w768.view(-1)[:Bc * LL * 192].view(Bc, LL, 192)
+                zin, zout = (z3, zb) if outgoing else (zb, z3)
+                ops.tri_mul_fwd(blocks[name], zin, zout, mask_f, Bc, L, outgoing, self._blk_ws[key])
+                continue
             # sigmoid(left_gate | right_gate) channel-major like the projections they gate; sigmoid(final_gate) row-major
             GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
             Gf = w768.view(-1)[Bc * 256 * LL:Bc * 448 * LL].view(Bc, LL, 192)
@@ -376,6 +454,10 @@ class Engine:
         # ---------------- triangle attention (seqformer.py:506-550)
         for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
             pre = P_BLK + name + '.'
+            if blocks is not None and (P.gemm_mode == 2 or L <= 389):
+                key = ('attn', Bc, L)
+                ops.tri_attn_block_fwd(blocks[name], z2, mask_f, Bc, L, per_row, self._blk_ws[key], exact=P.gemm_mode != 2)
+                continue
             _ln_lin(P, pre + 'qkvg', pre + 'norm', None, z2, w768)
             bT = ws.get('biasT', (Bc, 4, LL))
             _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True)
@@ -392,7 +474,9 @@ class Engine:
             _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'
-        if P.gemm_mode == 2:
+        if blocks is not None:
+            ops.transition_fwd(*blocks['pair_transition'], z2, exact=P.gemm_mode != 2, workspace=w768)
+        elif P.gemm_mode == 2:
             # LayerNorm -> Linear -> ReLU -> Linear + residual in ONE kernel: the 768-wide hidden never travels through HBM
             _ln_lin(P, pre + '1', pre + '0', None, z2, z2, act=1, resid=z2, mlp=P.mlp_second(pre + '3'))
         else:

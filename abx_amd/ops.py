@@ -6,7 +6,8 @@ import math
 import torch
 
 from abx_amd import _lib
-from abx_amd._lib import AbxGemm, AbxTriAttn, AbxIpaTail, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, check
+from abx_amd._lib import (AbxGemm, AbxTriAttn, AbxIpaTail, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, AbxLinearPack, AbxLinearSrc,
+                           AbxTriMulPack, AbxTriAttnPack, check)
 
 
 def _stream():
@@ -382,6 +383,121 @@ def transpose_last2(x, out, transpose=True):
     check(_lib.load().abx_transpose_last2(_p(_f32(x)), _p(out), x.numel() // (L * L), L, Lp, int(bool(transpose)), _stream()),
           'abx_transpose_last2')
     return out
+
+
+# ---- op-group entry points of the C ABI (include/abx_hip.h, csrc/blocks.hip) ---------------------------------------------------------
+class LinearPack:
+    """A Linear (optionally with its LayerNorm folded in) packed by abx_pack_linear: .c is the AbxLinearPack, the device buffer it points
+    into is kept alive here; .Wt / .csum / .bias / .planes are tensor views of the same memory for the descriptor-level calls."""
+
+    def __init__(self, sources, K, ln=None, permute_k16=False, device=None):
+        """sources: list of (W (rows, K), b (rows) or None, glu in {0, 1, 2}); ln: (gamma, beta) of the LayerNorm to fold or None."""
+        lib = _lib.load()
+        dev = device if device is not None else sources[0][0].device
+        N = sum(int(W.shape[0]) for W, _, _ in sources)
+        nbytes = int(lib.abx_pack_linear_bytes(K, N))
+        self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self.buf.data_ptr()) % 256
+        base = self.buf[off:off + nbytes]
+        keep = []
+        arr = (AbxLinearSrc * len(sources))()
+        for i, (W, b, glu) in enumerate(sources):
+            W = _f32(W).contiguous()
+            assert W.shape[1] == K
+            keep.append(W)
+            arr[i].W, arr[i].rows, arr[i].glu = _p(W), int(W.shape[0]), int(glu)
+            if b is not None:
+                b = _f32(b).contiguous()
+                keep.append(b)
+                arr[i].b = _p(b)
+        gamma = beta = None
+        if ln is not None:
+            gamma, beta = _f32(ln[0]).contiguous(), _f32(ln[1]).contiguous()
+        self.c = AbxLinearPack()
+        check(lib.abx_pack_linear(arr, len(sources), K, _p(gamma), _p(beta), 1 if permute_k16 else 0, base.data_ptr(), C.byref(self.c), _stream()),
+              'abx_pack_linear')
+        self.K, self.N, self.w_exp = K, N, int(self.c.b_exp)
+
+        def view(ptr, numel, dtype):
+            if not ptr:
+                return None
+            o = ptr - base.data_ptr()
+            return base[o:o + numel * torch.empty(0, dtype=dtype).element_size()].view(dtype)
+
+        Kp = (K + 15) // 16 * 16
+        self.Wt = view(self.c.Wt, K * N, torch.float32).view(K, N)
+        self.csum = view(self.c.csum, N, torch.float32)
+        self.bias = view(self.c.bias, N, torch.float32)
+        pl = view(self.c.planes, Kp * 2 * N, torch.float16).view(Kp // 16, 2, N, 16).as_subclass(WeightPlanes)
+        pl.w_exp = self.w_exp
+        self.planes = pl
+
+
+def _range_args(exact, name):
+    if RANGE_CHECK and not exact:
+        return range_word(torch.device('cuda', torch.cuda.current_device())).data_ptr(), RANGE_TAGS[name]
+    return None, 0
+
+
+def transition_fwd(l1, l2, z, exact=False, workspace=None):
+    """pair Transition in place on z (M, C) through abx_transition_fwd (one launch on the split-f16 path)."""
+    lib = _lib.load()
+    M = z.shape[0]
+    assert z.is_contiguous() and z.shape[1] == l1.K
+    if exact:
+        need = int(lib.abx_transition_workspace_bytes(M, l1.N, 1))
+        assert workspace is not None and workspace.numel() * workspace.element_size() >= need
+    rf, rt = _range_args(exact, 'pair_transition')
+    check(lib.abx_transition_fwd(C.byref(l1.c), C.byref(l2.c), _p(z), M, int(bool(exact)), _p(workspace), rf, rt, _stream()), 'abx_transition_fwd')
+    return z
+
+
+def tri_mul_pack(glu, out, gate):
+    p = AbxTriMulPack()
+    p.glu, p.out, p.gate = glu.c, out.c, gate.c
+    p._keep = (glu, out, gate)
+    return p
+
+
+def tri_mul_workspace(B, L, device):
+    """(workspace tensor, initialised) for abx_tri_mul_fwd: the operand-image region is zero-filled once."""
+    lib = _lib.load()
+    ws = torch.empty(int(lib.abx_tri_mul_workspace_bytes(B, L)) + 256, dtype=torch.uint8, device=device)
+    ws = ws[(-ws.data_ptr()) % 256:]
+    check(lib.abx_tri_mul_workspace_init(_p(ws), B, L, _stream()), 'abx_tri_mul_workspace_init')
+    return ws
+
+
+def tri_mul_fwd(pack, z_in, z_out, mask_f, B, L, outgoing, workspace):
+    lib = _lib.load()
+    assert z_in.is_contiguous() and z_out.is_contiguous() and z_in.data_ptr() != z_out.data_ptr()
+    rf, rt = _range_args(False, 'contraction')
+    check(lib.abx_tri_mul_fwd(C.byref(pack), _p(z_in), _p(z_out), _p(_f32(mask_f)), B, L, int(bool(outgoing)), _p(workspace), rf, rt, _stream()),
+          'abx_tri_mul_fwd')
+    return z_out
+
+
+def tri_attn_pack(qkvg, pair, out):
+    p = AbxTriAttnPack()
+    p.qkvg, p.pair, p.out = qkvg.c, pair.c, out.c
+    p._keep = (qkvg, pair, out)
+    return p
+
+
+def tri_attn_block_workspace(B, L, device):
+    ws = torch.empty(int(_lib.load().abx_tri_attn_block_workspace_bytes(B, L)) + 256, dtype=torch.uint8, device=device)
+    return ws[(-ws.data_ptr()) % 256:]
+
+
+def tri_attn_block_fwd(pack, z, mask_f, B, L, per_row, workspace, exact=False, attn_exact=None):
+    """exact: the three GEMMs on the exact kernels; attn_exact: the attention kernel (default: the global GEMM_EXACT switch, as tri_attn)."""
+    lib = _lib.load()
+    ax = bool(GEMM_EXACT if attn_exact is None else attn_exact)
+    ex = int(bool(exact)) | (2 if ax else 0)
+    rf, rt = _range_args(ex == 3, 'tri_attn')
+    check(lib.abx_tri_attn_block_fwd(C.byref(pack), _p(z), _p(_f32(mask_f)), B, L, int(bool(per_row)), ex, _p(workspace), rf, rt, _stream()),
+          'abx_tri_attn_block_fwd')
+    return z
 
 
 def tri_attn_kernel_name(L, exact=None, bias_vec=True):

@@ -406,6 +406,67 @@ typedef struct AbxGuidanceArgs {
 long long abx_clash_grad_workspace_bytes(int B, int L);
 int abx_clash_grad(const AbxGuidanceArgs* a, void* workspace, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Op-group entry points: one call per reference module of the pair stack, for a maintainer who binds
+ * abx/model/seqformer.py without the Python orchestration of abx_amd/model/forward.py.  Each is a fixed sequence of the launches above
+ * (abx_gemm descriptors filled here exactly as forward.py fills them; same kernels, same bits), asynchronous on the stream, no
+ * allocation: weights come as packs built once by abx_pack_linear into caller memory, scratch as a caller workspace
+ * (abx_*_workspace_bytes).  exact = 0: the split-f16 kernels (needs L >= 64 and B * L * L >= 32768 rows: what AbxGemm.exact = 2 serves);
+ * exact = 1: the exact fp32-MFMA kernels (any size; triangle attention: L <= 389).  range_flag / range_tag: see AbxGemm.range_flag
+ * (every launch of a group ORs the same tag).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* One Linear (optionally with the preceding LayerNorm folded in), packed for both arithmetic paths.  All pointers point into the
+ * caller's buffer handed to abx_pack_linear. */
+typedef struct AbxLinearPack {
+    const float* Wt;                    /* [K][N] fp32, rows scaled by the LayerNorm gamma when folded */
+    const float* csum;                  /* [N] column sums of Wt (folded LayerNorm) or NULL */
+    const float* bias;                  /* [N]: beta @ W^T + b (folded) / b / NULL */
+    const unsigned short* planes;       /* abx_split_weights_f16 image [Kp/16][2][N][16] of Wt (of its k-permuted copy with ABX_PACK_PERMUTE_K16) */
+    int b_exp;                          /* exponent of the planes */
+    int K, N;
+} AbxLinearPack;
+/* a group of weight rows that becomes output columns: W [rows][K] (torch Linear.weight), b [rows] or NULL; glu: 0 = the sources
+ * are concatenated in order; 1 / 2 = value / gate rows of a gated projection: channel c of the concatenated value (gate) sources
+ * lands in column (c / 32) * 64 + c % 32 (+ 32), the (value, gate) column pairs of AbxGemm.glu */
+typedef struct AbxLinearSrc { const float* W; const float* b; int rows; int glu; } AbxLinearSrc;
+#define ABX_PACK_PERMUTE_K16 1          /* planes in the k order of the fused transition's second layer (0-3, 8-11, 4-7, 12-15 per 16) */
+long long abx_pack_linear_bytes(int K, int N);
+/* gamma / beta: [K] of the LayerNorm to fold, or NULL.  Synchronises the stream once (the plane exponent needs max |w| on the host):
+ * packing is set-up work, outside any graph capture.  buf: 256-byte aligned device memory of abx_pack_linear_bytes(K, N). */
+int abx_pack_linear(const AbxLinearSrc* src, int nsrc, int K, const float* gamma, const float* beta, int flags, void* buf,
+                    AbxLinearPack* out, hipStream_t stream);
+
+/* pair Transition (seqformer.py:358-376): z <- z + W2 relu(W1 LN(z) + b1) + b2 on rows [M][C], in place.
+ * l1: pack of transition.1 with transition.0 (LayerNorm) folded; l2: pack of transition.3 with ABX_PACK_PERMUTE_K16.
+ * exact = 0: ONE kernel (AbxGemm.mlp; C <= 192, no workspace); exact = 1: two GEMMs, workspace = M * l1.N floats. */
+long long abx_transition_workspace_bytes(long long M, int hidden, int exact);
+int abx_transition_fwd(const AbxLinearPack* l1, const AbxLinearPack* l2, float* z, long long M, int exact, void* workspace,
+                       int* range_flag, int range_tag, hipStream_t stream);
+
+/* TriangleMultiplication (seqformer.py:443-504), outgoing ('bikc,bjkc->bijc') or incoming ('bkic,bkjc->bijc').
+ * glu: [left_proj | right_proj] (glu = 1) and [left_gate | right_gate] (glu = 2) with `norm` folded; out: proj_out with
+ * `final_norm` folded; gate: final_gate with `norm` folded.  z_in (B, L*L, 192) -> z_out (B, L*L, 192), z_out != z_in (the tail
+ * reads all channels of a row of z_in while other tiles write theirs); mask (B, L) float 0/1.  Split-f16 path only (exact = 0):
+ * three launches - gated projections written as f16 operand images, plane x plane contraction, output projection * final gate +
+ * residual.  The image region of the workspace must read zero where the kernels never write (pad k-tiles when ceil4(L) % 16 != 0):
+ * abx_tri_mul_workspace_init once per (workspace, B, L). */
+typedef struct AbxTriMulPack { AbxLinearPack glu, out, gate; } AbxTriMulPack;
+long long abx_tri_mul_workspace_bytes(int B, int L);
+int abx_tri_mul_workspace_init(void* workspace, int B, int L, hipStream_t stream);
+int abx_tri_mul_fwd(const AbxTriMulPack* w, const float* z_in, float* z_out, const float* mask, int B, int L, int outgoing,
+                    void* workspace, int* range_flag, int range_tag, hipStream_t stream);
+
+/* TriangleAttention block (seqformer.py:506-550 + Attention.forward :272-312), starting node (per_row = 1) or ending node:
+ * z <- z + proj_out(attention(LN(z))) in place on (B, L*L, 192).  qkvg: [proj_q | proj_k | proj_v | gate] with `norm` folded;
+ * pair: proj_pair (192 -> 4 heads) with `norm` folded; out: attn.proj_out.  Launches: q|k|v|gate GEMM, bias GEMM, bias transpose /
+ * pad (ending node or L % 4 != 0), abx_tri_attn_fwd, output GEMM + residual.  exact here is two bits: bit 0 the three GEMMs, bit 1 the
+ * attention kernel (a small complex runs exact GEMMs - too few rows for the split tiles - with the split-f16 attention, which has no
+ * size limit: exact = 1; everything exact, L <= 389: exact = 3). */
+typedef struct AbxTriAttnPack { AbxLinearPack qkvg, pair, out; } AbxTriAttnPack;
+long long abx_tri_attn_block_workspace_bytes(int B, int L);
+int abx_tri_attn_block_fwd(const AbxTriAttnPack* w, float* z, const float* mask, int B, int L, int per_row, int exact, void* workspace,
+                           int* range_flag, int range_tag, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
