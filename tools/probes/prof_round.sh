@@ -1,11 +1,12 @@
+# One profiling round on the GPU box (bash tools/probes/prof_round.sh <tag>): headline bench with CPU baseline, the per-GPU batch sizes of
+# strong scaling, rocprofv3 kernel stats + HBM traffic passes of the same command, in-kernel clocks, counter passes of the dominant kernels.
+TAG=${1:-r04}
 export TMPDIR=/tmp
-O=gpurun_out/r03i; mkdir -p $O
+O=gpurun_out/$TAG; mkdir -p $O
 python bench.py --steps 4 --warmup 2 > $O/bench_L352.json 2> $O/bench_L352.err
-python bench.py --samples 12 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b12.json 2>> $O/bench.err
-python bench.py --samples 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b1.json 2>> $O/bench.err
-python bench.py --samples 13 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b13.json 2>> $O/bench.err
-python bench.py --samples 25 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b25.json 2>> $O/bench.err
-python bench.py --samples 50 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b50.json 2>> $O/bench.err
+for b in 50 25 13 12 1; do python bench.py --samples $b --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_b$b.json 2>> $O/bench.err; done
+python bench.py --workload 6ct7like --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_6ct7like.json 2>> $O/bench.err
+python bench.py --workload 6qd7like --samples 32 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_6qd7like.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-op-profile > $O/prof.log 2>&1
 python tools/rocprof_summary.py $(find $O/prof -name "*results.db" | head -1) $O/kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-op-profile > $O/pmc_fetch.log 2>&1
@@ -13,7 +14,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/prof
 python tools/probes/clock_probe.py 3 > $O/clock.txt 2>&1
-bash tools/pmc_run.sh tri r03i_tri; python tools/pmc_reduce.py gpurun_out/r03i_tri tri_attn4 > $O/pmc_triattn4.txt
-bash tools/pmc_run.sh contract r03i_contract; python tools/pmc_reduce.py gpurun_out/r03i_contract gemm3_kernel > $O/pmc_contract.txt
-rm -rf gpurun_out/r03i_tri_* gpurun_out/r03i_contract_*
+bash tools/pmc_run.sh tri ${TAG}_tri; python tools/pmc_reduce.py gpurun_out/${TAG}_tri tri_attn8 > $O/pmc_triattn8.txt
+bash tools/pmc_run.sh mlp ${TAG}_mlp; python tools/pmc_reduce.py gpurun_out/${TAG}_mlp gemm3_mlp > $O/pmc_mlp.txt
+rm -rf gpurun_out/${TAG}_tri_* gpurun_out/${TAG}_mlp_*
+python tools/ab_lib.py tools/probes/bin/libabx_stamp.so tools/probes/tri_stamps.py 20 352 > $O/triattn8_stamps.txt 2>&1
+for c in config2 config5 config4; do python tools/e2e_bench.py $c > $O/e2e_$c.json 2>> $O/e2e.err; done
 ls -la $O
