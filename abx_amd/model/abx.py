@@ -93,6 +93,7 @@ class ScoreNetwork(nn.Module):
             return hit
         free, _ = torch.cuda.mem_get_info(device)
         chunk = max(1, min(B, _MAX_CHUNK, int(0.45 * (free + held) / need)))
+        chunk = -(-B // -(-B // chunk))          # equal shares: 100 samples that do not fit one launch run as 50 + 50, not 99 + 1
         self._auto_chunks[key] = chunk
         return chunk
 
