@@ -137,6 +137,14 @@ class TrajectoryWriter:
         self.q = queue.Queue(maxsize=max_pending)
         self.files, self.error = [], None
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        # The worker formats PDB text in Python and holds the GIL while it does; the sampling thread gives the GIL up at every host
+        # synchronisation (the range word of a network pass, model/abx.py) and would then wait a full switch interval (5 ms) to get it
+        # back with the GPU idle: a short interval while a writer is alive (ABX_WRITER_SWITCH_INTERVAL seconds; 0 keeps the default)
+        import sys
+        self._switch = sys.getswitchinterval()
+        want = float(os.environ.get('ABX_WRITER_SWITCH_INTERVAL', '2e-4'))
+        if want > 0:
+            sys.setswitchinterval(min(self._switch, want))
         self.worker = threading.Thread(target=self._run, daemon=True)
         self.worker.start()
 
@@ -177,6 +185,8 @@ class TrajectoryWriter:
     def close(self):
         self.q.put(None)
         self.worker.join()
+        import sys
+        sys.setswitchinterval(self._switch)
         if self.error is not None:
             raise self.error
         return self.files

@@ -14,7 +14,7 @@ LayerNorm -> Linear -> ReLU -> Linear projection run here; the ESM2 weights (`im
 reference checkpoint) are skipped by `load_state_dict`.
 
 Lifetime of what a call returns: `representations` and `_prev_pos` are views of two internal ping-pong buffers (a (B,L,L,192)
-tensor is 9.5 GB at B = 100, L = 352).  A pass never writes the buffer that `batch['prev_pair']` currently points to, so the
+tensor is 9.5 GB at B = 100, L = 352; three since round 4: the input buffer of a call stays pinned until its range word is read).  A pass never writes the buffer that `batch['prev_pair']` currently points to, so the
 self-conditioning input of the next call is always intact; the representations returned by call n are overwritten during call
 n + 1.  Callers that keep them longer set `ScoreNetwork.clone_outputs = True` (fresh tensors, as the reference returns).
 The trajectory-invariant embeddings travel in `batch['_static']`: their lifetime is that of the batch dict they were built from
@@ -62,7 +62,8 @@ class ScoreNetwork(nn.Module):
         self._engine_key = None
         self._engine_serial = 0
         self._bufs = {}
-        self.range_log = []              # passes that left the split-f16 operand ranges and were repeated on the exact kernels
+        self.range_log = []              # calls that left the split-f16 operand ranges and were repeated on the exact kernels
+        self._pinned = set()
         self._n_calls = 0
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -131,15 +132,50 @@ class ScoreNetwork(nn.Module):
         self._static = hit[1]
         num_recycle = self._model_conf.num_recycle
         self._n_calls += 1
-        with torch.no_grad():
+        from abx_amd import ops
+
+        def passes():
             batch.update(is_recycling=True)
             for _ in range(num_recycle):
-                ret = self._pass(eng, batch, final=False)
-                prev = get_prev(batch, ret, self._model_conf)
-                batch.update(seq_t=ret['heads']['sequence_module']['seq_0'])
+                r = self._pass(eng, batch, final=False)
+                prev = get_prev(batch, r, self._model_conf)
+                batch.update(seq_t=r['heads']['sequence_module']['seq_0'])
                 batch.update(prev)
             batch.update(is_recycling=False)
-            ret = self._pass(eng, batch, final=bool(compute_loss))
+            return self._pass(eng, batch, final=bool(compute_loss))
+
+        # Range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag): the kernels OR a bit into the device's range word
+        # when a value they store is not finite - what an activation beyond their operand ranges becomes (the reference's plain fp32
+        # contractions have no such range: seqformer.py:260-312, 443-504).  The word is read ONCE per call (one host synchronisation; a
+        # read per pass cost 18 % of a 32-sample trajectory step, whose kernels are short enough for the launch thread to be exposed
+        # after every drain); the call's inputs - the self-conditioning tensors of the previous call, the tokens - stay intact until then
+        # (the representation buffers rotate three ways and the call's input buffer is pinned), and a flagged call is repeated on the
+        # exact fp32-MFMA kernels, so a caller never sees the contract: results are the reference's either way.  Inside a hipGraph capture
+        # the word only accumulates (abx_amd.graph checks it after each replay).
+        word = ops.range_word(device) if ops.RANGE_CHECK and not ops.GEMM_EXACT else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        start = {k: batch.get(k) for k in ('seq_t', 'prev_pos', 'prev_seq', 'prev_pair')}
+        self._pinned = {v.data_ptr() for k, v in start.items() if k != 'seq_t' and torch.is_tensor(v)}
+        try:
+            with torch.no_grad():
+                if word is not None and not capturing:
+                    word.zero_()
+                ret = passes()
+                if word is not None and not capturing:
+                    bits = int(word.item())
+                    if bits:
+                        self.range_log.append({'call': self._n_calls, 'ops': ops.range_names(bits), 'L': L, 'B': B})
+                        if L > 389 and (bits & ops.RANGE_TAGS['tri_attn']):
+                            raise FloatingPointError('triangle attention operands left the split-f16 range (|k|, |v| < 4095, |q| scale < 5600) or '
+                                                     f'are not finite, and the exact fp32 kernel serves L <= 389 only (L = {L})')
+                        batch.update(start)
+                        ops.GEMM_EXACT = True
+                        try:
+                            ret = passes()
+                        finally:
+                            ops.GEMM_EXACT = False
+        finally:
+            self._pinned = set()
         return ret
 
     def _esm_embed(self, batch):
@@ -163,9 +199,9 @@ class ScoreNetwork(nn.Module):
         # ping-pong representation buffers: write the one that batch['prev_*'] does NOT point to (the self-conditioning input of
         # this pass); foreign prev_* tensors (first call, reference-style drivers) leave both free
         f32, i64 = torch.float32, torch.int64
-        busy = {batch[k].data_ptr() for k in ('prev_seq', 'prev_pair', 'prev_pos') if torch.is_tensor(batch.get(k))}
+        busy = {batch[k].data_ptr() for k in ('prev_seq', 'prev_pair', 'prev_pos') if torch.is_tensor(batch.get(k))} | self._pinned
         tag = '0'
-        for cand in ('0', '1'):
+        for cand in ('0', '1', '2'):
             mine = [self._bufs.get(n + cand) for n in ('rep_seq', 'rep_pair', 'prev_pos')]
             if not any(b is not None and b.data_ptr() in busy for b in mine):
                 tag = cand
@@ -201,31 +237,8 @@ class ScoreNetwork(nn.Module):
         from abx_amd import ops
         ops.timestep_embedding(st['t64'], c.index_embed_size, st['temb'])
         chunk = max(1, min(self.max_chunk, B)) if self.max_chunk else self._auto_chunk(B, L, device)
-        # Range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag): the kernels OR a bit into the device's range word
-        # when an accumulator is not finite - what an activation beyond their operand ranges becomes (the reference's plain fp32
-        # contractions have no such range: seqformer.py:260-312, 443-504).  The word is read once per pass (the inputs of a pass, the
-        # previous pass's buffers, are still intact then) and a flagged pass is repeated on the exact fp32-MFMA kernels, so a caller never
-        # sees the contract: results are the reference's either way.  Inside a hipGraph capture the word only accumulates
-        # (abx_amd.graph checks it after each replay).
-        word = ops.range_word(device) if ops.RANGE_CHECK and not ops.GEMM_EXACT else None
-        capturing = torch.cuda.is_current_stream_capturing()
-        if word is not None and not capturing:
-            word.zero_()
         for b0 in range(0, B, chunk):
             eng.run_chunk(st, b0, min(B, b0 + chunk), final)
-        if word is not None and not capturing:
-            bits = int(word.item())
-            if bits:
-                self.range_log.append({'call': self._n_calls, 'ops': ops.range_names(bits), 'L': L, 'B': B})
-                if L > 389 and (bits & ops.RANGE_TAGS['tri_attn']):
-                    raise FloatingPointError(f'triangle attention operands left the split-f16 range (|k|, |v| < 4095, |q| scale < 5600) or are not '
-                                             f'finite, and the exact fp32 kernel serves L <= 389 only (L = {L})')
-                ops.GEMM_EXACT = True
-                try:
-                    for b0 in range(0, B, chunk):
-                        eng.run_chunk(st, b0, min(B, b0 + chunk), final)
-                finally:
-                    ops.GEMM_EXACT = False
         folding = {
             'rot_score': st['rot_score'], 'trans_score': st['trans_score'], 'rigids': st['rigids'],
             'final_atom14_positions': st['atom14'], 'final_atom_positions': st['atom37'],

@@ -31,7 +31,7 @@ GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 # ---- range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag) ----------------------------------------------
 # Every split-f16 launch made through this module carries the address of one device word per GPU and a bit that names its call-site
 # class; a kernel whose accumulators are not finite - what an operand beyond the split ranges turns into - ORs its bit into the word.
-# abx_amd.model.abx.ScoreNetwork clears the word before a network pass, reads it after, and repeats the pass on the exact fp32-MFMA
+# abx_amd.model.abx.ScoreNetwork clears the word before a network call, reads it after, and repeats the call on the exact fp32-MFMA
 # kernels when it is set, so the range contract of the fast path never reaches a caller as a wrong or non-finite result.
 RANGE_TAGS = {'gemm': 1, 'contraction': 2, 'plane_projection': 4, 'tri_mul_tail': 8, 'pair_transition': 16, 'ipa_pair_init': 32,
               'tri_attn': 64, 'ipa_tail': 128}

@@ -163,7 +163,7 @@ typedef struct AbxGemm {
                                                       are not finite - what an operand beyond the split ranges above turns into, inf - inf,
                                                       and what a non-finite input gives too - ORs range_tag into *range_flag (one atomic per
                                                       wave, only then).  The caller clears the word, gives every call site its own bit, reads
-                                                      it after a pass and repeats the pass with exact = 1 (abx_amd/model/abx.py does) */
+                                                      it after a network call and repeats the call with exact = 1 (abx_amd/model/abx.py does) */
     unsigned long long* clock_probe;               /* diagnostics, optional DEVICE [2]: every workgroup of the split-f16 kernels adds
                                                       its elapsed shader-clock ticks (s_memtime) to [0] and its elapsed constant
                                                       100 MHz ticks (s_memrealtime) to [1]: 100 MHz * [0] / [1] = the shader clock

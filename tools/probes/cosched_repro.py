@@ -66,6 +66,46 @@ def worker(n, tag):
     def restore_k():
         for s, s0 in zip(state, state0):
             torch.add(s0, 0.0, out=s)
+    if os.environ.get('COSCHED_DIAG'):
+        # ---- diagnosis of a differing launch: WHICH elements differ (rows = threads of the kernel: one lane? one
+        # workgroup of 128 threads?), were the kernel's read-only inputs and the restored in/out state intact, does an immediate
+        # second launch from restored inputs reproduce launch 0
+        if os.environ['COSCHED_DIAG'] == 'k':
+            restore = restore_k                                    # inputs restored by elementwise kernels (the variant that differs most)
+        ro0 = [upd.clone(), fixed.clone(), state0[0].clone(), state0[1].clone()]
+        out = lambda: torch.cat([state[2], state[3], state[4], state[5]], dim=1)
+        restore(); ops.rigid_update(upd, fixed, state[0], state[1], state[2], state[3], state[4], state[5], M1, 10.0)
+        first = out().clone()
+        events, done = 0, 0
+        while done < n and events < 6:
+            outs_, pres_ = [], []
+            for _ in range(256):                                   # no host synchronisation inside a batch (that is what lets the processes interleave)
+                restore()
+                pres_.append([s.clone() for s in state])          # what the kernel is about to read (copies made by other kernels)
+                ops.rigid_update(upd, fixed, state[0], state[1], state[2], state[3], state[4], state[5], M1, 10.0)
+                outs_.append(out().clone())
+            done += 256
+            bad = (~torch.stack([(o == first).all() for o in outs_])).nonzero().flatten().tolist()
+            for bi in bad:
+                events += 1
+                o, pre = outs_[bi], pres_[bi]
+                d = (o != first)
+                rows = d.any(1).nonzero().flatten()
+                pre_ok = [bool((a == b).all()) for a, b in zip(pre, state0)]
+                ro_ok = all(bool((a == b).all()) for a, b in zip([upd, fixed, state[0], state[1]], ro0))
+                # the same launch again, now from the inputs that launch actually saw
+                for s_, p_ in zip(state, pre):
+                    s_.copy_(p_)
+                ops.rigid_update(upd, fixed, state[0], state[1], state[2], state[3], state[4], state[5], M1, 10.0)
+                again_saw = bool((out() == o).all())
+                r0 = int(rows[0])
+                cols = d[r0].nonzero().flatten().tolist()
+                print(f'DIAG {tag} | launch {done - 256 + bi}: {int(d.sum())} elements in {rows.numel()} rows differ; rows {rows[:12].tolist()} '
+                      f'(workgroups of 128 threads: {sorted(set((rows // 128).tolist()))[:8]}); row {r0} columns {cols} got {o[r0, cols].tolist()} '
+                      f'first {first[r0, cols].tolist()}; in / out state as restored before the launch (cur_q, cur_t, ...): {pre_ok}; read-only inputs intact: {ro_ok}; '
+                      f're-launch from the inputs that launch saw reproduces ITS output: {again_saw}', flush=True)
+        print(f'DIAG {tag} | rigid_update: {events} differing launches of {done} (diagnostic loop, 256 launches per synchronisation)', flush=True)
+        return
     loop('rigid_update, kernel restore', restore_k, lambda: ops.rigid_update(upd, fixed, state[0], state[1], state[2], state[3], state[4], state[5], M1, 10.0),
          lambda: torch.cat([state[2], state[3], state[4], state[5]], dim=1), n)
     # torch only, the same restore-by-copy_ / launch / concatenate pattern with an elementwise kernel in the middle
@@ -114,6 +154,7 @@ if __name__ == '__main__':
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(workers)]
         outs = [p.communicate()[0] for p in procs]
         lines = [ln for o in outs for ln in o.splitlines() if ln.startswith('RESULT')]
+        print('\n'.join(ln for o in outs for ln in o.splitlines() if ln.startswith('DIAG')))
         print('\n'.join(sorted(lines, key=lambda s: s.split('|')[1])))
         hashes = {}
         for ln in lines:
