@@ -4,7 +4,7 @@ HIP kernels of libabx_hip.so (no PyTorch/CPU fallback: a missing library raises)
 
 Extensions (all optional, default = reference behaviour):
   batch['_shared_context'] = True   the B samples are copies of ONE complex -> trajectory-invariant embeddings are built once
-  ScoreNetwork.max_chunk            samples per launch through the pair stack (workspace size); None = fit 45 % of the free HBM
+  ScoreNetwork.max_chunk            samples per launch through the pair stack (workspace size); None = fit 50 % of the free HBM
 
 ESM2 hook (seqformer.py:185-191, encoder.py:72-121).  With `esm.enabled` the per-layer ESM2 representations of
 the CURRENT antibody sequence are an INPUT of every network pass: a (B, Lab, embed_channel, num_layers + 1) tensor taken from
@@ -39,8 +39,8 @@ def get_prev(batch, value, config):
     }
 
 
-# per-sample workspace of a pair-stack pass: w768 + w384 + bias/mask buffers + tri-mul plane operands ~ 8.2 KB per pair position
-_WORKSPACE_BYTES_PER_PAIR = 8200      # (+ the op-group workspaces of csrc/blocks.hip: attention output, bias copies, tri-mul product)
+# per-sample workspace of a pair-stack pass: w384 + the op-group workspaces of csrc/blocks.hip (attention: q|k|v|gate, bias copies, output; tri-mul: operand images, product) ~ 7.3 KB per pair position
+_WORKSPACE_BYTES_PER_PAIR = 7300      # (w384 1536 + attention block 3872 + tri-mul block 1540 + seq-attn bias 128 + masks: 7.1 KB measured)
 _MAX_CHUNK = 8192
 
 
@@ -55,7 +55,7 @@ class ScoreNetwork(nn.Module):
         self.impl = ScoreNetworkIteration(model_conf)
         self.diffuser = diffuser
         self._auto_chunks = {}
-        self.max_chunk = None            # None: as many samples per pair-stack launch as fit in 45 % of the free HBM
+        self.max_chunk = None            # None: as many samples per pair-stack launch as fit in 50 % of the free HBM
         self.clone_outputs = False
         self.esm_provider = None         # callable(batch) -> (B, Lab, embed_channel, num_layers + 1) when esm.enabled
         self._engine = None
@@ -87,13 +87,15 @@ class ScoreNetwork(nn.Module):
         (the workspace a previous decision allocated counts as available: it is what gets reused or replaced), and clamped to
         the grid limits of the kernels (abx_transpose_last2 / abx_tri_attn_fwd: 4 * chunk, chunk <= 65535)."""
         key = (B, L)
-        held = sum(b.numel() * b.element_size() for b in self._engine.ws.bufs.values()) if self._engine is not None else 0
+        held = 0
+        if self._engine is not None:        # what a previous decision allocated: the named scratch buffers and the op-group workspaces
+            held = sum(b.numel() * b.element_size() for b in list(self._engine.ws.bufs.values()) + list(self._engine._blk_ws.values()))
         need = _WORKSPACE_BYTES_PER_PAIR * L * L
         hit = self._auto_chunks.get(key)
         if hit is not None and hit * need <= held * 1.05:
             return hit
         free, _ = torch.cuda.mem_get_info(device)
-        chunk = max(1, min(B, _MAX_CHUNK, int(0.45 * (free + held) / need)))
+        chunk = max(1, min(B, _MAX_CHUNK, int(0.5 * (free + held) / need)))
         chunk = -(-B // -(-B // chunk))          # equal shares: 100 samples that do not fit one launch run as 50 + 50, not 99 + 1
         self._auto_chunks[key] = chunk
         return chunk
