@@ -524,7 +524,6 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
     float ls[1], lq[1], lsh[1] = {0.f};
     float rstd = 0.f, dmean = 0.f;
     const int nchunk = (g.N + BN - 1) / BN;
-    using T = SplitTerms;
     for (int c = 0; c < nchunk; ++c) {
         issue_w2(c * (BN / 16), 0);                                          // first W2 k-tile of the chunk: lands under GEMM 1
         f32x16 acc1[1][BN / 32];
@@ -568,9 +567,13 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
                             v[4 * q + e] = (hc + e < g.N) ? x : 0.f;
                         }
                     }
+                    // the hidden activations enter GEMM 2 as UNLIFTED pieces of h 2^4 (a0 = f16(h'), a1 = f16(h' - a0): what split2b writes
+                    // for plane operands), so its three terms a1 p0 + a0 p1 + a0 p0 need no p2 = p0 2^-11 derived from the W2 fragments
+                    // (192 v_pk_mul_f16 per chunk walk and 8 registers less).  |h| < 4094 (beyond: NaN -> the range probe -> the exact
+                    // kernels); 22 significant bits from |h| = 2^-7, 2^-29 absolute below - post-ReLU hidden values next to an O(1) sum
                     unsigned q0[4], q1[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) split2h(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+                    for (int e = 0; e < 4; ++e) split2b(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
                     hf[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
                     hf[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
                 }
@@ -581,18 +584,18 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
                 if (rows_live && (c * (BN / 16) + kl) * 16 < g.N) {
 #pragma unroll
                     for (int t0 = 0; t0 < TN2; t0 += TG2) {
-                        u32x4 wb[TG2][3];
+                        u32x4 wb[TG2][2];
 #pragma unroll
                         for (int t = 0; t < TG2; ++t)
 #pragma unroll
                             for (int p = 0; p < 2; ++p) wb[t][p] = *reinterpret_cast<const u32x4*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
+                        // smallest first: a1 p0, a0 p1, a0 p0
+                        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
 #pragma unroll
-                        for (int t = 0; t < TG2; ++t) wb[t][2] = f16x8_lo(wb[t][0]);
-#pragma unroll
-                        for (int term = 0; term < T::N; ++term)
+                        for (int term = 0; term < 3; ++term)
 #pragma unroll
                             for (int t = 0; t < TG2; ++t)
-                                acc2[0][t0 + t] = mfma_split(hf[T::A[term]], wb[t][T::B[term]], acc2[0][t0 + t]);
+                                acc2[0][t0 + t] = mfma_split(hf[TA[term]], wb[t][TB[term]], acc2[0][t0 + t]);
                     }
                 }
                 wait_vm_and_barrier<0>();
@@ -600,7 +603,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
         }
     }
     {
-        const float cs2 = __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - g.b2_exp);
+        const float cs2 = __builtin_ldexpf(1.0f, -4 - g.b2_exp);             // (the hidden went in as h 2^4: split2b)
 #pragma unroll
         for (int t = 0; t < TN2; ++t) acc2[0][t] *= cs2;
     }

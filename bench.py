@@ -113,7 +113,8 @@ class OpTimer:
         return name, 0.0, 0.0
 
     def __enter__(self):
-        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table')
+        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table',
+                'range_word', 'range_names')       # (host-side helpers: no launch to time)
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
             if callable(fn) and not isinstance(fn, type) and not name.startswith('_') and name not in skip and getattr(fn, '__module__', '') == self.ops.__name__:
