@@ -43,6 +43,17 @@ __device__ __forceinline__ void split2h_raw(float a, float b, unsigned& p0, unsi
     p0 = __builtin_bit_cast(unsigned, h0);
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
+// The same pieces with the remainder by the mixed-precision FMA (f16 source x f32 constant + f32 addend -> f16 result): (x - p0) 2^11 =
+// x 2^11 - 2^11 p0 is exact in fp32 (x - p0 is, and the scale is a power of two), so one rounding to f16 gives what convert - subtract -
+// scale - convert gives, in 5 instructions per pair instead of 7.  For the GEMM main loop only (two pairs per MFMA group); `m2048` is
+// -2048.0f in a VGPR of the caller (an SGPR operand costs the main kernels a spill, a literal is not encodable in VOP3P).
+__device__ __forceinline__ void split2h_mix(float a, float b, float m2048, unsigned& p0, unsigned& p1) {
+    const f32x2 x = (f32x2){a, b} * (f32x2){0.0625f, 0.0625f};
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2));
+    const f32x2 xs = (f32x2){a, b} * (f32x2){128.0f, 128.0f};
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p1) : "v"(p0), "v"(m2048), "v"(xs[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p1) : "v"(p0), "v"(m2048), "v"(xs[1]));
+}
 __device__ __forceinline__ void split2h(float a, float b, unsigned& p0, unsigned& p1) {
     split2h_raw(a * 0.0625f, b * 0.0625f, p0, p1);
 }

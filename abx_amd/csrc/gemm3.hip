@@ -46,6 +46,15 @@ __device__ __forceinline__ void glds16(const void* src, char* dst_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst_wave_base, 16, 0, 0);
 }
 
+// A per-lane 32-bit byte offset as the compiler must see it AT the DMA instruction: defined in the same basic block, so that the
+// address is (scalar base) + zext(32-bit VGPR) and the load takes the scalar-base form `global_load_lds v, s[a:a+1]`.  Hoisted out
+// of the k loop the zero-extension becomes a 64-bit VGPR pair and every DMA instruction a v_lshl_add_u64 first (4 VALU instructions
+// and 4 VGPRs per k-step of the 128 x 128 tile).
+__device__ __forceinline__ unsigned vgpr32(unsigned o) {
+    asm volatile("" : "+v"(o));
+    return o;
+}
+
 template <int N> __device__ __forceinline__ void wait_vm_and_barrier() {
     // own DMA writes for the next tile have landed (the newest N stay in flight), own LDS reads retired, then the block barrier
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -110,7 +119,9 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     char* As = reinterpret_cast<char*>(smem);                 // RING stages
     char* Bs = As + RING * A_STAGE;                           // RING stages
     const int m0 = mt * BM, n0 = nt * BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a scalar: the LDS destinations of the DMA instructions - m0 - are then SALU arithmetic, not a VALU
+    // computation + v_readfirstlane per instruction)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int h = lane >> 5;
 
@@ -180,14 +191,14 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         const char* src = baseA + tile * a_step;
 #pragma unroll
         for (int i = 0; i < NLA; ++i)
-            if (RING > 2 || A_IMG % 4096 == 0 || (wave * NLA + i) * 1024 < A_IMG) glds16(src + offsA[i], dst + i * 1024);
+            if (RING > 2 || A_IMG % 4096 == 0 || (wave * NLA + i) * 1024 < A_IMG) glds16(src + vgpr32(offsA[i]), dst + i * 1024);
     };
     auto issue_b = [&](int tile) {
         char* dst = Bs + (tile % RING) * B_STAGE + wave * NLB * 1024;
         const char* src = baseB + tile * b_step;
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
-            if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + offsB[i], dst + i * 1024);
+            if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + vgpr32(offsB[i]), dst + i * 1024);
     };
 
 #pragma unroll
@@ -197,6 +208,8 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float m2048 = -2048.0f;
+    asm volatile("" : "+v"(m2048));                           // (a VGPR constant of split2h_mix; not rematerialised into an SGPR)
     const bool relu = g.a_relu != 0;
     const bool ln_inline = g.ln_csum != nullptr && g.ln_stats == nullptr;
     f32x2 ls2[TM], lq2[TM];
@@ -294,7 +307,9 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
                 }
                 unsigned q0[4], q1[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split2h(x[2 * e], x[2 * e + 1], q0[e], q1[e]);
+                for (int e = 0; e < 4; ++e) {
+                    split2h_mix(x[2 * e], x[2 * e + 1], m2048, q0[e], q1[e]);
+                }
                 a[i][0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
                 a[i][1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
             }
@@ -372,12 +387,12 @@ __device__ __forceinline__ bool gemm3_row_stats(const AbxGemm& g, float* st_lds,
     return gstats != nullptr || ln_inline;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false, bool PROBE = true>
+template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false, bool PROBE = true, int RING = 2>
 __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN];
     float ls[TM], lq[TM], lsh[TM];
-    gemm3_mainloop<BM, BN, WM, WN, AMODE>(g, smem, mt, nt, b, acc, ls, lq, lsh);
+    gemm3_mainloop<BM, BN, WM, WN, AMODE, false, true, RING>(g, smem, mt, nt, b, acc, ls, lq, lsh);
     float* st_lds = smem;                                   // [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     __syncthreads();
@@ -413,8 +428,8 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_IMG = AMODE == 2 ? 2 * BM * 32 : BM * 64;
     constexpr int A_STAGE = A_IMG;
     constexpr int B_STAGE = 2 * BN * 32;
-    constexpr int RING = 2;
-    constexpr int OPER = (RING * A_STAGE + 2 * B_STAGE) / 4;                       // floats
+    constexpr int RING = 2;       // (3 stages at 3 blocks per CU, 4 at 2: 4.08 / 4.67 ms against 3.68 at N = 768, K = 192, 20 samples - DESIGN.md 4c)
+    constexpr int OPER = RING * (A_STAGE + B_STAGE) / 4;                           // floats
     constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;      // epilogue column group (gemm_epilogue.h)
     constexpr int SCR = 4 * 32 * ((TS ? WM : TGW * 32) + 4);
     constexpr int EPI = 2 * BM + SCR;
@@ -423,21 +438,40 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     // contiguous range of tiles, so the N-tiles that share an A panel - and all tiles of one batch entry of the
     // triangle-multiplication contraction - meet in one private L2.  Bijective for any grid size.
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
+    const int per_batch = ntn * ntm;
+    const ClockProbe probe(g.clock_probe);
+    constexpr bool PROBE = !(BM == 128 && BN == 128 && MINW >= 4);      // (no register for it at four blocks per CU: gemm_epilogue.h)
+#ifdef ABX_PERSIST
+    if (g.tune & 256) {
+        // experiment: resident blocks walk the tiles of their XCD's range (slot s takes x0 + s, x0 + s + slots, ...)
+        const long long total = (long long)per_batch * g.batch;
+        const long long q = total >> 3, r = total & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+        const long long x0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, xn = q + (xcd < r ? 1 : 0);
+        for (long long i = slot; i < xn; i += slots) {
+            const long long wgid = x0 + i;
+            const int b = (int)(wgid / per_batch);
+            const int rem = (int)(wgid - (long long)b * per_batch);
+            const int mt = rem / ntn, nt = rem % ntn;
+            const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
+            if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS, false, PROBE, RING>(g, smem, mt, nt, b);
+            else gemm3_block<BM, BN, WM, WN, AMODE, true, TS, false, PROBE, RING>(g, smem, mt, nt, b);
+            __syncthreads();
+        }
+        return;
+    }
+#endif
     long long wgid = blockIdx.x;
     if (!(g.tune & 1)) {
         const long long nwg = gridDim.x, bid = blockIdx.x;
         const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int per_batch = ntn * ntm;
     const int b = (int)(wgid / per_batch);
     const int rem = (int)(wgid - (long long)b * per_batch);
     const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
-    const ClockProbe probe(g.clock_probe);
-    constexpr bool PROBE = !(BM == 128 && BN == 128 && MINW >= 4);      // (no register for it at four blocks per CU: gemm_epilogue.h)
-    if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS, false, PROBE>(g, smem, mt, nt, b);
-    else gemm3_block<BM, BN, WM, WN, AMODE, true, TS, false, PROBE>(g, smem, mt, nt, b);
+    if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS, false, PROBE, RING>(g, smem, mt, nt, b);
+    else gemm3_block<BM, BN, WM, WN, AMODE, true, TS, false, PROBE, RING>(g, smem, mt, nt, b);
     probe.finish();
 }
 
@@ -789,6 +823,9 @@ template <int BM, int BN, int WM, int WN, int MINW>
 int launch3(const AbxGemm& g, hipStream_t st) {
     const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
     dim3 grid((unsigned)(mt * ntn * g.batch), 1, 1), block(256);
+#ifdef ABX_PERSIST
+    if ((g.tune & 256) && grid.x > 256u * MINW) grid.x = 256u * MINW;
+#endif
     const int amode = g.A_split ? 2 : (g.sAk == 1 ? 0 : 1);
     if (g.c_transposed) {
         if (amode != 0) { abx_set_error("abx_gemm: transposed store needs a k-contiguous fp32 A"); return ABX_ERR_ARG; }

@@ -22,7 +22,11 @@ C = torch.empty(M2, N, device=DEV)
 C1 = torch.empty(1, N, device=DEV).expand(M2, N)
 z1 = r(1, K).expand(M2, K)
 ops.RANGE_CHECK = False
-for name, a, c in (('normal', z, C), ('C rows -> 1 row (no HBM writes)', z, C1), ('A rows -> 1 row (no HBM reads)', z1, C),
-                   ('both (instruction streams alone)', z1, C1), ('normal', z, C)):
-    ms = timeit(lambda: ops.gemm(a, W, c, bias=bias, ln=(None, csum), B3=W3, exact=2), reps=9)
+TUNE = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+cases = (('normal', z, C), ('C rows -> 1 row (no HBM writes)', z, C1), ('A rows -> 1 row (no HBM reads)', z1, C),
+         ('both (instruction streams alone)', z1, C1), ('normal', z, C))
+if len(sys.argv) > 3 and sys.argv[3] == 'ab':          # A / B runs of library variants: the normal launch and the HBM-free one, more repeats
+    cases = (('normal', z, C), ('both (instruction streams alone)', z1, C1), ('normal', z, C), ('both (instruction streams alone)', z1, C1))
+for name, a, c in cases:
+    ms = timeit(lambda: ops.gemm(a, W, c, bias=bias, ln=(None, csum), B3=W3, exact=2, tune=TUNE), reps=21)
     print(f'{name:36s} Bc={Bc} N={N} K={K}: {ms:7.3f} ms', flush=True)
