@@ -1,5 +1,6 @@
 export TMPDIR=/tmp
 for r in 1 2; do
-ABX_HIP_LIB=$PWD/tools/probes/bin/libabx_base.so python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-op-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('base', d['result_digest'][:12], d['ms_per_step'], d['value'])"
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-op-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('new ', d['result_digest'][:12], d['ms_per_step'], d['value'])"
+python tools/probes/kb_store.py 20 768 ab 0 2>&1 | grep -v amdgpu.ids | awk -v v=head '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
+python tools/ab_lib.py tools/probes/bin/libabx_pers.so tools/probes/kb_store.py 20 768 ab 0 2>&1 | grep -v amdgpu.ids | awk -v v=pers_t0 '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
+python tools/ab_lib.py tools/probes/bin/libabx_pers.so tools/probes/kb_store.py 20 768 ab 256 2>&1 | grep -v amdgpu.ids | awk -v v=pers_t256 '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
 done
