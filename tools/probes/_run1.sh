@@ -1,6 +1,5 @@
 export TMPDIR=/tmp
 for r in 1 2; do
 python tools/probes/kb_store.py 20 768 ab 0 2>&1 | grep -v amdgpu.ids | awk -v v=head '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
-python tools/ab_lib.py tools/probes/bin/libabx_pers.so tools/probes/kb_store.py 20 768 ab 0 2>&1 | grep -v amdgpu.ids | awk -v v=pers_t0 '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
-python tools/ab_lib.py tools/probes/bin/libabx_pers.so tools/probes/kb_store.py 20 768 ab 256 2>&1 | grep -v amdgpu.ids | awk -v v=pers_t256 '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
+python tools/ab_lib.py tools/probes/bin/libabx_t96_5.so tools/probes/kb_store.py 20 768 ab 512 2>&1 | grep -v amdgpu.ids | awk -v v=t96_5 '{printf "%s %s %s | ", v, $1, $(NF-1)} END {print ""}'
 done
