@@ -128,6 +128,23 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     // ---- DMA sources: a block-uniform base pointer (advanced per k-tile) plus per-lane 32-bit byte offsets, so the loads
     // use the scalar-base addressing form and cost no vector address arithmetic in the loop
     unsigned offsA[NLA], offsB[NLB];
+    // The weight side first: its sources need two shifts, and with two stages its first k-tile is requested here, before the
+    // integer divisions of the A-row maps below - a block's first DMA round trip is exposed (nothing of this block can run
+    // before it lands), so it starts as early as the block knows where to read
+    const char* baseB = reinterpret_cast<const char*>(
+        g.B_split + ((g.batch_inner > 0 && g.A_split) ? (long long)(b / g.batch_inner) * g.sB3b + (long long)(b % g.batch_inner) * g.sB3i
+                                                      : (long long)b * g.sB3b));
+    plane_sources<BN, NLB>(g.sB3p, g.sB3n, n0, g.N, offsB);
+    const long long b_step = g.sB3k * 2;
+    const int nk = g.K / BK;
+    auto issue_b = [&](int tile) {
+        char* dst = Bs + (tile % RING) * B_STAGE + wave * NLB * 1024;
+        const char* src = baseB + tile * b_step;
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + vgpr32(offsB[i]), dst + i * 1024);
+    };
+    if constexpr (RING == 2) issue_b(0);
     const char* baseA = nullptr;
     long long a_step = 0;                                      // bytes per k-tile
     if constexpr (AMODE == 3) {
@@ -178,12 +195,6 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         plane_sources<BM, NLA>(g.sA3p, g.sA3m, m0, g.M, offsA);
         a_step = g.sA3k * 2;
     }
-    const char* baseB = reinterpret_cast<const char*>(
-        g.B_split + ((g.batch_inner > 0 && g.A_split) ? (long long)(b / g.batch_inner) * g.sB3b + (long long)(b % g.batch_inner) * g.sB3i
-                                                      : (long long)b * g.sB3b));
-    plane_sources<BN, NLB>(g.sB3p, g.sB3n, n0, g.N, offsB);
-    const long long b_step = g.sB3k * 2;
-    const int nk = g.K / BK;
 
     auto issue_a = [&](int tile) {          // tile index clamped by the caller
         if constexpr (AMODE == 3) return;
@@ -192,13 +203,6 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 #pragma unroll
         for (int i = 0; i < NLA; ++i)
             if (RING > 2 || A_IMG % 4096 == 0 || (wave * NLA + i) * 1024 < A_IMG) glds16(src + vgpr32(offsA[i]), dst + i * 1024);
-    };
-    auto issue_b = [&](int tile) {
-        char* dst = Bs + (tile % RING) * B_STAGE + wave * NLB * 1024;
-        const char* src = baseB + tile * b_step;
-#pragma unroll
-        for (int i = 0; i < NLB; ++i)
-            if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + vgpr32(offsB[i]), dst + i * 1024);
     };
 
 #pragma unroll
@@ -224,7 +228,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
 #pragma unroll
     for (int r = 0; r < RING - 1; ++r) {
         issue_a(min(r, nk - 1));
-        issue_b(min(r, nk - 1));
+        if constexpr (RING != 2) issue_b(min(r, nk - 1));
     }
     wait_vm_and_barrier<INFLIGHT>();
 
@@ -460,14 +464,15 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
         return;
     }
 #endif
-    long long wgid = blockIdx.x;
+    // (32-bit: the dispatch keeps the grid below 2^31 tiles; a 64-bit division is ~80 instructions in front of the block's first DMA)
+    unsigned wgid = blockIdx.x;
     if (!(g.tune & 1)) {
-        const long long nwg = gridDim.x, bid = blockIdx.x;
-        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+        const unsigned nwg = gridDim.x, bid = blockIdx.x;
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int b = (int)(wgid / per_batch);
-    const int rem = (int)(wgid - (long long)b * per_batch);
+    const int b = (int)(wgid / (unsigned)per_batch);
+    const int rem = (int)(wgid - (unsigned)b * (unsigned)per_batch);
     const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     if (interior) gemm3_block<BM, BN, WM, WN, AMODE, false, TS, false, PROBE, RING>(g, smem, mt, nt, b);
@@ -483,10 +488,10 @@ __global__ __launch_bounds__(256, MINW) void gemm3_oln_kernel(const AbxGemm g) {
     constexpr int EPI = 2 * BM + 4 * 32 * (TGW * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntm = (g.M + BM - 1) / BM;
-    const long long nwg = gridDim.x, bid = blockIdx.x;
-    const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    const long long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int b = (int)(wgid / ntm), mt = (int)(wgid - (long long)b * ntm);
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
     const bool interior = (mt + 1) * BM <= g.M && BN <= g.N;
     if (interior) gemm3_block<BM, BN, WM, WN, 0, false, false, true>(g, smem, mt, 0, b);
     else gemm3_block<BM, BN, WM, WN, 0, true, false, true>(g, smem, mt, 0, b);
@@ -500,12 +505,12 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
     constexpr int EPI = 4 * BM + 4 * 32 * (TGW * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
-    const long long nwg = gridDim.x, bid = blockIdx.x;
-    const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    const long long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int per_batch = ntn * ntm;
-    const int b = (int)(wgid / per_batch);
-    const int rem = (int)(wgid - (long long)b * per_batch);
+    const int b = (int)(wgid / (unsigned)per_batch);
+    const int rem = (int)(wgid - (unsigned)b * (unsigned)per_batch);
     const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
     if (interior) gemm3_dual_block<BM, BN, WM, WN, false>(g, smem, mt, nt, b);
@@ -654,10 +659,10 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
     constexpr int EPI = 2 * 128 + 4 * 32 * (3 * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntm = (g.M + 127) / 128;
-    const long long nwg = gridDim.x, bid = blockIdx.x;
-    const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    const long long wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int b = (int)(wgid / ntm), mt = (int)(wgid - (long long)b * ntm);
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
     const ClockProbe probe(g.clock_probe);
     if ((mt + 1) * 128 <= g.M && g.N2 == 192) gemm3_mlp_block<false>(g, smem, mt, b);
     else gemm3_mlp_block<true>(g, smem, mt, b);
