@@ -75,6 +75,32 @@ class AbxIpaTail(C.Structure):
     ]
 
 
+class AbxHeadsTail(C.Structure):
+    _fields_ = [
+        ('s', c_f), ('s_s', LL), ('s0', c_f), ('s_s0', LL), ('M', I),
+        ('W_act', C.c_void_p), ('e_act', I), ('b_act', c_f),
+        ('W_init', C.c_void_p), ('e_init', I), ('b_init', c_f),
+        ('W_r0', C.c_void_p), ('e_r0', I), ('b_r0', c_f),
+        ('W_r1', C.c_void_p), ('e_r1', I), ('b_r1', c_f),
+        ('W_r2', C.c_void_p), ('e_r2', I), ('b_r2', c_f),
+        ('W_r3', C.c_void_p), ('e_r3', I), ('b_r3', c_f),
+        ('W_proj', C.c_void_p), ('e_proj', I), ('b_proj', c_f),
+        ('un', c_f),
+        ('lns_w', c_f), ('lns_b', c_f),
+        ('W_s1', C.c_void_p), ('e_s1', I), ('b_s1', c_f),
+        ('W_s3', C.c_void_p), ('e_s3', I), ('b_s3', c_f),
+        ('W_s5', C.c_void_p), ('e_s5', I), ('b_s5', c_f),
+        ('logits', c_f),
+        ('lnp_w', c_f), ('lnp_b', c_f),
+        ('W_p1', C.c_void_p), ('e_p1', I), ('b_p1', c_f),
+        ('W_p3', C.c_void_p), ('e_p3', I), ('b_p3', c_f),
+        ('W_p5', C.c_void_p), ('e_p5', I), ('b_p5', c_f),
+        ('pl', c_f),
+        ('ln_eps', F),
+        ('range_flag', c_f), ('range_tag', I),
+    ]
+
+
 class AbxTriAttn(C.Structure):
     _fields_ = [
         ('q', c_f), ('k', c_f), ('v', c_f), ('gate', c_f),
@@ -161,6 +187,7 @@ _PROTOS = {
     'abx_gemm_check_modes': (I, [C.POINTER(AbxGemm)]),
     'abx_split_weights_f16': (I, [c_f, LL, LL, I, I, I, C.c_void_p, _S]),
     'abx_ipa_tail': (I, [C.POINTER(AbxIpaTail), _S]),
+    'abx_heads_tail': (I, [C.POINTER(AbxHeadsTail), _S]),
     'abx_gemm3_occupancy': (I, [I]),
     'abx_row_stats': (I, [c_f, LL, LL, LL, I, I, I, F, c_f, _S]),
     'abx_layernorm': (I, [c_f, LL, LL, I, c_f, c_f, F, c_f, LL, c_f, LL, _S]),

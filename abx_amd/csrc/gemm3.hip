@@ -824,6 +824,156 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
     }
 }
 
+// ---- Per-residue heads on the final single representation in ONE kernel: the torsion ResNet (sidechain.py:28-62), the SequenceHead MLP
+// and - on the last pass - the PredictedLDDTHead MLP (head.py:143-226).  Thirteen (eighteen) launches of 352 ... 35 200-row GEMMs and
+// LayerNorms otherwise, each a latency chain of its own at small batches.
+//     t  = relu(s) W_act + b + relu(s0) W_init + b;   t += relu(relu(t) W_r0 + b) W_r1 + b;   t += relu(relu(t) W_r2 + b) W_r3 + b
+//     un = relu(t) W_proj + b                                            (14 columns: the unnormalised torsion sin / cos)
+//     logits = relu(relu(LN_s(s) W_s1 + b) W_s3 + b) W_s5 + b            (20 columns);  pLDDT logits likewise (50 columns)
+// A block owns 32 rows; 4 waves x (32 rows x 32 of the 128 hidden columns), swapped MFMA operands (lane = row), activations in LDS
+// between the GEMMs (AMODE 3 main loops as in ipa_tail_kernel), only the weight planes stream.  The 14 / 20 / 50-column projections
+// run as 128-column GEMMs on zero-padded planes (negligible work; one code path).  Split-f16 arithmetic throughout.
+constexpr int HT_C = 256, HT_H = 128;
+constexpr int HT_ASTR = HT_C * 4 + 16, HT_HSTR = HT_H * 4 + 16;             // bytes per activation row in LDS
+constexpr int HT_RING = 4;
+constexpr int HT_OPER = HT_RING * (2 * HT_H * 32);                           // 4 weight stages of 8 KB
+constexpr int HT_LDS = HT_OPER + 2 * 32 * HT_ASTR + 2 * 32 * HT_HSTR;
+
+__global__ __launch_bounds__(256, 1) void heads_tail_kernel(const AbxHeadsTail a) {
+    constexpr int BM = 32, BN = HT_H, WM = 32, WN = 32;
+    extern __shared__ __attribute__((aligned(16))) float ht_smem[];
+    char* lds = reinterpret_cast<char*>(ht_smem);
+    char* S = lds + HT_OPER;
+    char* S0 = S + 32 * HT_ASTR;                                            // s0, later LN(s)
+    char* T1 = S0 + 32 * HT_ASTR;
+    char* T2 = T1 + 32 * HT_HSTR;
+    const int mt = blockIdx.x, m0 = mt * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, row = lane & 31;
+    const int colb = wave * WN + 4 * h;               // column of accumulator register r (swapped operands): colb + 8 (r >> 2) + (r & 3)
+    const bool row_ok = m0 + row < a.M;
+
+    for (int idx = threadIdx.x; idx < 32 * (HT_C / 4); idx += 256) {
+        const int r = idx / (HT_C / 4), c4 = idx % (HT_C / 4);
+        const long long gr = min(m0 + r, a.M - 1);
+        *reinterpret_cast<f32x4*>(S + r * HT_ASTR + c4 * 16) = *reinterpret_cast<const f32x4*>(a.s + gr * a.s_s + c4 * 4);
+        *reinterpret_cast<f32x4*>(S0 + r * HT_ASTR + c4 * 16) = *reinterpret_cast<const f32x4*>(a.s0 + gr * a.s_s0 + c4 * 4);
+    }
+    __syncthreads();
+
+    AbxGemm g = {};
+    g.M = a.M; g.N = HT_H; g.batch = 1; g.b_f16 = 1;
+    g.sB3k = 2 * HT_H * 16; g.sB3p = HT_H * 16; g.sB3n = 16;
+    f32x16 acc[1][1];
+    float ls[1], lq[1], lsh[1];
+    float x[16], y[16];
+    bool bad = false;
+
+    auto run = [&](const unsigned short* W, int e, int K, const char* abuf, int astr, int a_relu) {
+        g.K = K; g.B_split = W; g.b_exp = e; g.a_relu = a_relu;
+        gemm3_mainloop<BM, BN, WM, WN, 3, true, false, HT_RING>(g, ht_smem, mt, 0, 0, acc, ls, lq, lsh, abuf, astr);
+    };
+    // v = acc + bias (relu: after the Linear); into `dst` (add: on top of what it holds)
+    auto bias_to = [&](const float* bias, bool relu, bool add, float (&dst)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + colb + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[0][0][4 * q + e] + bi[e];
+                if (relu) v = relu_keep_nan(v);
+                dst[4 * q + e] = add ? dst[4 * q + e] + v : v;
+            }
+        }
+    };
+    auto to_lds = [&](char* buf, int stride, const float (&src)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(buf + row * stride + (colb + 8 * q) * 4) = (f32x4){src[4 * q], src[4 * q + 1], src[4 * q + 2], src[4 * q + 3]};
+    };
+    auto store_cols = [&](float* out, int ncol, const float (&src)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = colb + 8 * q + e;
+                if (c < ncol) {
+                    bad |= !(fabsf(src[4 * q + e]) <= 3.0e38f);
+                    if (row_ok) out[(long long)(m0 + row) * ncol + c] = src[4 * q + e];
+                }
+            }
+    };
+    // LayerNorm of the block's rows of s -> S0 (two passes like torch): 8 threads per row, 32 channels each
+    auto layer_norm_s = [&](const float* gamma, const float* beta) {
+        const int r = threadIdx.x >> 3, p = threadIdx.x & 7;
+        const float* src = reinterpret_cast<const float*>(S + r * HT_ASTR) + p * 32;
+        float* dst = reinterpret_cast<float*>(S0 + r * HT_ASTR) + p * 32;
+        float v[32], sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { v[c] = src[c]; sm += v[c]; }
+        sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+        const float mean = sm * (1.0f / HT_C);
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { v[c] -= mean; sq = fmaf(v[c], v[c], sq); }
+        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / HT_C) + a.ln_eps);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dst[c] = v[c] * rstd * gamma[p * 32 + c] + beta[p * 32 + c];
+    };
+    // LayerNorm -> Linear -> ReLU -> Linear -> ReLU -> Linear of one head (S0 holds LN(s) on entry)
+    auto head = [&](const unsigned short* W1, int e1, const float* b1, const unsigned short* W3, int e3, const float* b3,
+                    const unsigned short* W5, int e5, const float* b5, float* out, int ncol) {
+        run(W1, e1, HT_C, S0, HT_ASTR, 0);
+        bias_to(b1, true, false, y);
+        to_lds(T1, HT_HSTR, y);
+        __syncthreads();
+        run(W3, e3, HT_H, T1, HT_HSTR, 0);
+        bias_to(b3, true, false, y);
+        to_lds(T2, HT_HSTR, y);
+        __syncthreads();
+        run(W5, e5, HT_H, T2, HT_HSTR, 0);
+        bias_to(b5, false, false, y);
+        store_cols(out, ncol, y);
+    };
+
+    // ---- torsion module
+    run(a.W_act, a.e_act, HT_C, S, HT_ASTR, 1);
+    bias_to(a.b_act, false, false, x);
+    run(a.W_init, a.e_init, HT_C, S0, HT_ASTR, 1);
+    bias_to(a.b_init, false, true, x);
+    to_lds(T1, HT_HSTR, x);
+    __syncthreads();
+    {
+        const unsigned short* Wr[4] = {a.W_r0, a.W_r1, a.W_r2, a.W_r3};
+        const int er[4] = {a.e_r0, a.e_r1, a.e_r2, a.e_r3};
+        const float* br[4] = {a.b_r0, a.b_r1, a.b_r2, a.b_r3};
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            run(Wr[2 * blk], er[2 * blk], HT_H, T1, HT_HSTR, 1);
+            bias_to(br[2 * blk], false, false, y);
+            to_lds(T2, HT_HSTR, y);
+            __syncthreads();
+            run(Wr[2 * blk + 1], er[2 * blk + 1], HT_H, T2, HT_HSTR, 1);
+            bias_to(br[2 * blk + 1], false, true, x);
+            to_lds(T1, HT_HSTR, x);
+            __syncthreads();
+        }
+    }
+    run(a.W_proj, a.e_proj, HT_H, T1, HT_HSTR, 1);
+    bias_to(a.b_proj, false, false, y);
+    store_cols(a.un, 14, y);
+    // ---- sequence head, pLDDT head
+    layer_norm_s(a.lns_w, a.lns_b);
+    __syncthreads();
+    head(a.W_s1, a.e_s1, a.b_s1, a.W_s3, a.e_s3, a.b_s3, a.W_s5, a.e_s5, a.b_s5, a.logits, 20);
+    if (a.W_p1) {
+        layer_norm_s(a.lnp_w, a.lnp_b);          // (every read of S0 by the sequence head ended with its first main loop's barrier)
+        __syncthreads();
+        head(a.W_p1, a.e_p1, a.b_p1, a.W_p3, a.e_p3, a.b_p3, a.W_p5, a.e_p5, a.b_p5, a.pl, 50);
+    }
+    if (a.range_flag && __any(bad) && lane == 0) atomicOr(a.range_flag, a.range_tag);
+}
+
 template <int BM, int BN, int WM, int WN, int MINW>
 int launch3(const AbxGemm& g, hipStream_t st) {
     const long long mt = ((long long)g.M + BM - 1) / BM, ntn = ((long long)g.N + BN - 1) / BN;
@@ -1003,4 +1153,28 @@ extern "C" int abx_ipa_tail(const AbxIpaTail* ap, hipStream_t st) {
     if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&ipa_tail_kernel), IT_LDS, "abx_ipa_tail")) return rc;
     hipLaunchKernelGGL(ipa_tail_kernel, dim3((unsigned)((a.M + 31) / 32)), dim3(256), IT_LDS, st, a);
     return abx_check_launch("abx_ipa_tail");
+}
+
+extern "C" int abx_heads_tail(const AbxHeadsTail* ap, hipStream_t st) {
+    ABX_REQUIRE(ap != nullptr, "abx_heads_tail: null descriptor");
+    const AbxHeadsTail a = *ap;
+    auto al16 = [](const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    ABX_REQUIRE(a.M > 0 && al16(a.s) && al16(a.s0) && a.s_s % 4 == 0 && a.s_s0 % 4 == 0 && a.s_s >= HT_C && a.s_s0 >= HT_C,
+                "abx_heads_tail: s / s0 are (M, 256) fp32 rows, 16-byte aligned");
+    ABX_REQUIRE(a.un && a.logits, "abx_heads_tail: un (M, 14) and logits (M, 20) outputs");
+    const unsigned short* Ws[] = {a.W_act, a.W_init, a.W_r0, a.W_r1, a.W_r2, a.W_r3, a.W_proj, a.W_s1, a.W_s3, a.W_s5};
+    const float* bs[] = {a.b_act, a.b_init, a.b_r0, a.b_r1, a.b_r2, a.b_r3, a.b_proj, a.b_s1, a.b_s3, a.b_s5};
+    for (int i = 0; i < 10; ++i)
+        ABX_REQUIRE(al16(Ws[i]) && al16(bs[i]), "abx_heads_tail: weight planes (abx_split_weights_f16, 128 columns) and [128] biases, 16-byte aligned");
+    for (int e : {a.e_act, a.e_init, a.e_r0, a.e_r1, a.e_r2, a.e_r3, a.e_proj, a.e_s1, a.e_s3, a.e_s5})
+        ABX_REQUIRE(e >= -100 && e <= 100, "abx_heads_tail: weight exponent out of range");
+    ABX_REQUIRE(al16(a.lns_w) && al16(a.lns_b), "abx_heads_tail: LayerNorm parameters of the sequence head ([256])");
+    if (a.W_p1) {
+        ABX_REQUIRE(al16(a.W_p1) && al16(a.W_p3) && al16(a.W_p5) && al16(a.b_p1) && al16(a.b_p3) && al16(a.b_p5) && al16(a.lnp_w) && al16(a.lnp_b) && a.pl,
+                    "abx_heads_tail: the pLDDT head needs all of its operands");
+        for (int e : {a.e_p1, a.e_p3, a.e_p5}) ABX_REQUIRE(e >= -100 && e <= 100, "abx_heads_tail: weight exponent out of range");
+    }
+    if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&heads_tail_kernel), HT_LDS, "abx_heads_tail")) return rc;
+    hipLaunchKernelGGL(heads_tail_kernel, dim3((unsigned)((a.M + 31) / 32)), dim3(256), HT_LDS, st, a);
+    return abx_check_launch("abx_heads_tail");
 }

@@ -163,6 +163,30 @@ class Packed:
                 self._split_cache[pre + 'attn.proj_out'] = out.planes
         return self._blocks
 
+    def heads_pack(self):
+        """Operands of ops.heads_tail (torsion ResNet + SequenceHead + PredictedLDDTHead in one launch), or None when the checkpoint's
+        widths are not the 256 -> 128 ones the kernel is built for; built once."""
+        if not hasattr(self, '_heads'):
+            self._heads = None
+            pre = P_IPA + 'sidechain_module.torsion_module.'
+            names = [pre + 'proj_act.1', pre + 'proj_init_act.1', pre + 'blocks.0.net.1', pre + 'blocks.0.net.3', pre + 'blocks.1.net.1',
+                     pre + 'blocks.1.net.3', pre + 'projection']
+            shapes = [(256, 128), (256, 128), (128, 128), (128, 128), (128, 128), (128, 128), (128, 14)]
+            heads = (('impl.sequence_module.net.', 20), ('impl.predicted_lddt.net.', 50))
+            ok = all(n in self.wt and tuple(self.wt[n].shape) == sh for n, sh in zip(names, shapes)) and (pre + 'blocks.2.net.1') not in self.wt
+            for hp, nout in heads:
+                ok = ok and all((hp + i) in self.wt for i in '135') and tuple(self.wt[hp + '1'].shape) == (256, 128) and \
+                    tuple(self.wt[hp + '3'].shape) == (128, 128) and tuple(self.wt[hp + '5'].shape) == (128, nout)
+            if ok and self.wt[names[0]].is_cuda:
+                zb = lambda n: self.b[n] if self.b.get(n) is not None else torch.zeros(128, device=self.wt[n].device)
+                full = lambda n: (ops.split_weights(self.wt[n]), zb(n))
+                tors = [full(n) for n in names[:-1]] + [ops.pad_planes_128(self.wt[names[-1]], self.b.get(names[-1]))]
+                hd = []
+                for hp, _ in heads:
+                    hd.append((self.ln(hp + '0'), full(hp + '1'), full(hp + '3'), ops.pad_planes_128(self.wt[hp + '5'], self.b.get(hp + '5'))))
+                self._heads = (tors, hd[0], hd[1])
+        return self._heads
+
     def split_narrow(self, wt, key):
         """float16 weight planes of a skinny (N <= 32) weight matrix: the pair-stack bias projections stream their 9.5 GB A operand
         through the 128 x 32 tile of the split-f16 GEMM (DMA pipeline) instead of the exact kernel's register-staged loads."""
@@ -222,6 +246,8 @@ class Engine:
         # exact-arithmetic tri-mul)
         self.block_api = not bool(__import__('os').environ.get('ABX_NO_BLOCK_API'))
         self._blk_ws = {}
+        # True: torsion ResNet + sequence / pLDDT head MLPs of a pass in one launch (abx_heads_tail) instead of 13 - 18 small ones
+        self.fused_heads = not bool(__import__('os').environ.get('ABX_NO_FUSED_HEADS'))
         c = cfg_model.embeddings_and_seqformer
         pp = c.prev_pos
         # squared distogram breaks exactly as torch computes them on the host (common_modules.py:108-109)
@@ -540,13 +566,21 @@ class Engine:
         # torsions (sidechain.py:28-72)
         pre = P_IPA + 'sidechain_module.torsion_module.'
         ta = ws.get('t_a', (M1, 128)); tb = ws.get('t_b', (M1, 128))
-        _lin(P, pre + 'proj_act.1', s, ta, a_relu=True)
-        _lin(P, pre + 'proj_init_act.1', s0, ta, a_relu=True, resid=ta)
-        for blk in range(ic.torsion.num_residual_block):
-            _lin(P, pre + f'blocks.{blk}.net.1', ta, tb, a_relu=True)
-            _lin(P, pre + f'blocks.{blk}.net.3', tb, ta, a_relu=True, resid=ta)
         un = ws.get('t_un', (M1, 14))
-        _lin(P, pre + 'projection', ta, un, a_relu=True)
+        logits = st['logits'][b0:b1]
+        pl = ws.get('h_pl', (M1, 50))
+        # torsion ResNet + SequenceHead MLP (+ PredictedLDDTHead MLP on the last pass) in ONE launch: 13 (18) launches otherwise
+        heads = P.heads_pack() if (self.fused_heads and P.gemm_mode == 2 and NC == 256 and ic.torsion.num_residual_block == 2 and
+                                   logits.is_contiguous()) else None
+        if heads is not None:
+            ops.heads_tail(s, s0, heads[0], heads[1], heads[2], un, logits.view(M1, 20), pl if final else None)
+        else:
+            _lin(P, pre + 'proj_act.1', s, ta, a_relu=True)
+            _lin(P, pre + 'proj_init_act.1', s0, ta, a_relu=True, resid=ta)
+            for blk in range(ic.torsion.num_residual_block):
+                _lin(P, pre + f'blocks.{blk}.net.1', ta, tb, a_relu=True)
+                _lin(P, pre + f'blocks.{blk}.net.3', tb, ta, a_relu=True, resid=ta)
+            _lin(P, pre + 'projection', ta, un, a_relu=True)
         angles = st['angles'][b0:b1]
         ops.torsion_finalize(un, st['torsion_gt'][b0:b1].contiguous(), fixed.reshape(-1), angles, M1)
         sm = st['structure_module'][b0:b1]
@@ -563,21 +597,21 @@ class Engine:
         # ---------------- sequence head (head.py:162-201)
         pre = 'impl.sequence_module.net.'
         hx = ws.get('h_x', (M1, NC))
-        ops.layernorm(s, *P.ln(pre + '0'), out=hx)
-        _lin(P, pre + '1', hx, ta, act=1)
-        _lin(P, pre + '3', ta, tb, act=1)
-        logits = st['logits'][b0:b1]
-        _lin(P, pre + '5', tb, logits.view(M1, 20))
+        if heads is None:
+            ops.layernorm(s, *P.ln(pre + '0'), out=hx)
+            _lin(P, pre + '1', hx, ta, act=1)
+            _lin(P, pre + '3', ta, tb, act=1)
+            _lin(P, pre + '5', tb, logits.view(M1, 20))
         ops.seq_head_atoms(logits, fixed.reshape(-1), seq_t.contiguous(), st['rigids'][b0:b1], angles,
                            st['a37to14'][b0:b1].contiguous(), P.default_frames, P.group_idx, P.lit_pos,
                            st['seq_0'][b0:b1], st['atom14'][b0:b1], st['atom37'][b0:b1], M1)
         if final:
-            pre = 'impl.predicted_lddt.net.'
-            ops.layernorm(s, *P.ln(pre + '0'), out=hx)
-            _lin(P, pre + '1', hx, ta, act=1)
-            _lin(P, pre + '3', ta, tb, act=1)
-            pl = ws.get('h_pl', (M1, 50))
-            _lin(P, pre + '5', tb, pl)
+            if heads is None:
+                pre = 'impl.predicted_lddt.net.'
+                ops.layernorm(s, *P.ln(pre + '0'), out=hx)
+                _lin(P, pre + '1', hx, ta, act=1)
+                _lin(P, pre + '3', ta, tb, act=1)
+                _lin(P, pre + '5', tb, pl)
             ops.plddt(pl, st['pLDDT'][b0:b1], M1, 50)
         # ---------------- self-conditioning distogram for the next call (abx.py:17-26)
         ops.prev_pos(st['atom37'][b0:b1], self.sq_breaks, st['prev_pos_out'][b0:b1], Bc, L)

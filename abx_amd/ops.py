@@ -6,7 +6,7 @@ import math
 import torch
 
 from abx_amd import _lib
-from abx_amd._lib import (AbxGemm, AbxTriAttn, AbxIpaTail, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, AbxLinearPack, AbxLinearSrc,
+from abx_amd._lib import (AbxGemm, AbxTriAttn, AbxIpaTail, AbxHeadsTail, AbxScoreArgs, AbxReverseArgs, AbxGuidanceArgs, AbxLinearPack, AbxLinearSrc,
                            AbxTriMulPack, AbxTriAttnPack, check)
 
 
@@ -34,7 +34,7 @@ GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 # abx_amd.model.abx.ScoreNetwork clears the word before a network call, reads it after, and repeats the call on the exact fp32-MFMA
 # kernels when it is set, so the range contract of the fast path never reaches a caller as a wrong or non-finite result.
 RANGE_TAGS = {'gemm': 1, 'contraction': 2, 'plane_projection': 4, 'tri_mul_tail': 8, 'pair_transition': 16, 'ipa_pair_init': 32,
-              'tri_attn': 64, 'ipa_tail': 128}
+              'tri_attn': 64, 'ipa_tail': 128, 'heads_tail': 256}
 RANGE_CHECK = not bool(__import__('os').environ.get('ABX_NO_RANGE_CHECK'))     # (A / B measurements of the probe's cost)
 _range_words = {}
 
@@ -591,6 +591,55 @@ def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5, affine=None
         a.range_flag, a.range_tag = range_word(s.device).data_ptr(), RANGE_TAGS['ipa_tail']
     check(_lib.load().abx_ipa_tail(C.byref(a), _stream()), 'abx_ipa_tail')
     return s
+
+
+def pad_planes_128(wt, bias):
+    """(WeightPlanes, bias[128]) of a (K, n <= 128) weight zero-padded to 128 columns: the narrow last projections of abx_heads_tail."""
+    K, n = wt.shape
+    w = torch.zeros(K, 128, device=wt.device, dtype=torch.float32)
+    w[:, :n] = wt
+    b = torch.zeros(128, device=wt.device, dtype=torch.float32)
+    if bias is not None:
+        b[:n] = bias
+    return split_weights(w), b
+
+
+def heads_tail(s, s0, torsion, seq_head, plddt_head, un, logits, pl=None, eps=1e-5):
+    """The per-residue heads in one launch (csrc/gemm3.hip heads_tail_kernel; reference sidechain.py:28-62, head.py:143-226).
+    s, s0 (M, 256) fp32 rows; torsion = 7 x (WeightPlanes (K, 128), bias [128]): proj_act, proj_init_act, the four ResNet linears, the
+    projection padded to 128 columns (pad_planes_128); seq_head / plddt_head = ((gamma, beta), (planes, bias) x 3), last one padded;
+    un (M, 14), logits (M, 20), pl (M, 50) contiguous outputs (pl None: the pLDDT head is skipped)."""
+    M = s.shape[0]
+    assert s.shape == (M, 256) and s0.shape == (M, 256) and s.stride(1) == 1 and s0.stride(1) == 1
+    assert un.shape == (M, 14) and un.is_contiguous() and logits.shape == (M, 20) and logits.is_contiguous()
+    a = AbxHeadsTail()
+    a.s, a.s_s, a.s0, a.s_s0, a.M = _p(_f32(s)), s.stride(0), _p(_f32(s0)), s0.stride(0), M
+    keep = []
+
+    def put(tag, wb, K):
+        w3, bias = wb
+        _weight_planes(w3, 128, K, what='heads_tail ' + tag)
+        assert w3.shape[0] * 16 == K and bias.numel() == 128
+        setattr(a, 'W_' + tag, _p(w3)); setattr(a, 'e_' + tag, w3.w_exp); setattr(a, 'b_' + tag, _p(_f32(bias)))
+        keep.append((w3, bias))
+    for tag, wb, K in zip(('act', 'init', 'r0', 'r1', 'r2', 'r3', 'proj'), torsion, (256, 256, 128, 128, 128, 128, 128)):
+        put(tag, wb, K)
+    (g_s, b_s), *lin_s = seq_head
+    a.lns_w, a.lns_b = _p(_f32(g_s)), _p(_f32(b_s))
+    for tag, wb, K in zip(('s1', 's3', 's5'), lin_s, (256, 128, 128)):
+        put(tag, wb, K)
+    a.un, a.logits = _p(_f32(un)), _p(_f32(logits))
+    if pl is not None:
+        assert pl.shape == (M, 50) and pl.is_contiguous()
+        (g_p, b_p), *lin_p = plddt_head
+        a.lnp_w, a.lnp_b = _p(_f32(g_p)), _p(_f32(b_p))
+        for tag, wb, K in zip(('p1', 'p3', 'p5'), lin_p, (256, 128, 128)):
+            put(tag, wb, K)
+        a.pl = _p(_f32(pl))
+    a.ln_eps = float(eps)
+    if RANGE_CHECK:
+        a.range_flag, a.range_tag = range_word(s.device).data_ptr(), RANGE_TAGS['heads_tail']
+    check(_lib.load().abx_heads_tail(C.byref(a), _stream()), 'abx_heads_tail')
 
 
 def ipa_qpack_numel(B, L):

@@ -201,6 +201,38 @@ typedef struct AbxIpaTail {
     int* range_flag; int range_tag;                /* see AbxGemm.range_flag: set when the layer's output rows are not finite */
 } AbxIpaTail;
 int abx_ipa_tail(const AbxIpaTail* desc, hipStream_t stream);
+/* The per-residue heads on the final single representation in ONE launch (split-f16 arithmetic of AbxGemm, activations resident on the
+ * CU): TorsionModule (abx/model/sidechain.py:28-62: proj_act + proj_init_act, two ResNet blocks, projection -> 14 unnormalised
+ * sin / cos), SequenceHead.net (abx/model/head.py:143-163: LayerNorm, 256 -> 128 -> 128 -> 20) and, when W_p1 != NULL,
+ * PredictedLDDTHead.net (head.py:206-226: LayerNorm, 256 -> 128 -> 128 -> 50).  Weights as abx_split_weights_f16 planes
+ * [K/16][2][128][16] of the (K, 128) transposed weight with their exponents; the 14 / 20 / 50-column projections ZERO-PADDED to 128
+ * columns (planes and [128] biases).  Thirteen (eighteen) abx_gemm / abx_layernorm calls otherwise. */
+typedef struct AbxHeadsTail {
+    const float* s; long long s_s;                 /* (M, 256) structure-module output, row stride in floats */
+    const float* s0; long long s_s0;               /* (M, 256) initial single representation (init_seq_layer_norm output) */
+    int M;
+    const unsigned short* W_act; int e_act; const float* b_act;        /* torsion_module.proj_act.1       256 -> 128 */
+    const unsigned short* W_init; int e_init; const float* b_init;     /* torsion_module.proj_init_act.1  256 -> 128 */
+    const unsigned short* W_r0; int e_r0; const float* b_r0;           /* blocks.0.net.1 */
+    const unsigned short* W_r1; int e_r1; const float* b_r1;           /* blocks.0.net.3 */
+    const unsigned short* W_r2; int e_r2; const float* b_r2;           /* blocks.1.net.1 */
+    const unsigned short* W_r3; int e_r3; const float* b_r3;           /* blocks.1.net.3 */
+    const unsigned short* W_proj; int e_proj; const float* b_proj;     /* projection 128 -> 14 (padded) */
+    float* un;                                                         /* (M, 14) out */
+    const float* lns_w; const float* lns_b;                            /* sequence_module.net.0 (LayerNorm [256]) */
+    const unsigned short* W_s1; int e_s1; const float* b_s1;           /* net.1 256 -> 128 */
+    const unsigned short* W_s3; int e_s3; const float* b_s3;           /* net.3 128 -> 128 */
+    const unsigned short* W_s5; int e_s5; const float* b_s5;           /* net.5 128 -> 20 (padded) */
+    float* logits;                                                     /* (M, 20) out */
+    const float* lnp_w; const float* lnp_b;                            /* predicted_lddt.net.0; the head is optional (W_p1 == NULL: skipped) */
+    const unsigned short* W_p1; int e_p1; const float* b_p1;
+    const unsigned short* W_p3; int e_p3; const float* b_p3;
+    const unsigned short* W_p5; int e_p5; const float* b_p5;           /* 128 -> 50 (padded) */
+    float* pl;                                                         /* (M, 50) out */
+    float ln_eps;
+    int* range_flag; int range_tag;                /* see AbxGemm.range_flag: set when an output value is not finite */
+} AbxHeadsTail;
+int abx_heads_tail(const AbxHeadsTail* desc, hipStream_t stream);
 /* diagnostics: resident workgroups per CU of the main split-f16 GEMM instantiations (0: 128x192, 1: 128x128,
  * 2: 128x128 transposed store, 3: 128x192 plane operands); negative on error */
 int abx_gemm3_occupancy(int which);

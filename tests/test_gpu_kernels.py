@@ -739,6 +739,55 @@ def test_ipa_tail(ops, M):
         assert float((x1 - x2).abs().max()) < 1e-5, nm
 
 
+@pytest.mark.parametrize('M,with_plddt', [(352, True), (4224 + 5, False), (31, True)])
+def test_heads_tail(ops, M, with_plddt):
+    """abx_heads_tail: TorsionModule (sidechain.py:28-62), SequenceHead.net and PredictedLDDTHead.net (head.py:143-226) in one launch
+    against float64; ragged last row block, with and without the pLDDT head, untouched pLDDT output when it is skipped."""
+    gen = lambda i: g(700 + i)
+    W = lambda i, K, N: torch.randn(K, N, generator=gen(i)) / K ** 0.5
+    bv = lambda i, N: torch.randn(N, generator=gen(i)) * 0.3
+    d = lambda t: t.to(DEV).contiguous()
+    s, s0 = torch.randn(M, 256, generator=gen(0)) * 1.5, torch.randn(M, 256, generator=gen(1)) + 0.3
+    tw = [(W(2, 256, 128), bv(3, 128)), (W(4, 256, 128), bv(5, 128))] + [(W(6 + 2 * i, 128, 128), bv(7 + 2 * i, 128)) for i in range(4)] + \
+         [(W(14, 128, 14), bv(15, 14))]
+    heads = []
+    for k, n in ((0, 20), (1, 50)):
+        ln = (1 + 0.2 * torch.randn(256, generator=gen(20 + 10 * k)), 0.2 * torch.randn(256, generator=gen(21 + 10 * k)))
+        heads.append((ln, (W(22 + 10 * k, 256, 128), bv(23 + 10 * k, 128)), (W(24 + 10 * k, 128, 128), bv(25 + 10 * k, 128)),
+                      (W(26 + 10 * k, 128, n), bv(27 + 10 * k, n))))
+    D = lambda t: t.double()
+    relu = torch.relu
+    t = relu(D(s)) @ D(tw[0][0]) + D(tw[0][1]) + relu(D(s0)) @ D(tw[1][0]) + D(tw[1][1])
+    for blk in range(2):
+        t = t + relu(relu(t) @ D(tw[2 + 2 * blk][0]) + D(tw[2 + 2 * blk][1])) @ D(tw[3 + 2 * blk][0]) + D(tw[3 + 2 * blk][1])
+    ref_un = relu(t) @ D(tw[6][0]) + D(tw[6][1])
+    refs = []
+    for ln, l1, l3, l5 in heads:
+        hx = torch.nn.functional.layer_norm(D(s), (256,), D(ln[0]), D(ln[1]), 1e-5)
+        refs.append(relu(relu(hx @ D(l1[0]) + D(l1[1])) @ D(l3[0]) + D(l3[1])) @ D(l5[0]) + D(l5[1]))
+    full = lambda wb: (ops.split_weights(d(wb[0])), d(wb[1]))
+    tors = [full(wb) for wb in tw[:-1]] + [ops.pad_planes_128(d(tw[-1][0]), d(tw[-1][1]))]
+    hd = [((d(ln[0]), d(ln[1])), full(l1), full(l3), ops.pad_planes_128(d(l5[0]), d(l5[1]))) for ln, l1, l3, l5 in heads]
+    un = torch.full((M, 14), float('nan'), device=DEV)
+    logits = torch.full((M, 20), float('nan'), device=DEV)
+    pl = torch.full((M, 50), 7.0, device=DEV)
+    ops.heads_tail(d(s), d(s0), tors, hd[0], hd[1], un, logits, pl if with_plddt else None)
+    check(un, ref_un, 5e-6, f'heads_tail torsions M={M}')
+    check(logits, refs[0], 5e-6, f'heads_tail logits M={M}')
+    if with_plddt:
+        check(pl, refs[1], 5e-6, f'heads_tail pLDDT logits M={M}')
+    else:
+        assert bool((pl == 7.0).all())
+    # the range word: a non-finite input row reaches the outputs and sets the kernel's bit
+    if M == 352:
+        word = ops.range_word(DEV); word.zero_()
+        sb = d(s); sb[5, 17] = float('inf')
+        ops.heads_tail(sb, d(s0), tors, hd[0], hd[1], un, logits, None)
+        torch.cuda.synchronize()
+        assert int(word.item()) & ops.RANGE_TAGS['heads_tail']
+        word.zero_()
+
+
 @pytest.mark.parametrize('L', [52, 131, 230, 402, 600])
 def test_seq_attn(ops, L):
     """L = 52: one key per lane slot, partial; 131: three key slots (4-slot instantiation), one query block; 230: two query

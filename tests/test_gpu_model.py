@@ -1266,6 +1266,36 @@ def test_design_driver_optimize_mode_with_guidance(tmp_path):
     assert moved > 1e-4, 'the guidance terms left the trajectory unchanged'
 
 
+def test_fused_heads_equal_the_separate_launches(gpu_model, cfg):
+    """the torsion ResNet, the SequenceHead MLP and the PredictedLDDTHead MLP of a pass in one launch (abx_heads_tail,
+    Engine.fused_heads, the default on the split-f16 path) against the 13 - 18 launches it replaces: same tokens, torsion angles,
+    logits, pLDDT and frames within fp32 rounding of the different accumulation orders (the narrow last projections move from the exact
+    fp32 kernel to split-f16).  L = 120: the split-f16 path (gemm_mode 2)."""
+    from abx_amd import sampler
+    model, D = gpu_model
+    w, B = dict(L_heavy=50, L_light=44, L_antigen=26, cdr=(30, 39)), 3
+    b = _synthetic_batch(D, w, B=B, n_masked_tail=2)
+    t_ = torch.full((B,), 0.4040404040404041, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+    eng = model._get_engine(torch.device(DEV))
+    assert eng.P.heads_pack() is not None
+    outs = []
+    for fused in (True, False):
+        eng.fused_heads = fused
+        try:
+            r = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}, compute_loss=True)
+            f = r['heads']['folding']
+            outs.append({'logits': r['heads']['sequence_module']['logits'].clone(), 'seq_0': r['heads']['sequence_module']['seq_0'].clone(),
+                         'angles': f['sidechains'][-1]['angles_sin_cos'].clone(), 'rigids': f['rigids'].clone(),
+                         'atom14': f['final_atom14_positions'].clone(), 'pLDDT': r['heads']['predicted_lddt']['pLDDT'].clone()})
+        finally:
+            eng.fused_heads = True
+    assert torch.equal(outs[0]['seq_0'], outs[1]['seq_0'])
+    assert torch.equal(outs[0]['rigids'], outs[1]['rigids'])                   # (the frames do not depend on the heads)
+    for k, tol in (('logits', 2e-5), ('angles', 2e-5), ('atom14', 2e-4), ('pLDDT', 2e-3)):
+        assert float((outs[0][k] - outs[1][k]).abs().max()) < tol, (k, float((outs[0][k] - outs[1][k]).abs().max()))
+
+
 def test_op_group_entry_points_equal_the_descriptor_level_path(gpu_model, cfg):
     """SURVEY 8b / VERDICT r3 #7: abx_tri_mul_fwd, abx_tri_attn_block_fwd and abx_transition_fwd (csrc/blocks.hip: one C call per
     reference module, weights packed by abx_pack_linear) issue the same kernels with the same descriptors as the Python orchestration

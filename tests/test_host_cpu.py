@@ -114,7 +114,7 @@ def test_gemm_mode_table_rejects_every_illegal_pair(lib):
 def test_ctypes_structs_match_c_layout():
     from abx_amd import _lib
     structs = {'AbxGemm': _lib.AbxGemm, 'AbxTriAttn': _lib.AbxTriAttn, 'AbxScoreArgs': _lib.AbxScoreArgs,
-               'AbxReverseArgs': _lib.AbxReverseArgs, 'AbxGuidanceArgs': _lib.AbxGuidanceArgs, 'AbxIpaTail': _lib.AbxIpaTail,
+               'AbxReverseArgs': _lib.AbxReverseArgs, 'AbxGuidanceArgs': _lib.AbxGuidanceArgs, 'AbxIpaTail': _lib.AbxIpaTail, 'AbxHeadsTail': _lib.AbxHeadsTail,
                'AbxLinearPack': _lib.AbxLinearPack, 'AbxLinearSrc': _lib.AbxLinearSrc, 'AbxTriMulPack': _lib.AbxTriMulPack,
                'AbxTriAttnPack': _lib.AbxTriAttnPack}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(){']
