@@ -72,6 +72,7 @@ class AbxIpaTail(C.Structure):
         ('fixed', c_f), ('init_q', c_f), ('init_t', c_f),
         ('cur_q', c_f), ('cur_t', c_f), ('cur_R', c_f), ('delta_q', c_f), ('pscale', F),
         ('range_flag', c_f), ('range_tag', I),
+        ('partial', c_f), ('n_partial', I), ('s_partial', LL),
     ]
 
 

@@ -755,9 +755,26 @@ __global__ __launch_bounds__(256, 1) void ipa_tail_kernel(const AbxIpaTail a) {
     };
 
     // ---- 1: s + feat W_final + b -> LN1 -> act[0] (and kept in registers: the residual of the transition)
-    g.A = a.feat; g.sAm = a.s_feat; g.sAk = 1; g.K = a.K1;
-    g.B_split = a.W_final; g.b_exp = a.e_final;
-    gemm3_mainloop<BM, BN, WM, WN, 0, true, false, IT_RING>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh);
+    if (a.partial) {
+        // feat W_final comes as n_partial K-slice products of a split-K GEMM launched before (the 132-k-step chain of this block becomes
+        // 12 k-steps of 11 x as many blocks): summed here in slice order, then the bias
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+        for (int sl = 0; sl < a.n_partial; ++sl) {
+            const float* pp = a.partial + (long long)sl * a.s_partial + (long long)grc * IT_C;
+            for_groups([&](int j, int q, int c) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][j][4 * q + e] += pv[e];
+            });
+        }
+    } else {
+        g.A = a.feat; g.sAm = a.s_feat; g.sAk = 1; g.K = a.K1;
+        g.B_split = a.W_final; g.b_exp = a.e_final;
+        gemm3_mainloop<BM, BN, WM, WN, 0, true, false, IT_RING>(g, it_smem, mt, 0, 0, acc, ls, lq, lsh);
+    }
     bias_act(a.b_final, false);
     for_groups([&](int j, int q, int c) {
         const f32x4 rv = *reinterpret_cast<const f32x4*>(a.s + (long long)grc * a.s_s + c);
@@ -1140,11 +1157,18 @@ extern "C" int abx_ipa_tail(const AbxIpaTail* ap, hipStream_t st) {
     ABX_REQUIRE(ap != nullptr, "abx_ipa_tail: null descriptor");
     const AbxIpaTail a = *ap;
     auto al16 = [](const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    ABX_REQUIRE(a.M > 0 && a.K1 > 0 && a.K1 % 16 == 0 && a.C == IT_C, "abx_ipa_tail: M > 0, K1 % 16 == 0, C == 256");
-    ABX_REQUIRE(al16(a.feat) && al16(a.s) && a.s_feat % 4 == 0 && a.s_s % 4 == 0 && a.s_feat >= a.K1 && a.s_s >= IT_C,
-                "abx_ipa_tail: feat / s must be 16-byte aligned rows");
-    ABX_REQUIRE(32LL * a.s_feat < (1LL << 28), "abx_ipa_tail: feature rows too long");
-    ABX_REQUIRE(al16(a.W_final) && al16(a.W_t0) && al16(a.W_t2) && al16(a.W_t4), "abx_ipa_tail: weight planes (abx_split_weights_f16)");
+    ABX_REQUIRE(a.M > 0 && a.C == IT_C, "abx_ipa_tail: M > 0, C == 256");
+    ABX_REQUIRE(al16(a.s) && a.s_s % 4 == 0 && a.s_s >= IT_C, "abx_ipa_tail: s must be 16-byte aligned rows");
+    if (a.partial) {
+        ABX_REQUIRE(al16(a.partial) && a.n_partial > 0 && a.s_partial >= (long long)a.M * IT_C && a.s_partial % 4 == 0,
+                    "abx_ipa_tail: partial = n_partial K-slice products (M, 256) of feat W_final, s_partial floats apart");
+    } else {
+        ABX_REQUIRE(a.K1 > 0 && a.K1 % 16 == 0, "abx_ipa_tail: K1 % 16 == 0");
+        ABX_REQUIRE(al16(a.feat) && a.s_feat % 4 == 0 && a.s_feat >= a.K1, "abx_ipa_tail: feat must be 16-byte aligned rows");
+        ABX_REQUIRE(32LL * a.s_feat < (1LL << 28), "abx_ipa_tail: feature rows too long");
+        ABX_REQUIRE(al16(a.W_final), "abx_ipa_tail: weight planes (abx_split_weights_f16)");
+    }
+    ABX_REQUIRE(al16(a.W_t0) && al16(a.W_t2) && al16(a.W_t4), "abx_ipa_tail: weight planes (abx_split_weights_f16)");
     ABX_REQUIRE(al16(a.b_final) && al16(a.b_t0) && al16(a.b_t2) && al16(a.b_t4) && al16(a.ln1_w) && al16(a.ln1_b) && al16(a.ln2_w) && al16(a.ln2_b),
                 "abx_ipa_tail: biases and LayerNorm parameters ([256], 16-byte aligned)");
     for (int e : {a.e_final, a.e_t0, a.e_t2, a.e_t4}) ABX_REQUIRE(e >= -100 && e <= 100, "abx_ipa_tail: weight exponent out of range");

@@ -248,6 +248,8 @@ class Engine:
         self._blk_ws = {}
         # True: torsion ResNet + sequence / pLDDT head MLPs of a pass in one launch (abx_heads_tail) instead of 13 - 18 small ones
         self.fused_heads = not bool(__import__('os').environ.get('ABX_NO_FUSED_HEADS'))
+        # K-slices of the IPA final_proj GEMM in front of abx_ipa_tail (0: the tail walks K itself)
+        self.ipa_splitk = int(__import__('os').environ.get('ABX_IPA_SPLITK', '11'))
         c = cfg_model.embeddings_and_seqformer
         pp = c.prev_pos
         # squared distogram breaks exactly as torch computes them on the host (common_modules.py:108-109)
@@ -550,9 +552,15 @@ class Engine:
             ops.ipa_pair(attn_ws, zi, ifeat, Bc, L)
             if tail is not None:
                 # final_proj + residual + LayerNorm + the three-layer transition + residual + LayerNorm + affine_update + frame update:
-                # one launch, the 256-wide activations stay on the CU (eight launches otherwise)
+                # one launch, the 256-wide activations stay on the CU (eight launches otherwise).  final_proj (K = 2 112) runs in front of
+                # it as a split-K GEMM of 11 K-slices (one launch, batch = slice) whose products the tail adds in slice order: the
+                # tail's 32-row blocks would otherwise walk 132 k-steps each - at every batch size, so that a sample's numbers do not
+                # depend on how many samples share the launch
+                part = None
+                if self.ipa_splitk and ifeat.shape[1] % (16 * self.ipa_splitk) == 0:
+                    part = ops.gemm_splitk(ifeat, tail[0][0], ws.get('i_part', (self.ipa_splitk, M1, NC)))
                 ops.ipa_tail(ifeat, s, *tail, affine=(P.wt[P_IPA + 'affine_update'], P.b[P_IPA + 'affine_update']),
-                             rigid=(fixed.reshape(-1), init_q, init_t, cur_q, cur_t, cur_R, delta_q, ic.position_scale))
+                             rigid=(fixed.reshape(-1), init_q, init_t, cur_q, cur_t, cur_R, delta_q, ic.position_scale), partial=part)
                 continue
             else:
                 _lin(P, P_IPA + 'attention_module.final_proj', ifeat, s, resid=s)

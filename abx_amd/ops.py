@@ -564,16 +564,44 @@ def ipa_pair(attn_ws, z, feat, B, L):
     check(_lib.load().abx_ipa_pair(_p(attn_ws), _p(z), _p(feat), B, L, _stream()), 'abx_ipa_pair')
 
 
-def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5, affine=None, rigid=None):
+def gemm_splitk(A, w3, partial):
+    """K-slice products of A (M, K) fp32 rows against split_weights planes w3 of a (K, N) weight: partial[s] = A[:, s*Ks:(s+1)*Ks] @
+    W[s*Ks:(s+1)*Ks] for the S = partial.shape[0] slices (Ks = K / S a multiple of 16), ONE abx_gemm launch with batch = slice (operand
+    windows by batch strides; split-f16 arithmetic).  The caller adds the slices in a fixed order (abx_ipa_tail's `partial` input): a
+    long-K, few-row GEMM becomes S times as many blocks with a 1 / S as long k loop."""
+    S, M, N = partial.shape
+    K = A.shape[1]
+    assert A.shape[0] == M and A.stride(1) == 1 and partial.is_contiguous() and K % (16 * S) == 0
+    _weight_planes(w3, N, K, what='gemm_splitk')
+    assert w3.shape[0] * 16 == K
+    Ks = K // S
+    g = AbxGemm()
+    g.A, g.sAb, g.sAm, g.sAk = _p(_f32(A)), Ks, A.stride(0), 1
+    g.B_split, g.sB3b, g.sB3k, g.sB3p, g.sB3n = _p(w3), (Ks // 16) * w3.stride(0), w3.stride(0), w3.stride(1), w3.stride(2)
+    g.b_f16, g.b_exp = 1, w3.w_exp
+    g.C, g.sCb, g.sCm = _p(_f32(partial)), M * N, N
+    g.M, g.N, g.K, g.batch = M, N, Ks, S
+    g.alpha, g.exact = 1.0, 2
+    if RANGE_CHECK:
+        g.range_flag, g.range_tag = range_word(A.device).data_ptr(), RANGE_TAGS['gemm']
+    check(_lib.load().abx_gemm(C.byref(g), _stream()), 'abx_gemm(split-K)')
+    return partial
+
+
+def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5, affine=None, rigid=None, partial=None):
     """The tail of an IPA layer in one launch (csrc/gemm3.hip ipa_tail_kernel; reference score_network.py:126-163):
     s <- LN1(s + feat @ W_final + b_final);  s <- LN2(s + relu(relu(s @ W0 + b0) @ W2 + b2) @ W4 + b4), in place.
     feat (M, K1) and s (M, 256) fp32 rows; w_* = (WeightPlanes of the (K, 256) weight, bias (256)); ln* = (gamma, beta).
     affine = (Wt (256, 6) fp32, bias (6)) with rigid = (fixed_i32, init_q, init_t, cur_q, cur_t, cur_R, delta_q, position_scale): also
-    affine_update of the new s and the frame update of rigid_update() in the same launch."""
+    affine_update of the new s and the frame update of rigid_update() in the same launch.
+    partial (S, M, 256): feat @ W_final already computed as S K-slice products (gemm_splitk); the kernel adds them instead of walking K1."""
     M, K1 = feat.shape
     assert s.shape == (M, 256) and feat.stride(1) == 1 and s.stride(1) == 1 and K1 % 16 == 0
     a = AbxIpaTail()
     a.feat, a.s_feat, a.s, a.s_s, a.M, a.K1, a.C = _p(_f32(feat)), feat.stride(0), _p(_f32(s)), s.stride(0), M, K1, 256
+    if partial is not None:       # feat @ W_final as K-slice products (gemm_splitk), summed by the kernel in slice order
+        assert partial.dim() == 3 and partial.shape[1:] == (M, 256) and partial.is_contiguous()
+        a.partial, a.n_partial, a.s_partial = _p(_f32(partial)), partial.shape[0], M * 256
     for tag, (w3, bias), K in (('final', w_final, K1), ('t0', w_t0, 256), ('t2', w_t2, 256), ('t4', w_t4, 256)):
         _weight_planes(w3, 256, K, what='ipa_tail ' + tag)
         assert w3.shape[0] * 16 == K and bias.numel() == 256

@@ -199,6 +199,11 @@ typedef struct AbxIpaTail {
     const int* fixed; const float* init_q; const float* init_t;
     float* cur_q; float* cur_t; float* cur_R; float* delta_q; float pscale;
     int* range_flag; int range_tag;                /* see AbxGemm.range_flag: set when the layer's output rows are not finite */
+    /* optional (partial != NULL): feat W_final arrives as n_partial K-slice products (each (M, 256) fp32, s_partial floats apart) of a
+     * split-K abx_gemm launched before (batch = slice: sAb = K1 / n_partial, sB3b = (K1 / n_partial / 16) * sB3k, sCb = s_partial); the kernel adds
+     * them in slice order instead of walking K1 itself - a 32-row block's 132-k-step DMA chain at K1 = 2 112 is what a layer costs at
+     * small batches.  feat / W_final / K1 are then unused. */
+    const float* partial; int n_partial; long long s_partial;
 } AbxIpaTail;
 int abx_ipa_tail(const AbxIpaTail* desc, hipStream_t stream);
 /* The per-residue heads on the final single representation in ONE launch (split-f16 arithmetic of AbxGemm, activations resident on the

@@ -716,6 +716,13 @@ def test_ipa_tail(ops, M):
     ops.gemm(h2, d(W4), s6, bias=wd[3][1], B3=wd[3][0], resid=s6, exact=2)
     ops.layernorm(s6, *lnd[1], out=s6)
     assert float((sd - s6).abs().max()) < 2e-5
+    # final_proj in front of the tail as a split-K GEMM of 11 K-slices (ops.gemm_splitk, one launch), summed by the tail in slice order
+    part = ops.gemm_splitk(featd, wd[0][0], torch.full((11, M, Cc), float('nan'), device=DEV))
+    refp = torch.stack([feat[:, i * 192:(i + 1) * 192].double() @ Wf[i * 192:(i + 1) * 192].double() for i in range(11)])
+    check(part, refp, 5e-6, f'split-K slices M={M}')
+    sk = d(s0)
+    ops.ipa_tail(featd, sk, wd[0], lnd[0], wd[1], wd[2], wd[3], lnd[1], partial=part)
+    check(sk, ref, 5e-6, f'ipa_tail on split-K partials M={M}')
     # with the affine_update + frame update in the same launch: against abx_gemm (exact kernel, N = 6) + abx_rigid_update on the new s
     Wa, ba = d(torch.randn(Cc, 6, generator=gen(20)) * 0.05), d(torch.randn(6, generator=gen(21)) * 0.05)
     q0 = torch.nn.functional.normalize(torch.randn(M, 4, generator=gen(22)), dim=-1)

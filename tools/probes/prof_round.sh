@@ -16,7 +16,8 @@ rm -rf $O/pmc_fetch $O/pmc_write $O/prof
 python tools/probes/clock_probe.py 3 > $O/clock.txt 2>&1
 bash tools/pmc_run.sh tri ${TAG}_tri; python tools/pmc_reduce.py gpurun_out/${TAG}_tri tri_attn8 > $O/pmc_triattn8.txt
 bash tools/pmc_run.sh mlp ${TAG}_mlp; python tools/pmc_reduce.py gpurun_out/${TAG}_mlp gemm3_mlp > $O/pmc_mlp.txt
-rm -rf gpurun_out/${TAG}_tri_* gpurun_out/${TAG}_mlp_*
+bash tools/pmc_run.sh qkvg ${TAG}_qkvg; python tools/pmc_reduce.py gpurun_out/${TAG}_qkvg 'gemm3_kernel<128, 128' > $O/pmc_qkvg.txt
+rm -rf gpurun_out/${TAG}_tri_* gpurun_out/${TAG}_mlp_* gpurun_out/${TAG}_qkvg_*
 python tools/ab_lib.py tools/probes/bin/libabx_stamp.so tools/probes/tri_stamps.py 20 352 > $O/triattn8_stamps.txt 2>&1
 for c in config2 config5 config4; do python tools/e2e_bench.py $c > $O/e2e_$c.json 2>> $O/e2e.err; done
 ls -la $O
