@@ -185,6 +185,7 @@ _PROTOS = {
     'abx_last_error_string': (C.c_char_p, []),
     'abx_init': (I, [I]),
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
+    'abx_gemm_side': (I, [C.POINTER(AbxGemm), C.POINTER(AbxGemm), _S]),
     'abx_gemm_check_modes': (I, [C.POINTER(AbxGemm)]),
     'abx_split_weights_f16': (I, [c_f, LL, LL, I, I, I, C.c_void_p, _S]),
     'abx_ipa_tail': (I, [C.POINTER(AbxIpaTail), _S]),

@@ -314,23 +314,21 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
     exact &= 1;
     const int Lp = (L + 3) / 4 * 4, C = 192;
     const TriAttnWs w = tri_attn_ws(workspace, B, L);
-    {   // q | k | v | gate
+    {   // q | k | v | gate, and the pair bias stored (b, h, i, j) as side tiles of the same grid (abx_gemm_side: one launch on the
+        // split-f16 path, the two launches otherwise)
         AbxGemm g = {};
         g.A = z; g.sAm = C; g.sAk = 1;
         g.C = w.qkvg; g.sCm = 768;
         g.M = (int)M2; g.batch = 1;
         set_weights(g, qkvg, true, exact);
         set_range(g, range_flag, range_tag, exact);
-        if (int rc = abx_gemm(&g, st)) return rc;
-    }
-    {   // pair bias, stored (b, h, i, j)
-        AbxGemm g = {};
-        g.A = z; g.sAb = LL * C; g.sAm = C; g.sAk = 1;
-        g.C = w.bT; g.sCb = 4 * LL; g.sCm = LL; g.c_transposed = 1;
-        g.M = (int)LL; g.batch = B;
-        set_weights(g, pair, true, exact);
-        set_range(g, range_flag, range_tag, exact);
-        if (int rc = abx_gemm(&g, st)) return rc;
+        AbxGemm s2 = {};
+        s2.A = z; s2.sAb = LL * C; s2.sAm = C; s2.sAk = 1;
+        s2.C = w.bT; s2.sCb = 4 * LL; s2.sCm = LL; s2.c_transposed = 1;
+        s2.M = (int)LL; s2.batch = B;
+        set_weights(s2, pair, true, exact);
+        set_range(s2, range_flag, range_tag, exact);
+        if (int rc = abx_gemm_side(&g, &s2, st)) return rc;
     }
     const float* bias = w.bT;
     if (!per_row || Lp != L) {      // key-contiguous rows of Lp floats; ending node: bias[b,h,q,k] = P[b,k,q,h]

@@ -20,6 +20,7 @@
 // MFMA operand reads (lane -> m, lane>>5 -> k) are conflict-free; tile t+1 is prefetched into registers while tile t is on
 // the matrix cores; one barrier per k-tile.  Interior blocks run a guard-free path; edge blocks a fully predicated one.
 // Block ids are remapped so that the N-tiles of one M-panel run on the same XCD (private L2) back to back.
+#include <stdlib.h>
 #include "common.h"
 #include "abx_hip.h"
 #include "gemm_epilogue.h"
@@ -462,9 +463,10 @@ extern "C" int abx_gemm_check_modes(const AbxGemm* gp) {
     return ABX_OK;
 }
 
-extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
+// validation of a descriptor and the vector-access flags the kernels read (shared by abx_gemm and abx_gemm_side)
+static int gemm_prepare(const AbxGemm* gp, AbxGemm& g) {
     if (int rc = abx_gemm_check_modes(gp)) return rc;
-    AbxGemm g = *gp;
+    g = *gp;
     ABX_REQUIRE((g.A || g.A_split) && (g.B || g.B_split) && (g.C || g.C_split), "abx_gemm: null operand");
     ABX_REQUIRE(!g.glu || (g.c_transposed && g.N % 128 == 0 && !g.gate), "abx_gemm: glu needs a transposed store, N % 128 == 0, no gate");
     const long long tile_rows = ((long long)(g.pair_L + 7) / 8 * 8) * ((long long)(g.pair_Lp + 15) / 16 * 16);
@@ -494,6 +496,30 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     g.g_vec_ok = g.gate && al16(g.gate) && (g.sGb % 4 == 0) && (g.sGm % 4 == 0);
     g.r_vec_ok = g.resid && al16(g.resid) && (g.sRb % 4 == 0) && (g.sRm % 4 == 0);
     g.rs_vec_ok = g.rowscale && al16(g.rowscale) && (g.sRSb % 4 == 0);
+    return ABX_OK;
+}
+
+int abx_gemm3_side_dispatch(const AbxGemm& g, const AbxGemm& s2, hipStream_t st, int* rc);
+
+extern "C" int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm, hipStream_t st) {
+    ABX_REQUIRE(main_gemm && side_gemm, "abx_gemm_side: null descriptor");
+    AbxGemm g, s2;
+    if (int rc = gemm_prepare(main_gemm, g)) return rc;
+    if (int rc = gemm_prepare(side_gemm, s2)) return rc;
+    int rc = 0;
+    static const bool off = getenv("ABX_NO_GEMM_SIDE") != nullptr;          // (A / B measurements: always the two launches)
+    if (!off && !abx_gemm3_side_dispatch(g, s2, st, &rc)) return rc;
+    // not a (128 x 128 plain, skinny transposed) split-f16 pair: the two launches
+    if (int r1 = abx_gemm(main_gemm, st)) return r1;
+    return abx_gemm(side_gemm, st);
+}
+
+extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
+    AbxGemm g;
+    if (int rc = gemm_prepare(gp, g)) return rc;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    (void)al16;
+    const bool akc = g.sAk == 1;
     if (g.exact != 1) {
         int rc = 0;
         if (!abx_gemm3_dispatch(g, st, &rc)) return rc;

@@ -480,6 +480,35 @@ __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     probe.finish();
 }
 
+// A 128 x 128 plain-store GEMM with a SIDE GEMM in its grid: the skinny (N <= 32, transposed store) projection of the SAME rows - the
+// triangle attention's pair bias next to its q | k | v | gate projection (seqformer.py:520-531).  Side tiles (128 rows x 32 columns,
+// the block body of the narrow kernel) are dealt evenly between the main tiles in launch order, so a side tile runs while the main
+// tiles of the same rows are resident on its XCD and takes its A panel from that L2 instead of a second 9.5 GB HBM read of z in a
+// launch of its own.  Every tile's arithmetic is what the two separate launches do: results are bit-identical.
+__global__ __launch_bounds__(256, 4) void gemm3_side_kernel(const AbxGemm g, const AbxGemm s2) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) float smem[35840 / 4];
+    const unsigned ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM, per_batch = ntn * ntm;
+    const unsigned stm = (s2.M + BM - 1) / BM, ts = stm * (unsigned)s2.batch;
+    const unsigned total = gridDim.x, bid = blockIdx.x;
+    const unsigned q = total >> 3, r = total & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    // slot w is a side tile when floor((w + 1) ts / total) > floor(w ts / total); it is side tile floor(w ts / total)
+    const unsigned sw = (unsigned)(((unsigned long long)wgid * ts) / total), sw1 = (unsigned)(((unsigned long long)(wgid + 1) * ts) / total);
+    if (sw1 > sw) {
+        const int b = (int)(sw / stm), mt = (int)(sw - (unsigned)b * stm);
+        if ((mt + 1) * BM <= s2.M && 32 <= s2.N) gemm3_block<BM, 32, 32, 32, 0, false, true>(s2, smem, mt, 0, b);
+        else gemm3_block<BM, 32, 32, 32, 0, true, true>(s2, smem, mt, 0, b);
+        return;
+    }
+    const unsigned w = wgid - sw;
+    const int b = (int)(w / per_batch);
+    const int rem = (int)(w - (unsigned)b * per_batch);
+    const int mt = rem / (int)ntn, nt = rem % (int)ntn;
+    if ((mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N) gemm3_block<BM, BN, 32, 128, 0, false, false, false, false>(g, smem, mt, nt, b);
+    else gemm3_block<BM, BN, 32, 128, 0, true, false, false, false>(g, smem, mt, nt, b);
+}
+
 // Linear -> LayerNorm over the output row (out_ln): k-contiguous fp32 A, one n-tile, plain store
 template <int BM, int BN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_oln_kernel(const AbxGemm g) {
@@ -1129,6 +1158,26 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if (!wide && !g.glu && !force && mt128 * ntn128 * g.batch < 384 && g.M > 64) *rc = launch3<64, 128, 32, 64, 4>(g, st);
     else if (wide) *rc = launch3<128, 192, 32, 192, 3>(g, st);
     else *rc = launch3<128, 128, 32, 128, 4>(g, st);
+    return 0;
+}
+
+// abx_gemm_side (gemm.hip): both descriptors validated and their vector flags filled.  Returns 1 when the pair is not served by
+// the side kernel (the caller then issues two launches).
+int abx_gemm3_side_dispatch(const AbxGemm& g, const AbxGemm& s2, hipStream_t st, int* rc) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    auto plain_a = [&](const AbxGemm& d) {
+        return d.B_split && d.b_f16 && !d.A_split && d.A && d.sAk == 1 && d.K % 16 == 0 && al16(d.A) && d.sAm % 4 == 0 && d.sAb % 4 == 0 &&
+               al16(d.B_split) && d.sB3n % 8 == 0 && d.sB3p % 8 == 0 && d.sB3k % 8 == 0 && d.sB3b % 8 == 0 && d.b_exp >= -100 && d.b_exp <= 100 &&
+               !d.glu && !d.C_split && !d.A2 && !d.out_ln_w && !d.mlp && d.a_pair_transpose <= 0 && d.pair_Lp == 0 && d.batch_inner == 0 &&
+               128LL * d.sAm < (1LL << 30) && (long long)(d.K / 16) * d.sB3k < (1LL << 31) && d.exact != 1;
+    };
+    if (!plain_a(g) || !plain_a(s2)) return 1;
+    if (g.c_transposed || g.N % 128 != 0 || g.N < 128) return 1;                      // main: the 128 x 128 plain-store kernel
+    if (!s2.c_transposed || s2.N > 32) return 1;                                      // side: the 128 x 32 transposed-store tile
+    const long long tq = ((long long)g.M + 127) / 128 * (g.N / 128) * g.batch, ts = ((long long)s2.M + 127) / 128 * s2.batch;
+    if (tq < 384 || ts <= 0 || ts > tq || tq + ts >= (1LL << 31)) return 1;           // (small problems keep their own tile choice)
+    hipLaunchKernelGGL(gemm3_side_kernel, dim3((unsigned)(tq + ts)), dim3(256), 0, st, g, s2);
+    *rc = abx_check_launch("abx_gemm_side");
     return 0;
 }
 

@@ -486,9 +486,11 @@ class Engine:
                 key = ('attn', Bc, L)
                 ops.tri_attn_block_fwd(blocks[name], z2, mask_f, Bc, L, per_row, self._blk_ws[key], exact=P.gemm_mode != 2)
                 continue
-            _ln_lin(P, pre + 'qkvg', pre + 'norm', None, z2, w768)
+            # q | k | v | gate and the pair bias (b, h, i, j) read the same LayerNorm(z) rows: one launch, the bias tiles inside the
+            # projection's grid (ops.gemm_side; two launches when the pair does not qualify - exact arithmetic, small problems)
             bT = ws.get('biasT', (Bc, 4, LL))
-            _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True)
+            ops.gemm_side(_ln_lin(P, pre + 'qkvg', pre + 'norm', None, z2, w768, defer=True),
+                          _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True))
             o = w384[:M2 * 192].view(M2, 192)
             # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
             # i.e. the transpose (2 MB per sample); starting node: a padded copy only when L % 4 != 0

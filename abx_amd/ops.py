@@ -175,7 +175,8 @@ def _weight_planes(w3, N, K=None, what='B3'):
 
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
-         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0, c_split_tile=False):
+         resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0, c_split_tile=False,
+         defer=False):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -191,6 +192,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     dual=(A2, B3_2, csum2, bias2): Cout = epi(A' B) * sigmoid(LN(A2) @ W2 + bias2) (+ resid): A2 (b, rows, K2) k-contiguous fp32 (the
     UNpadded pair tensor when pair is given), B3_2 = split_weights of the gamma-scaled gate weights (K2, N), csum2 their column sums.
     out_ln=(gamma, beta[, eps]): LayerNorm over the N output columns right after bias / alpha / act (split-f16 path only, N <= 128).
+    defer=True: nothing is launched, the filled AbxGemm is returned (for gemm_side).
     mlp=(B3_2, bias2): fused two-layer transition Cout = relu(LN(A) @ B + bias) @ W2 + bias2 (+ resid); B (K, N) is the first layer
     (N = hidden width, act must be 1, ln given), B3_2 = split_weights(permute_k16(W2t)) of the second layer W2t (N, N2), Cout / resid
     have N2 <= 192 columns and may alias A."""
@@ -333,8 +335,17 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         cd, sd = (1, 2) if g.c_transposed else (2, 1)
         assert resid.shape == (nb, M if c_planes else Cout.shape[1], No if mlp is not None else N) and resid.stride(cd) == 1, 'resid must be laid out like Cout'
         g.resid, g.sRb, g.sRm = _p(_f32(resid)), (resid.stride(0) if nb > 1 else 0), resid.stride(sd)
+    if defer:           # the filled descriptor instead of a launch (gemm_side); the caller keeps the operand tensors alive
+        return g
     check(lib.abx_gemm(C.byref(g), _stream()), 'abx_gemm')
     return Cout
+
+
+def gemm_side(g_main, g_side):
+    """abx_gemm_side: two GEMMs over the same rows in one launch (descriptors from gemm(..., defer=True)): a plain-store split-f16
+    problem with N % 128 == 0 and a skinny (N <= 32) transposed-store projection whose tiles ride in its grid and read their A panel
+    from the L2; bit-identical to the two launches, which is what the library issues when the pair does not qualify."""
+    check(_lib.load().abx_gemm_side(C.byref(g_main), C.byref(g_side), _stream()), 'abx_gemm_side')
 
 
 def planes_to_float(p, a_side, dim=0):

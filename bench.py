@@ -94,6 +94,13 @@ class OpTimer:
                                              out_ln=kw.get('out_ln') is not None)
             K2 = kw['dual'][0].shape[-1] if kw.get('dual') is not None else 0
             return kern, 2.0 * nb * M * N * (K + K2), 4.0 * nb * (M * (K + K2)) + 4.0 * nb * M * N + 4.0 * (K + K2) * N
+        if name == 'gemm_side':             # (main, side) descriptors in one launch
+            fl = sum(2.0 * d.batch * d.M * d.N * d.K for d in args[:2])
+            by = sum(4.0 * d.batch * d.M * (d.K + d.N) for d in args[:2])
+            return 'gemm3_side_kernel', fl, by
+        if name == 'gemm_splitk':
+            S, M, N = args[2].shape
+            return 'gemm3 split-K (K slices as batch)', 2.0 * M * N * args[0].shape[1], 4.0 * M * (args[0].shape[1] + S * N)
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
             return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
@@ -114,7 +121,7 @@ class OpTimer:
 
     def __enter__(self):
         skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table',
-                'range_word', 'range_names')       # (host-side helpers: no launch to time)
+                'range_word', 'range_names', 'pad_planes_128')       # (host-side helpers: no launch to time)
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
             if callable(fn) and not isinstance(fn, type) and not name.startswith('_') and name not in skip and getattr(fn, '__module__', '') == self.ops.__name__:
@@ -122,6 +129,8 @@ class OpTimer:
 
                 def wrap(fn=fn, name=name):
                     def inner(*a, **k):
+                        if k.get('defer'):            # a descriptor for gemm_side: nothing is launched
+                            return fn(*a, **k)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                         r = fn(*a, **k)

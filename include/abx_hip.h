@@ -172,6 +172,12 @@ typedef struct AbxGemm {
     int c_vec_ok, g_vec_ok, r_vec_ok, rs_vec_ok;   /* filled by the library (16-byte epilogue accesses possible) */
 } AbxGemm;
 int abx_gemm(const AbxGemm* desc, hipStream_t stream);
+/* Two GEMMs over the SAME rows in one launch: `main_gemm` a plain-store split-f16 problem with N % 128 == 0 (k-contiguous fp32 A), `side_gemm` a
+ * skinny (N <= 32) transposed-store projection - TriangleAttention's q | k | v | gate projection and its pair bias, which both read
+ * LayerNorm(z) (seqformer.py:520-531).  The side tiles are dealt between the main tiles of the grid, so the skinny projection reads its
+ * A panel from the L2 the main tiles have just filled instead of streaming the 9.5 GB pair tensor from HBM in a launch of its own.
+ * Bit-identical to abx_gemm(main_gemm) + abx_gemm(side_gemm), which is also what it does when the pair does not qualify. */
+int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm, hipStream_t stream);
 /* the mode table above, without a launch: 0 or a negative code (abx_last_error_string names the offending pair / requirement) */
 int abx_gemm_check_modes(const AbxGemm* desc);
 /* fp32 weights W[n][k] -> out[Kp/16][2][N][16] float16 planes (p0, p1) of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks

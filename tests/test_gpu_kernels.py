@@ -746,6 +746,37 @@ def test_ipa_tail(ops, M):
         assert float((x1 - x2).abs().max()) < 1e-5, nm
 
 
+@pytest.mark.parametrize('L,Bc', [(72, 5), (65, 6)])
+def test_gemm_side_equals_the_two_launches(ops, L, Bc):
+    """abx_gemm_side: the q | k | v | gate projection (LayerNorm folded, N = 768, plain store) with the triangle attention's pair bias
+    (N = 4, transposed (b, h, i, j) store) as side tiles of its grid: bit-identical to the two separate launches; L = 65: ragged last
+    row tiles on both sides (L * L % 128 != 0)."""
+    ge = g(900 + L)
+    LL, K = L * L, 192
+    z = (torch.randn(Bc, LL, K, generator=ge) * 1.3 + 0.2).to(DEV)
+    Wq, Wb = (torch.randn(K, 768, generator=ge) / K ** 0.5).to(DEV), (torch.randn(K, 4, generator=ge) / K ** 0.5).to(DEV)
+    bq, bb = torch.randn(768, generator=ge).to(DEV), torch.randn(4, generator=ge).to(DEV)
+    csq, csb = Wq.sum(0).contiguous(), Wb.sum(0).contiguous()
+    W3q, W3b = ops.split_weights(Wq), ops.split_weights(Wb)
+    outs = []
+    for side in (True, False):
+        q = torch.full((Bc * LL, 768), float('nan'), device=DEV)
+        bT = torch.full((Bc, 4, LL), float('nan'), device=DEV)
+        kq = dict(bias=bq, ln=(None, csq), B3=W3q, exact=2)
+        kb = dict(bias=bb, ln=(None, csb), B3=W3b, exact=2)
+        if side:
+            ops.gemm_side(ops.gemm(z.view(Bc * LL, K), Wq, q, defer=True, **kq), ops.gemm(z, Wb, bT.transpose(1, 2), defer=True, **kb))
+        else:
+            ops.gemm(z.view(Bc * LL, K), Wq, q, **kq)
+            ops.gemm(z, Wb, bT.transpose(1, 2), **kb)
+        outs.append((q, bT))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    x = z.double().cpu()
+    ln = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    check(outs[0][1], (ln @ Wb.double().cpu() + bb.double().cpu()).transpose(1, 2), 5e-6, f'side bias L={L}')
+    check(outs[0][0], (ln @ Wq.double().cpu() + bq.double().cpu()).reshape(Bc * LL, 768), 5e-6, f'main projection L={L}')
+
+
 @pytest.mark.parametrize('M,with_plddt', [(352, True), (4224 + 5, False), (31, True)])
 def test_heads_tail(ops, M, with_plddt):
     """abx_heads_tail: TorsionModule (sidechain.py:28-62), SequenceHead.net and PredictedLDDTHead.net (head.py:143-226) in one launch
