@@ -342,7 +342,10 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
 // scalar-cache miss per key; layout [head group][key][4]), parked in a wave-private LDS strip and read back as broadcasts; 24 accumulators per lane, keys
 // summed in order: no block barrier, no cross-lane reduction.
 constexpr int PAIR_WAVES = 4;                    // rows per workgroup
-constexpr int UZ = 16;                           // keys per step
+#ifndef ABX_PAIR_UZ
+#define ABX_PAIR_UZ 8
+#endif
+constexpr int UZ = ABX_PAIR_UZ;                  // keys per step (two steps in flight)
 
 __global__ __launch_bounds__(PAIR_WAVES * 64) void ipa_pair_kernel(const float* __restrict__ attn, const float* __restrict__ z,
                                                                    float* __restrict__ feat, long long rows, int L) {
@@ -358,16 +361,21 @@ __global__ __launch_bounds__(PAIR_WAVES * 64) void ipa_pair_kernel(const float* 
     f32x2 acc[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) acc[h] = (f32x2){0.f, 0.f};
-    for (int j0 = 0; j0 < L; j0 += UZ) {
-        f32x2 zv[UZ];
+    // software pipeline, two register sets in ping-pong: the slab rows and weights of step s + 1 are requested before step s is summed,
+    // so a wave always has a step in flight (at a dozen samples per GPU a CU holds ~18 of these waves: nothing else hides a step's HBM
+    // round trip)
+    f32x2 za[UZ], zb[UZ];
+    float wa[NHG], wb[NHG];
+    auto request = [&](int j0, f32x2 (&zd)[UZ], float (&wd)[NHG]) {
 #pragma unroll
-        for (int u = 0; u < UZ; ++u) zv[u] = *reinterpret_cast<const f32x2*>(zr + (long long)min(j0 + u, L - 1) * CZ);
-        float wv[NHG];                                           // head group q: 16 keys x 4 heads = 64 consecutive floats
+        for (int u = 0; u < UZ; ++u) zd[u] = *reinterpret_cast<const f32x2*>(zr + (long long)min(j0 + u, L - 1) * CZ);
 #pragma unroll
-        for (int q = 0; q < NHG; ++q) wv[q] = wr[(long long)q * nw + min(j0 * HG + lane, nw - 1)];
+        for (int q = 0; q < NHG; ++q) wd[q] = wr[(long long)q * nw + min(j0 * HG + (lane & (UZ * HG - 1)), nw - 1)];   // head group q: UZ keys x 4 heads
+    };
+    auto sum_step = [&](int j0, const f32x2 (&zd)[UZ], const float (&wd)[NHG]) {
         // the previous step's broadcast reads of this strip have retired (same wave, in-order LDS queue)
 #pragma unroll
-        for (int q = 0; q < NHG; ++q) ws[q * 64 + lane] = wv[q];
+        for (int q = 0; q < NHG; ++q) ws[q * (UZ * HG) + (lane & (UZ * HG - 1))] = wd[q];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -376,17 +384,26 @@ __global__ __launch_bounds__(PAIR_WAVES * 64) void ipa_pair_kernel(const float* 
             if (j0 + u < L) {
                 f32x4 w4[H / 4];
 #pragma unroll
-                for (int q = 0; q < NHG; ++q) w4[q] = *reinterpret_cast<const f32x4*>(ws + q * 64 + u * HG);
+                for (int q = 0; q < NHG; ++q) w4[q] = *reinterpret_cast<const f32x4*>(ws + q * (UZ * HG) + u * HG);
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     const float wh = w4[h >> 2][h & 3];
-                    acc[h][0] = fmaf(wh, zv[u][0], acc[h][0]);
-                    acc[h][1] = fmaf(wh, zv[u][1], acc[h][1]);
+                    acc[h][0] = fmaf(wh, zd[u][0], acc[h][0]);
+                    acc[h][1] = fmaf(wh, zd[u][1], acc[h][1]);
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    };
+    request(0, za, wa);
+    for (int j0 = 0; j0 < L; j0 += 2 * UZ) {
+        if (j0 + UZ < L) request(j0 + UZ, zb, wb);
+        sum_step(j0, za, wa);
+        if (j0 + UZ < L) {
+            if (j0 + 2 * UZ < L) request(j0 + 2 * UZ, za, wa);
+            sum_step(j0 + UZ, zb, wb);
+        }
     }
     float* fo = feat + row * NFEAT + (H * SV + 4 * H * PV) + lane * 2;
 #pragma unroll
