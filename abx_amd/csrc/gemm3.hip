@@ -1099,7 +1099,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
             return 0;
         }
         const long long mt = ((long long)g.M + 127) / 128;
-        hipLaunchKernelGGL((gemm3_oln_kernel<128, 128, 32, 128, 3>), dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
+        hipLaunchKernelGGL((gemm3_oln_kernel<128, 128, 32, 128, 4>), dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(out_ln)");
         return 0;
     }

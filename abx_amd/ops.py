@@ -65,7 +65,7 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     if dual:
         return 'gemm3_dual_kernel<128, 96, 32, 96, 3>'
     if out_ln:
-        return 'gemm3_oln_kernel<128, 128, 32, 128, 3>'
+        return 'gemm3_oln_kernel<128, 128, 32, 128, 4>'
     exact = 1 if GEMM_EXACT else int(exact or 0)
     blocks128 = ((M + 127) // 128) * ((N + 127) // 128) * batch
     wide192 = ((N + 191) // 192) * 192 <= ((N + 127) // 128) * 128
