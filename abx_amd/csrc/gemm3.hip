@@ -93,7 +93,7 @@ __device__ __forceinline__ void plane_sources(long long s_plane, long long s_row
 // meaning); a caller that walks the same A rows again passes STATS = false and the lshift of its first walk.
 // AMODE 3: the A operand is resident in LDS (a_lds: BM fp32 rows of a_lds_stride bytes, k-contiguous; written by the caller before
 // the call): no A stage, no A DMA - the fused IPA tail chains its GEMMs this way.
-template <int BM, int BN, int WM, int WN, int AMODE, bool SWAP = false, bool STATS = true, int RING = 2>
+template <int BM, int BN, int WM, int WN, int AMODE, bool SWAP = false, bool STATS = true, int RING = 2, int JGO = 0>
 __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, int mt, int nt, int b, f32x16 (&acc)[WM / 32][WN / 32],
                                                float (&ls)[WM / 32], float (&lq)[WM / 32], float (&lshift)[WM / 32],
                                                const char* a_lds = nullptr, int a_lds_stride = 0) {
@@ -321,7 +321,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         // product terms, smallest first (SplitTerms); the B fragments are fetched per group of JG sub-tiles (register budget);
         // consecutive MFMAs hit different accumulators
         using T = SplitTerms;
-        constexpr int JG = TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN;
+        constexpr int JG = JGO > 0 ? JGO : (TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN);
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += JG) {
             u32x4 bb[JG][3];
@@ -391,12 +391,12 @@ __device__ __forceinline__ bool gemm3_row_stats(const AbxGemm& g, float* st_lds,
     return gstats != nullptr || ln_inline;
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false, bool PROBE = true, int RING = 2>
+template <int BM, int BN, int WM, int WN, int AMODE, bool EDGE, bool TS, bool OLN = false, bool PROBE = true, int RING = 2, int JGO = 0>
 __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN];
     float ls[TM], lq[TM], lsh[TM];
-    gemm3_mainloop<BM, BN, WM, WN, AMODE, false, true, RING>(g, smem, mt, nt, b, acc, ls, lq, lsh);
+    gemm3_mainloop<BM, BN, WM, WN, AMODE, false, true, RING, JGO>(g, smem, mt, nt, b, acc, ls, lq, lsh);
     float* st_lds = smem;                                   // [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     __syncthreads();
@@ -407,7 +407,7 @@ __device__ __forceinline__ void gemm3_block(const AbxGemm& g, float* smem, int m
 // Two main loops over the same output tile into two accumulator sets: the channel-major product (AMODE 1) against proj_out, then
 // the rows of z (k-contiguous, inline LayerNorm) against the final-gate weights; the gate never travels through HBM and z is
 // read once for both the gate and the residual.
-template <int BM, int BN, int WM, int WN, bool EDGE>
+template <int BM, int BN, int WM, int WN, bool EDGE, int JGO = 0, int TGO = 0>
 __device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, int mt, int nt, int b) {
     constexpr int TM = WM / 32, TN = WN / 32;
     f32x16 acc[TM][TN], acc2[TM][TN];
@@ -417,14 +417,14 @@ __device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, 
     g2.A_split = nullptr; g2.a_relu = 0; g2.a_pair_transpose = 0; g2.a_pair = g.pair_Lp > 0 ? 1 : 0;
     g2.B_split = g.B2_split; g2.sB3p = g.sB23p; g2.sB3n = g.sB23n; g2.sB3k = g.sB23k; g2.sB3b = 0;
     g2.ln_csum = g.ln2_csum; g2.ln_stats = nullptr; g2.batch_inner = 0; g2.b_exp = g.b2_exp;
-    if (g.sAk == 1) gemm3_mainloop<BM, BN, WM, WN, 0>(g, smem, mt, nt, b, acc, ls, lq, lsh);
-    else gemm3_mainloop<BM, BN, WM, WN, 1>(g, smem, mt, nt, b, acc, ls, lq, lsh);
-    gemm3_mainloop<BM, BN, WM, WN, 0>(g2, smem, mt, nt, b, acc2, ls2, lq2, lsh2);
+    if (g.sAk == 1) gemm3_mainloop<BM, BN, WM, WN, 0, false, true, 2, JGO>(g, smem, mt, nt, b, acc, ls, lq, lsh);
+    else gemm3_mainloop<BM, BN, WM, WN, 1, false, true, 2, JGO>(g, smem, mt, nt, b, acc, ls, lq, lsh);
+    gemm3_mainloop<BM, BN, WM, WN, 0, false, true, 2, JGO>(g2, smem, mt, nt, b, acc2, ls2, lq2, lsh2);
     float* st_lds = smem;                                   // [BM][2] + [BM][2]
     const bool stats = gemm3_row_stats<BM, BN, WM, WN, EDGE>(g, st_lds, mt, b, ls, lq);
     gemm3_row_stats<BM, BN, WM, WN, EDGE>(g2, st_lds + 2 * BM, mt, b, ls2, lq2);
     __syncthreads();
-    gemm_epilogue<BM, BN, WM, WN, EDGE, false>(g, st_lds, smem + 4 * BM, acc, mt * BM, nt * BN, b, stats, &acc2, st_lds + 2 * BM);
+    gemm_epilogue<BM, BN, WM, WN, EDGE, false, false, true, TGO>(g, st_lds, smem + 4 * BM, acc, mt * BM, nt * BN, b, stats, &acc2, st_lds + 2 * BM);
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
@@ -530,7 +530,10 @@ template <int BM, int BN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) {
     constexpr int A_STAGE = BM * 64, B_STAGE = 2 * BN * 32;
     constexpr int OPER = (2 * A_STAGE + 2 * B_STAGE) / 4;
-    constexpr int TNW = WN / 32, TGW = TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW;
+    // four blocks per CU (MINW 4): one B sub-tile in flight and 32-column store groups keep the two accumulator sets inside 128
+    // VGPRs and the block inside 40 KB of LDS
+    constexpr int JGO = MINW >= 4 ? 1 : 0, TGO = MINW >= 4 ? 1 : 0;
+    constexpr int TNW = WN / 32, TGW = TGO > 0 ? TGO : (TNW > 3 ? (TNW % 3 == 0 ? 3 : 2) : TNW);
     constexpr int EPI = 4 * BM + 4 * 32 * (TGW * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntn = (g.N + BN - 1) / BN, ntm = (g.M + BM - 1) / BM;
@@ -542,8 +545,8 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
     const int rem = (int)(wgid - (unsigned)b * (unsigned)per_batch);
     const int mt = rem / ntn, nt = rem % ntn;
     const bool interior = (mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N;
-    if (interior) gemm3_dual_block<BM, BN, WM, WN, false>(g, smem, mt, nt, b);
-    else gemm3_dual_block<BM, BN, WM, WN, true>(g, smem, mt, nt, b);
+    if (interior) gemm3_dual_block<BM, BN, WM, WN, false, JGO, TGO>(g, smem, mt, nt, b);
+    else gemm3_dual_block<BM, BN, WM, WN, true, JGO, TGO>(g, smem, mt, nt, b);
 }
 
 // Fused two-layer transition (seqformer.py:358-376: LayerNorm -> Linear(4x) -> ReLU -> Linear, + residual) for 128 rows per block:
@@ -1121,7 +1124,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         return 0;
     }
     if (g.A2) {
-        // dual GEMM: 128 x 96 tiles (two accumulator sets of 48 registers)
+        // dual GEMM: 128 x 96 tiles (two accumulator sets of 48 registers), four blocks per CU
         if (g.A_split || g.c_transposed || g.glu || !g.B2_split || g.K2 % 16 != 0 || !al16(g.A2) || g.sA2m % 4 != 0 || g.sA2b % 4 != 0 ||
             !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 || !g.ln2_csum ||
             (g.pair_Lp > 0 ? (long long)g.pair_L * g.pair_L * g.sA2m : 128LL * g.sA2m) >= (1LL << 30) ||
@@ -1132,7 +1135,10 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         }
         // (128 x 192 tiles - A read and split once per row - need 2 x 96 accumulator registers and spill at 256 VGPRs)
         const long long mt = ((long long)g.M + 127) / 128, ntn = ((long long)g.N + 95) / 96;
-        hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
+        // four blocks per CU: the accumulator set of the first main loop is parked in scratch across the second (41 spill instructions,
+        // none inside a loop) and the kernel is still 5 % faster than at three blocks with 142 VGPRs (tune bit 10: the three-block build)
+        if (g.tune & 1024) hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 4>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(dual)");
         return 0;
     }

@@ -9,7 +9,7 @@
 // PROBE: the range probe (AbxGemm.range_flag) is compiled in.  Off for the exact fp32 kernels (no operand range) and for the 128 x 128
 // split tiles at four blocks per CU, whose 128 registers have no room for it: their outputs (q | k | v | gate, gated projections) are
 // operands of kernels that carry the probe (triangle attention, contraction), so a NaN row made there is reported one kernel later.
-template <int BM, int BN, int WM, int WN, bool EDGE, bool TS, bool OLN = false, bool PROBE = true>
+template <int BM, int BN, int WM, int WN, bool EDGE, bool TS, bool OLN = false, bool PROBE = true, int TGO = 0>
 __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __restrict__ st_lds, float* __restrict__ scratch,
                                               f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats,
                                               f32x16 (*acc2)[WM / 32][WN / 32] = nullptr, const float* __restrict__ st2_lds = nullptr) {
@@ -171,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
     if constexpr (!TS) {
         // plain store: each 32-row band goes through the wave's row-major LDS scratch [32][GW + 4] in column groups of GW <= 96
         // and leaves as float4 along n
-        constexpr int TG = TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN;     // sub-tiles per column group
+        constexpr int TG = TGO > 0 ? TGO : (TN > 3 ? (TN % 3 == 0 ? 3 : 2) : TN);     // sub-tiles per column group (TGO: the caller's choice)
         static_assert(TN % TG == 0, "column groups");
         constexpr int GW = TG * 32, LW = GW + 4, C4 = GW / 4, NQ = 32 * C4 / 64;
         float* wsc = scratch + wave * (32 * LW);
