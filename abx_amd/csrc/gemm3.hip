@@ -1124,7 +1124,7 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         return 0;
     }
     if (g.A2) {
-        // dual GEMM: 128 x 96 tiles (two accumulator sets of 48 registers), four blocks per CU
+        // dual GEMM: 128 x 96 tiles (two accumulator sets of 48 registers)
         if (g.A_split || g.c_transposed || g.glu || !g.B2_split || g.K2 % 16 != 0 || !al16(g.A2) || g.sA2m % 4 != 0 || g.sA2b % 4 != 0 ||
             !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 || !g.ln2_csum ||
             (g.pair_Lp > 0 ? (long long)g.pair_L * g.pair_L * g.sA2m : 128LL * g.sA2m) >= (1LL << 30) ||
@@ -1135,10 +1135,11 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         }
         // (128 x 192 tiles - A read and split once per row - need 2 x 96 accumulator registers and spill at 256 VGPRs)
         const long long mt = ((long long)g.M + 127) / 128, ntn = ((long long)g.N + 95) / 96;
-        // four blocks per CU: the accumulator set of the first main loop is parked in scratch across the second (41 spill instructions,
-        // none inside a loop) and the kernel is still 5 % faster than at three blocks with 142 VGPRs (tune bit 10: the three-block build)
-        if (g.tune & 1024) hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 4>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
+        // Three blocks per CU (142 VGPRs).  tune bit 10: the four-block build (one B sub-tile in flight, 32-column store groups, 128 VGPRs):
+        // 5 % faster (9.75 vs 10.28 ms at 100 samples), but the accumulator set of the first main loop is parked in scratch across the
+        // second and that is + 9 GB of HBM traffic per launch on the counters (43.9 vs 34.8 GB) - measured in profiles/r04l, not the default
+        if (g.tune & 1024) hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 4>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(dual)");
         return 0;
     }

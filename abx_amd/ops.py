@@ -63,7 +63,7 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     csrc/gemm3.hip); used by bench.py to aggregate per KERNEL exactly like `rocprofv3 --stats` does."""
     b = lambda x: 'true' if x else 'false'
     if dual:
-        return 'gemm3_dual_kernel<128, 96, 32, 96, 4>'
+        return 'gemm3_dual_kernel<128, 96, 32, 96, 3>'
     if out_ln:
         return 'gemm3_oln_kernel<128, 128, 32, 128, 4>'
     exact = 1 if GEMM_EXACT else int(exact or 0)

@@ -1,5 +1,5 @@
-"""The TriangleMultiplication tail (dual GEMM: LN(product) @ Wo * sigmoid(LN(z) @ Wg + bg) + z) at the bench geometry: four blocks per CU
-(committed: one B sub-tile in flight, 32-column store groups) against the three-block build (tune bit 10); outputs compared bit for bit."""
+"""The TriangleMultiplication tail (dual GEMM: LN(product) @ Wo * sigmoid(LN(z) @ Wg + bg) + z) at the bench geometry: three blocks per CU
+(the default) against the four-block build (tune bit 10: one B sub-tile in flight, 32-column store groups, one accumulator set parked in scratch); outputs compared bit for bit."""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from abx_amd import ops
