@@ -500,6 +500,7 @@ static int gemm_prepare(const AbxGemm* gp, AbxGemm& g) {
 }
 
 int abx_gemm3_side_dispatch(const AbxGemm& g, const AbxGemm& s2, hipStream_t st, int* rc);
+int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, int* rc);      // gemm_as.hip
 
 extern "C" int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm, hipStream_t st) {
     ABX_REQUIRE(main_gemm && side_gemm, "abx_gemm_side: null descriptor");
@@ -508,6 +509,7 @@ extern "C" int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm,
     if (int rc = gemm_prepare(side_gemm, s2)) return rc;
     int rc = 0;
     static const bool off = getenv("ABX_NO_GEMM_SIDE") != nullptr;          // (A / B measurements: always the two launches)
+    if (!off && !abx_gemm_as_dispatch(g, &s2, st, &rc)) return rc;      // A-stationary walk: the side rides in the ragged last N-tile
     if (!off && !abx_gemm3_side_dispatch(g, s2, st, &rc)) return rc;
     // not a (128 x 128 plain, skinny transposed) split-f16 pair: the two launches
     if (int r1 = abx_gemm(main_gemm, st)) return r1;
@@ -522,6 +524,7 @@ extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     const bool akc = g.sAk == 1;
     if (g.exact != 1) {
         int rc = 0;
+        if (!abx_gemm_as_dispatch(g, nullptr, st, &rc)) return rc;
         if (!abx_gemm3_dispatch(g, st, &rc)) return rc;
     }
     g.range_flag = nullptr;                 // exact fp32 products from here on: no operand range, a non-finite result is the input's
