@@ -132,7 +132,7 @@ class AbxTriMulPack(C.Structure):
 
 
 class AbxTriAttnPack(C.Structure):
-    _fields_ = [('qkvg', AbxLinearPack), ('pair', AbxLinearPack), ('out', AbxLinearPack)]
+    _fields_ = [('qkv', AbxLinearPack), ('gate', AbxLinearPack), ('pair', AbxLinearPack), ('out', AbxLinearPack)]
 
 
 class AbxScoreArgs(C.Structure):

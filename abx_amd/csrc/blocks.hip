@@ -282,12 +282,15 @@ extern "C" int abx_tri_mul_fwd(const AbxTriMulPack* wp, const float* z_in, float
 
 // ---- TriangleAttention block --------------------------------------------------------------------------------------------------------
 namespace {
-struct TriAttnWs { float* qkvg; float* bT; float* bT2; float* o; };
+struct TriAttnWs { float* qkv; float* hid; float* bT; float* bT2; float* o; };
 inline TriAttnWs tri_attn_ws(void* ws, int B, int L) {
     const long long LL = (long long)L * L, Lp = (L + 3) / 4 * 4;
     TriAttnWs w;
     char* p = static_cast<char*>(ws);
-    w.qkvg = reinterpret_cast<float*>(p); p += up(4LL * B * LL * 768);
+    // (the head of the workspace stays 768 floats per pair row: model/forward.py uses it as its 768-wide scratch between the blocks)
+    w.qkv = reinterpret_cast<float*>(p);                      // (B L L, 576) rows
+    w.hid = w.qkv + (long long)B * LL * 576;                  // (B L L, 192): gate * attention output, exact GEMMs only
+    p += up(4LL * B * LL * 768);
     w.bT = reinterpret_cast<float*>(p); p += up(4LL * B * 4 * LL);
     w.bT2 = reinterpret_cast<float*>(p); p += up(4LL * B * 4 * L * Lp);
     w.o = reinterpret_cast<float*>(p);
@@ -304,23 +307,25 @@ extern "C" long long abx_tri_attn_block_workspace_bytes(int B, int L) {
 extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const float* mask, int B, int L, int per_row, int exact,
                                       void* workspace, int* range_flag, int range_tag, hipStream_t st) {
     ABX_REQUIRE(wp && z && mask && workspace && B > 0 && L > 0, "abx_tri_attn_block_fwd: bad args");
-    const AbxLinearPack &qkvg = wp->qkvg, &pair = wp->pair, &out = wp->out;
-    ABX_REQUIRE(qkvg.csum && pair.csum && qkvg.N == 768 && pair.N == 4 && qkvg.K == 192 && pair.K == 192 && out.K == 192 && out.N == 192,
-                "abx_tri_attn_block_fwd: packs: qkvg = LN-folded 192 -> 768, pair = LN-folded 192 -> 4, out = 192 -> 192");
+    const AbxLinearPack &qkv = wp->qkv, &gate = wp->gate, &pair = wp->pair, &out = wp->out;
+    ABX_REQUIRE(qkv.csum && gate.csum && pair.csum && qkv.N == 576 && gate.N == 192 && pair.N == 4 && qkv.K == 192 && gate.K == 192 && pair.K == 192 &&
+                    out.K == 192 && out.N == 192,
+                "abx_tri_attn_block_fwd: packs: qkv = LN-folded 192 -> 576, gate = LN-folded 192 -> 192, pair = LN-folded 192 -> 4, out = 192 -> 192 "
+                "(ABX_PACK_PERMUTE_K16)");
     const long long LL = (long long)L * L, M2 = (long long)B * LL;
     ABX_REQUIRE(M2 < (1LL << 31), "abx_tri_attn_block_fwd: too many pair rows for one launch");
     ABX_REQUIRE(exact >= 0 && exact <= 3, "abx_tri_attn_block_fwd: exact is a 2-bit field");
-    const int attn_exact = (exact >> 1) & 1;                  // bit 1: the attention kernel; bit 0: the three GEMMs
+    const int attn_exact = (exact >> 1) & 1;                  // bit 1: the attention kernel; bit 0: the GEMMs
     exact &= 1;
     const int Lp = (L + 3) / 4 * 4, C = 192;
     const TriAttnWs w = tri_attn_ws(workspace, B, L);
-    {   // q | k | v | gate, and the pair bias stored (b, h, i, j) as side tiles of the same grid (abx_gemm_side: one launch on the
-        // split-f16 path, the two launches otherwise)
+    {   // q | k | v, and the pair bias stored (b, h, i, j) in the same grid (abx_gemm_side: one launch on the split-f16 path - the side
+        // rides in the free half of the projection's last column tile -, the two launches otherwise)
         AbxGemm g = {};
         g.A = z; g.sAm = C; g.sAk = 1;
-        g.C = w.qkvg; g.sCm = 768;
+        g.C = w.qkv; g.sCm = 576;
         g.M = (int)M2; g.batch = 1;
-        set_weights(g, qkvg, true, exact);
+        set_weights(g, qkv, true, exact);
         set_range(g, range_flag, range_tag, exact);
         AbxGemm s2 = {};
         s2.A = z; s2.sAb = LL * C; s2.sAm = C; s2.sAk = 1;
@@ -337,10 +342,10 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
     }
     {
         AbxTriAttn a = {};
-        a.q = w.qkvg; a.k = w.qkvg + 192; a.v = w.qkvg + 384; a.gate = w.qkvg + 576;
-        a.sb = LL * 768;
-        a.ss = per_row ? (long long)L * 768 : 768;
-        a.sl = per_row ? 768 : (long long)L * 768;
+        a.q = w.qkv; a.k = w.qkv + 192; a.v = w.qkv + 384; a.gate = nullptr;     // (the gate is applied by the tail)
+        a.sb = LL * 576;
+        a.ss = per_row ? (long long)L * 576 : 576;
+        a.sl = per_row ? 576 : (long long)L * 576;
         a.bias = bias; a.bias_sb = 4LL * L * Lp; a.bias_sh = (long long)L * Lp; a.bias_sq = Lp; a.bias_sk = 1;
         a.keymask = mask; a.km_sb = L;
         a.out = w.o; a.ob = LL * C;
@@ -352,14 +357,40 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
         if (!attn_exact) { a.range_flag = range_flag; a.range_tag = range_tag; }
         if (int rc = abx_tri_attn_fwd(&a, st)) return rc;
     }
-    {   // output projection + residual
+    if (!exact) {
+        // gated tail: z += (sigmoid(LN(z) Wg + bg) * o) Wo + bo in ONE kernel (AbxGemm.mlp = 2)
         AbxGemm g = {};
-        g.A = w.o; g.sAm = C; g.sAk = 1;
+        g.A = z; g.sAm = C; g.sAk = 1;
         g.C = z; g.sCm = C;
         g.M = (int)M2; g.batch = 1;
-        set_weights(g, out, false, exact);
+        set_weights(g, gate, true, 0);
+        g.act = 2;
+        g.gate = w.o; g.sGm = C;
+        g.mlp = 2; g.N2 = C; g.b2_exp = out.b_exp;
+        g.B2_split = out.planes; g.sB23k = 2LL * C * 16; g.sB23p = (long long)C * 16; g.sB23n = 16;
+        g.bias2 = out.bias;
         g.resid = z; g.sRm = C;
-        set_range(g, range_flag, range_tag, exact);
+        set_range(g, range_flag, range_tag, 0);
+        return abx_gemm(&g, st);
+    }
+    {   // exact GEMMs: hid = sigmoid(LN(z) Wg + bg) * o
+        AbxGemm g = {};
+        g.A = z; g.sAm = C; g.sAk = 1;
+        g.C = w.hid; g.sCm = C;
+        g.M = (int)M2; g.batch = 1;
+        set_weights(g, gate, true, 1);
+        g.act = 2;
+        g.gate = w.o; g.sGm = C; g.gate_sigmoid = 0;
+        if (int rc = abx_gemm(&g, st)) return rc;
+    }
+    {   // output projection + residual
+        AbxGemm g = {};
+        g.A = w.hid; g.sAm = C; g.sAk = 1;
+        g.C = z; g.sCm = C;
+        g.M = (int)M2; g.batch = 1;
+        set_weights(g, out, false, 1);
+        g.B_split = nullptr; g.b_f16 = 0;                   // (out's planes are k-permuted: not an operand of a plain GEMM)
+        g.resid = z; g.sRm = C;
         return abx_gemm(&g, st);
     }
 }

@@ -455,8 +455,10 @@ extern "C" int abx_gemm_check_modes(const AbxGemm* gp) {
             }
     ABX_REQUIRE(!on[GLU] || (g.c_transposed && g.N % 128 == 0 && !g.gate), "abx_gemm: glu needs a transposed store, N % 128 == 0, no gate");
     ABX_REQUIRE(!on[C_SPLIT] || g.c_transposed, "abx_gemm: c_split needs the transposed store (c_transposed)");
-    ABX_REQUIRE(!on[MLP] || (g.B2_split && g.act == 1 && g.ln_csum && !g.ln_stats && g.N2 > 0 && g.N2 <= 192 && !g.gate && !g.rowscale && !g.c_transposed),
-                "abx_gemm: mlp needs B2_split, act = 1, a folded LayerNorm (ln_csum, no ln_stats), 0 < N2 <= 192, no gate / rowscale / transposed store");
+    ABX_REQUIRE(!on[MLP] || (g.B2_split && g.ln_csum && !g.ln_stats && g.N2 > 0 && g.N2 <= 192 && !g.rowscale && !g.c_transposed &&
+                             (g.mlp == 2 ? (g.act == 2 && g.gate != nullptr) : (g.act == 1 && !g.gate))),
+                "abx_gemm: mlp needs B2_split, a folded LayerNorm (ln_csum, no ln_stats), 0 < N2 <= 192, no rowscale / transposed store; mlp = 1: "
+                "act = 1, no gate; mlp = 2 (gated tail): act = 2 and the gate operand");
     ABX_REQUIRE(!on[DUAL] || (g.B2_split && g.ln2_csum && !g.c_transposed), "abx_gemm: dual needs B2_split, ln2_csum and a plain store");
     ABX_REQUIRE(!on[OUT_LN] || (g.out_ln_b && g.N <= 128 && !g.c_transposed), "abx_gemm: out_ln needs out_ln_b, N <= 128 and a plain store");
     ABX_REQUIRE(!on[A_SPLIT] || (!g.ln_csum && !g.a_relu), "abx_gemm: a_split (plane x plane contraction) takes no LayerNorm and no relu-on-load");

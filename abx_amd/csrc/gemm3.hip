@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
 //   tile is requested before GEMM 1 of the chunk starts.
 // A is read from HBM once (the 6 chunk walks of a block hit the L2 / MALL), the hidden never leaves the CU, the output rows are
 // written once: 2 x 192 floats of HBM traffic per pair row instead of 2 x 192 + 2 x 768.
+constexpr int MLP_NH = 768;                                                  // widest hidden layer of the fused transition (LDS table)
 template <bool EDGE>
 __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, int mt, int b) {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 128, BN2 = 192, TN2 = BN2 / 32;
@@ -569,6 +570,13 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
     constexpr int B2_IMG = 2 * BN2 * 32;                                     // one k-tile of W2: [2][192][16] f16
     constexpr int NL2 = (B2_IMG + 4095) / 4096;
     char* W2s = reinterpret_cast<char*>(smem) + G1_BYTES;                    // 2 stages
+    // column sums and biases of the first layer in LDS [2][768] (read per k-step of GEMM 2: as global loads every step waited out an L2
+    // round trip - and, in issue order, the weight DMA requested before them)
+    float* cst = reinterpret_cast<float*>(W2s + 2 * B2_IMG);
+    for (int i = threadIdx.x; i < MLP_NH; i += 256) {
+        cst[i] = i < g.N ? g.ln_csum[i] : 0.f;
+        cst[MLP_NH + i] = (i < g.N && g.bias) ? g.bias[i] : 0.f;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     f32x16 acc2[1][TN2];
 #pragma unroll
@@ -622,15 +630,8 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int hc = hid0 + j * 32 + 8 * (2 * s2 + q) + 4 * h;    // 4 consecutive hidden channels
-                        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
-                        if (hc + 4 <= g.N) {
-                            cs = *reinterpret_cast<const f32x4*>(g.ln_csum + hc);
-                            if (g.bias) bi = *reinterpret_cast<const f32x4*>(g.bias + hc);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (hc + e < g.N) { cs[e] = g.ln_csum[hc + e]; bi[e] = g.bias ? g.bias[hc + e] : 0.f; }
-                        }
+                        const int hcl = min(hc, MLP_NH - 4);                 // (channels beyond N: zeros in the table, masked below)
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(cst + hcl), bi = *reinterpret_cast<const f32x4*>(cst + MLP_NH + hcl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = rstd * (acc1[0][j][8 * s2 + 4 * q + e] - dmean * cs[e]) + bi[e];
@@ -687,7 +688,7 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
 
 template <int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
-    constexpr int OPER = (2 * 128 * 64 + 2 * 2 * 128 * 32 + 2 * 2 * 192 * 32) / 4;           // floats
+    constexpr int OPER = (2 * 128 * 64 + 2 * 2 * 128 * 32 + 2 * 2 * 192 * 32) / 4 + 2 * MLP_NH;           // floats (stages + the constants table)
     constexpr int EPI = 2 * 128 + 4 * 32 * (3 * 32 + 4);
     __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
     const int ntm = (g.M + 127) / 128;
@@ -701,6 +702,182 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
     probe.finish();
 }
 
+
+// Gated tail of the TriangleAttention (seqformer.py:300-312: gate = sigmoid(gate_proj(LN z)), out = proj_out(gate * o), z += out) for 128
+// rows per block, in the shape of the fused transition above:
+//     out = (sigmoid(LN(A) Wg + bg) * G) Wo + bo (+ resid)        A: k-contiguous fp32 rows (the pair rows z, K = g.K), G = g.gate: the
+//                                                                attention output o, [M][N] fp32 rows; N = g.N gate channels, N2 outputs
+// The gate never exists in memory (9.5 GB written by the q | k | v | gate projection and read back by the attention kernel per block at
+// 100 samples of L = 352) and the output projection is no launch of its own.  The gate channels are walked in chunks of 96:
+//   GEMM 1 of a chunk = the main loop with swapped MFMA operands: the accumulators hold the transposed tiles gate^T[channel][row], lane =
+//   row; folded LayerNorm (lane-local statistics), bias, sigmoid on the registers;
+//   the G operand streams as k-tiles [128 rows][16 channels] fp32 through a double-buffered LDS stage of its own (DMA, the A-stage layout of
+//   the main loop); a lane reads the 8 channels its 8 gate registers of a k-step stand for (channels 8 q + 4 h + e of the 16-tile: the
+//   k order of permute_k16), multiplies, splits (unlifted pieces of v 2^4: split2b) - that IS the A operand of GEMM 2;
+//   GEMM 2 streams the W_o planes (k order permuted inside every 16-tile like the fused transition's second layer).
+constexpr int GT_NG = 192;                                                   // gate channels (LDS table)
+template <bool EDGE>
+__device__ __forceinline__ void gemm3_gtail_block(const AbxGemm& g, float* smem, int mt, int b) {
+    constexpr int BM = 128, BN = 96, WM = 32, WN = 96, BN2 = 192, TN2 = BN2 / 32;
+    constexpr int G1_BYTES = 2 * BM * 64 + 2 * 2 * BN * 32;                  // stages of GEMM 1 (A fp32 + gate-weight planes)
+    constexpr int B2_IMG = 2 * BN2 * 32;                                     // one k-tile of W_o: [2][192][16] f16
+    constexpr int NL2 = (B2_IMG + 4095) / 4096;
+    constexpr int G_IMG = BM * 64;                                           // one k-tile of G: fp32 [128][16]
+    char* W2s = reinterpret_cast<char*>(smem) + G1_BYTES;                    // 2 stages
+    // G comes from HBM (the W_o planes from the L2): THREE stages, requested two k-steps ahead - with two, every k-step of GEMM 2 waited
+    // out an HBM round trip that had started less than one step before (11.7 ms per launch at 100 samples of L = 352)
+    char* Gs = W2s + 2 * B2_IMG;
+    // column sums and biases of the gate projection in LDS [2][192] (see gemm3_mlp_block)
+    float* cst = reinterpret_cast<float*>(Gs + 3 * G_IMG);
+    for (int i = threadIdx.x; i < GT_NG; i += 256) {
+        cst[i] = i < g.N ? g.ln_csum[i] : 0.f;
+        cst[GT_NG + i] = (i < g.N && g.bias) ? g.bias[i] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5;
+    const int m0 = mt * BM;
+    f32x16 acc2[1][TN2];
+#pragma unroll
+    for (int t = 0; t < TN2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[0][t][r] = 0.f;
+    unsigned offs2[NL2];
+    plane_sources<BN2, NL2>(g.sB23p, g.sB23n, 0, g.N2, offs2);
+    const char* base2 = reinterpret_cast<const char*>(g.B2_split);
+    const long long step2 = g.sB23k * 2;
+    // G k-tiles: wave w fetches rows 32 w .. 32 w + 31 (two 1 KB chunks of 16 rows), 16-byte slots XOR-swizzled through the source address
+    unsigned offsG[2];
+    const char* baseG = reinterpret_cast<const char*>(g.gate + (long long)b * g.sGb + (long long)m0 * g.sGm);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 16 + (lane >> 2), p = lane & 3;
+        const int kq = p ^ ((r >> 2) & 3);
+        const int gri = min(m0 + r, g.M - 1) - m0;
+        offsG[i] = (unsigned)(((long long)gri * g.sGm + kq * 4) * 4);
+    }
+    static_assert(B2_IMG % 4096 == 0, "uniform DMA instruction counts per wave (counted waits)");
+    auto issue_w2 = [&](int ktile) {                                         // k-tile kt of W_o -> stage kt & 1
+        char* dst = W2s + (ktile & 1) * B2_IMG + wave * NL2 * 1024;
+        const char* src = base2 + ktile * step2;
+#pragma unroll
+        for (int i = 0; i < NL2; ++i) glds16(src + vgpr32(offs2[i]), dst + i * 1024);
+    };
+    const int nkt2 = g.N / 16;                                               // k-tiles of GEMM 2 (N % 16 == 0)
+    auto issue_g = [&](int ktile) {                                          // k-tile kt of G -> stage kt % 3; beyond the end: the last one again
+        const int kt = min(ktile, nkt2 - 1);                                 // (uniform instruction counts; its stage is not read any more)
+        char* dg = Gs + (ktile % 3) * G_IMG + wave * 2048;
+        const char* sg = baseG + kt * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(sg + vgpr32(offsG[i]), dg + i * 1024);
+    };
+    const int offB2 = plane_off<BN2>(0, lane & 31, h);
+    // this lane's 2 x 4 channels of a G k-tile: logical 16-byte slots h and 2 + h of its row
+    const int grow = wave * WM + (lane & 31), gx = (grow >> 2) & 3;
+    const int offG0 = grow * 64 + ((h ^ gx) << 4), offG1 = grow * 64 + (((2 + h) ^ gx) << 4);
+    constexpr int TG2 = 2;
+    const bool rows_live = m0 + wave * WM < g.M;
+
+    float ls[1], lq[1], lsh[1] = {0.f};
+    float rstd = 0.f, dmean = 0.f;
+    constexpr int KC = BN / 16;                                              // k-tiles of GEMM 2 per chunk (6: even, the stage parity runs on)
+    const int nchunk = (g.N + BN - 1) / BN;
+    for (int c = 0; c < nchunk; ++c) {
+        // first W_o k-tile and first TWO G k-tiles of the chunk: they land under GEMM 1 (whose main loop ends with every DMA drained)
+        issue_w2(c * KC);
+        issue_g(c * KC);
+        issue_g(c * KC + 1);
+        f32x16 acc1[1][BN / 32];
+        if (c == 0) {
+            gemm3_mainloop<BM, BN, WM, WN, 0, true, true>(g, smem, mt, c, b, acc1, ls, lq, lsh);
+            const float invK = 1.0f / (float)g.K;
+            const float sm = ls[0] + __shfl_xor(ls[0], 32, 64), sq = lq[0] + __shfl_xor(lq[0], 32, 64);
+            dmean = sm * invK;
+            rstd = 1.0f / sqrtf(fmaxf(sq * invK - dmean * dmean, 0.f) + g.ln_eps);
+        } else {
+            gemm3_mainloop<BM, BN, WM, WN, 0, true, false>(g, smem, mt, c, b, acc1, ls, lq, lsh);
+        }
+        const int hid0 = c * BN;
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int kl = 2 * j + s2;                                   // k-tile of the chunk
+                const int kg = c * KC + kl;                                  // k-tile of GEMM 2: W_o stage kg & 1, G stage kg % 3
+                // requests of this step, W_o first: the wait at its end leaves the two newest instructions - the G tile - in flight
+                if (kl + 1 < KC && (kg + 1) * 16 < g.N) {
+                    issue_w2(kg + 1);
+                    issue_g(kg + 2);
+                }
+                u32x4 hf[2];
+                {
+                    const char* gs = Gs + (kg % 3) * G_IMG;
+                    const f32x4 o0 = *reinterpret_cast<const f32x4*>(gs + offG0), o1 = *reinterpret_cast<const f32x4*>(gs + offG1);
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int hc = hid0 + j * 32 + 8 * (2 * s2 + q) + 4 * h;    // 4 consecutive gate channels
+                        const int hcl = min(hc, GT_NG - 4);
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(cst + hcl), bi = *reinterpret_cast<const f32x4*>(cst + GT_NG + hcl);
+                        const f32x4 ov = q ? o1 : o0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = rstd * (acc1[0][j][8 * s2 + 4 * q + e] - dmean * cs[e]) + bi[e];
+                            v[4 * q + e] = (hc + e < g.N) ? ov[e] * sigmoidf_(x) : 0.f;
+                        }
+                    }
+                    // unlifted pieces of v 2^4 (split2b): |gate * o| < 4094, else NaN -> the range probe -> the exact kernels
+                    unsigned q0[4], q1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) split2b(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+                    hf[0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                    hf[1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
+                }
+                const char* ws = W2s + (kg & 1) * B2_IMG + offB2;
+                if (rows_live && kg * 16 < g.N) {
+#pragma unroll
+                    for (int t0 = 0; t0 < TN2; t0 += TG2) {
+                        u32x4 wb[TG2][2];
+#pragma unroll
+                        for (int t = 0; t < TG2; ++t)
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) wb[t][p] = *reinterpret_cast<const u32x4*>(ws + (t0 + t) * 1024 + p * (BN2 * 32));
+                        constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};      // smallest first: a1 p0, a0 p1, a0 p0
+#pragma unroll
+                        for (int term = 0; term < 3; ++term)
+#pragma unroll
+                            for (int t = 0; t < TG2; ++t)
+                                acc2[0][t0 + t] = mfma_split(hf[TA[term]], wb[t][TB[term]], acc2[0][t0 + t]);
+                    }
+                }
+                if (kl + 1 < KC && (kg + 1) * 16 < g.N) wait_vm_and_barrier<2>();
+                else wait_vm_and_barrier<0>();                               // last k-tile of the chunk: nothing was requested
+            }
+        }
+    }
+    {
+        const float cs2 = __builtin_ldexpf(1.0f, -4 - g.b2_exp);
+#pragma unroll
+        for (int t = 0; t < TN2; ++t) acc2[0][t] *= cs2;
+    }
+    AbxGemm g2 = g;
+    g2.N = g.N2; g2.bias = g.bias2; g2.ln_csum = nullptr; g2.ln_stats = nullptr; g2.act = 0; g2.alpha = 1.0f; g2.gate = nullptr;
+    __syncthreads();
+    gemm_epilogue<BM, BN2, WM, BN2, EDGE, false>(g2, smem, smem + 2 * BM, acc2, mt * BM, 0, b, false);
+}
+
+constexpr int GT_LDS = 2 * 128 * 64 + 2 * 2 * 96 * 32 + 2 * 2 * 192 * 32 + 3 * 128 * 64 + 2 * GT_NG * 4;      // 79 360 bytes (two blocks per CU)
+
+__global__ __launch_bounds__(256, 2) void gemm3_gtail_kernel(const AbxGemm g) {
+    extern __shared__ __attribute__((aligned(16))) float gt_smem[];
+    const int ntm = (g.M + 127) / 128;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
+    const ClockProbe probe(g.clock_probe);
+    if ((mt + 1) * 128 <= g.M && g.N2 == 192) gemm3_gtail_block<false>(g, gt_smem, mt, b);
+    else gemm3_gtail_block<true>(g, gt_smem, mt, b);
+    probe.finish();
+}
 
 // ---- IPA layer tail (score_network.py:126-163 per layer: the single representation after the attention) in ONE kernel:
 //     s <- LN1(s + feat W_final + b)                                 attention_module.final_proj + attention_layer_norm
@@ -1106,13 +1283,31 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         *rc = abx_check_launch("abx_gemm(out_ln)");
         return 0;
     }
+    if (g.mlp == 2) {
+        // gated attention tail: out = (sigmoid(LN(A) B + bias) * gate) B2 + bias2 (+ resid)
+        if (g.A_split || g.sAk != 1 || g.c_transposed || g.C_split || g.glu || g.A2 || g.out_ln_w || !g.B2_split || g.N2 <= 0 || g.N2 > 192 ||
+            g.N % 16 != 0 || g.N > GT_NG || g.act != 2 || g.alpha != 1.0f || g.rowscale || !g.gate || !g.ln_csum || g.ln_stats || g.a_relu ||
+            g.a_pair_transpose > 0 || g.pair_Lp > 0 || !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 ||
+            (long long)(g.N / 16) * g.sB23k >= (1LL << 31) || !al16(g.ln_csum) || (g.bias && !al16(g.bias)) || !al16(g.gate) || g.sGm % 4 != 0 ||
+            g.sGb % 4 != 0 || 128LL * g.sGm >= (1LL << 30)) {
+            abx_set_error("abx_gemm: mlp = 2 (gated tail) needs a k-contiguous fp32 A with folded LayerNorm, act = 2, a 16-byte aligned gate "
+                          "operand [M][N], N % 16 == 0, N2 <= 192, plain store, B2_split planes in the permuted k order");
+            *rc = ABX_ERR_ARG;
+            return 0;
+        }
+        const long long mt = ((long long)g.M + 127) / 128;
+        if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm3_gtail_kernel), GT_LDS, "abx_gemm(gated tail)")) { *rc = e; return 0; }
+        hipLaunchKernelGGL(gemm3_gtail_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), GT_LDS, st, g);
+        *rc = abx_check_launch("abx_gemm(gated tail)");
+        return 0;
+    }
     if (g.mlp) {
         // fused two-layer transition: hidden = relu(LN(A) B + bias) never stored, out = hidden B2 + bias2 (+ resid)
         if (g.A_split || g.sAk != 1 || g.c_transposed || g.C_split || g.glu || g.A2 || g.out_ln_w || !g.B2_split || g.N2 <= 0 || g.N2 > 192 ||
-            g.N % 16 != 0 || g.act != 1 || g.alpha != 1.0f || g.rowscale || g.gate || !g.ln_csum || g.ln_stats || g.a_relu ||
+            g.N % 16 != 0 || g.N > MLP_NH || g.act != 1 || g.alpha != 1.0f || g.rowscale || g.gate || !g.ln_csum || g.ln_stats || g.a_relu ||
             g.a_pair_transpose > 0 || g.pair_Lp > 0 || !al16(g.B2_split) || g.sB23n % 8 != 0 || g.sB23p % 8 != 0 || g.sB23k % 8 != 0 ||
             (long long)(g.N / 16) * g.sB23k >= (1LL << 31) || !al16(g.ln_csum) || (g.bias && !al16(g.bias))) {
-            abx_set_error("abx_gemm: mlp needs a k-contiguous fp32 A with folded LayerNorm, relu, N % 16 == 0, N2 <= 192, plain store, "
+            abx_set_error("abx_gemm: mlp needs a k-contiguous fp32 A with folded LayerNorm, relu, N % 16 == 0, N <= 768, N2 <= 192, plain store, "
                           "B2_split planes in the permuted k order");
             *rc = ABX_ERR_ARG;
             return 0;

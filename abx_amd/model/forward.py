@@ -60,7 +60,7 @@ class Packed:
                 self.wt[P_BLK + tm + '.lr_proj'], self.wt[P_BLK + tm + '.lr_gates'],
                 self.b.get(P_BLK + tm + '.lr_proj'), self.b.get(P_BLK + tm + '.lr_gates'))
         for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
-            fused(P_BLK + ta + '.qkvg', [P_BLK + ta + s for s in ('.attn.proj_q', '.attn.proj_k', '.attn.proj_v', '.attn.gate')])
+            fused(P_BLK + ta + '.qkv', [P_BLK + ta + s for s in ('.attn.proj_q', '.attn.proj_k', '.attn.proj_v')])
         fused(P_BLK + 'outer_product_mean.lr', [P_BLK + 'outer_product_mean.left_proj', P_BLK + 'outer_product_mean.right_proj'])
         fused(P_IPA + 'attention_module.proj', [P_IPA + 'attention_module.' + s for s in (
             'proj_q_scalar', 'proj_kv_scalar', 'proj_q_point_local', 'proj_kv_point_local')])
@@ -133,12 +133,13 @@ class Packed:
                 blk[tm] = ops.tri_mul_pack(glu, out, gate)
             for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
                 pre = P_BLK + ta + '.'
-                qkvg = ops.LinearPack([(W(pre + 'attn.proj_q'), Bv(pre + 'attn.proj_q'), 0), (W(pre + 'attn.proj_k'), Bv(pre + 'attn.proj_k'), 0),
-                                       (W(pre + 'attn.proj_v'), Bv(pre + 'attn.proj_v'), 0), (W(pre + 'attn.gate'), Bv(pre + 'attn.gate'), 0)],
-                                      192, ln=ln(pre + 'norm'))
+                qkv = ops.LinearPack([(W(pre + 'attn.proj_q'), Bv(pre + 'attn.proj_q'), 0), (W(pre + 'attn.proj_k'), Bv(pre + 'attn.proj_k'), 0),
+                                      (W(pre + 'attn.proj_v'), Bv(pre + 'attn.proj_v'), 0)], 192, ln=ln(pre + 'norm'))
+                gate = ops.LinearPack([(W(pre + 'attn.gate'), Bv(pre + 'attn.gate'), 0)], 192, ln=ln(pre + 'norm'))
                 pair = ops.LinearPack([(W(pre + 'proj_pair'), Bv(pre + 'proj_pair'), 0)], 192, ln=ln(pre + 'norm'))
-                out = ops.LinearPack([(W(pre + 'attn.proj_out'), Bv(pre + 'attn.proj_out'), 0)], 192)
-                blk[ta] = ops.tri_attn_pack(qkvg, pair, out)
+                # (k-permuted planes: the gated tail feeds the output projection from the registers of the gate projection)
+                out = ops.LinearPack([(W(pre + 'attn.proj_out'), Bv(pre + 'attn.proj_out'), 0)], 192, permute_k16=True)
+                blk[ta] = ops.tri_attn_pack(qkv, gate, pair, out)
             self._blocks = blk
             # ONE packing per weight: the descriptor-level path (the _ln_lin / _lin calls of Engine.run_chunk) reads the same buffers,
             # so the two ways of issuing the op groups give the same bits
@@ -156,11 +157,13 @@ class Packed:
                 self._ln_cache[(pre + 'final_gate', pre + 'norm')] = (gate.Wt, gate.csum, gate.bias, gate.planes)
             for ta in ('triangle_attention_starting_node', 'triangle_attention_ending_node'):
                 pre = P_BLK + ta + '.'
-                qkvg, pair, out = blk[ta]._keep
-                self._ln_cache[(pre + 'qkvg', pre + 'norm')] = (qkvg.Wt, qkvg.csum, qkvg.bias, qkvg.planes)
+                qkv, gate, pair, out = blk[ta]._keep
+                self._ln_cache[(pre + 'qkv', pre + 'norm')] = (qkv.Wt, qkv.csum, qkv.bias, qkv.planes)
+                self._ln_cache[(pre + 'attn.gate', pre + 'norm')] = (gate.Wt, gate.csum, gate.bias, gate.planes)
                 self._ln_cache[(pre + 'proj_pair', pre + 'norm')] = (pair.Wt, pair.csum, pair.bias, pair.planes)
                 self.wt[pre + 'attn.proj_out'], self.b[pre + 'attn.proj_out'] = out.Wt, out.bias
-                self._split_cache[pre + 'attn.proj_out'] = out.planes
+                self._split_cache[('mlp2', pre + 'attn.proj_out')] = out.planes
+                self._split_cache[pre + 'attn.proj_out'] = None             # (its planes are k-permuted: never the operand of a plain GEMM)
         return self._blocks
 
     def heads_pack(self):
@@ -486,10 +489,11 @@ class Engine:
                 key = ('attn', Bc, L)
                 ops.tri_attn_block_fwd(blocks[name], z2, mask_f, Bc, L, per_row, self._blk_ws[key], exact=P.gemm_mode != 2)
                 continue
-            # q | k | v | gate and the pair bias (b, h, i, j) read the same LayerNorm(z) rows: one launch, the bias tiles inside the
-            # projection's grid (ops.gemm_side; two launches when the pair does not qualify - exact arithmetic, small problems)
+            # q | k | v and the pair bias (b, h, i, j) read the same LayerNorm(z) rows: one launch, the bias columns in the free half of the
+            # projection's last column tile (ops.gemm_side; two launches when the pair does not qualify - exact arithmetic, small problems)
             bT = ws.get('biasT', (Bc, 4, LL))
-            ops.gemm_side(_ln_lin(P, pre + 'qkvg', pre + 'norm', None, z2, w768, defer=True),
+            qkv = w768.view(-1)[:M2 * 576].view(M2, 576)
+            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True),
                           _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True))
             o = w384[:M2 * 192].view(M2, 192)
             # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
@@ -500,8 +504,14 @@ class Engine:
                 bT = bT2
             else:
                 bT = bT.view(Bc, 4, L, L)
-            ops.tri_attn(w768, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True)
-            _lin(P, pre + 'attn.proj_out', o, z2, resid=z2)
+            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True)       # (no gate: the tail applies it)
+            if P.gemm_mode == 2:
+                # gate projection, sigmoid, * attention output, output projection, + residual in ONE kernel (AbxGemm.mlp = 2)
+                _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, z2, act=2, gate=o, resid=z2, mlp=P.mlp_second(pre + 'attn.proj_out'))
+            else:
+                hid = w768.view(-1)[M2 * 576:M2 * 768].view(M2, 192)
+                _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, hid, act=2, gate=o, gate_sigmoid=False)
+                _lin(P, pre + 'attn.proj_out', hid, z2, resid=z2)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'
         if blocks is not None:

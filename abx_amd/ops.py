@@ -195,7 +195,8 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     defer=True: nothing is launched, the filled AbxGemm is returned (for gemm_side).
     mlp=(B3_2, bias2): fused two-layer transition Cout = relu(LN(A) @ B + bias) @ W2 + bias2 (+ resid); B (K, N) is the first layer
     (N = hidden width, act must be 1, ln given), B3_2 = split_weights(permute_k16(W2t)) of the second layer W2t (N, N2), Cout / resid
-    have N2 <= 192 columns and may alias A."""
+    have N2 <= 192 columns and may alias A.  With `gate` (M, N) fp32 rows and act = 2 the same call is the gated tail of the triangle attention
+    (AbxGemm.mlp = 2): Cout = (sigmoid(LN(A) @ B + bias) * gate) @ W2 + bias2 (+ resid)."""
     lib = _lib.load()
     g = AbxGemm()
     a_planes, b_planes, c_planes = A.dtype == torch.int16, B.dtype == torch.int16, Cout.dtype == torch.int16
@@ -244,10 +245,10 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         No = B32m.shape[2]
         _weight_planes(B32m, No, what='mlp B3_2')
         assert B32m.shape[0] * 16 == N
-        g.mlp, g.N2, g.b2_exp = 1, No, B32m.w_exp
+        g.mlp, g.N2, g.b2_exp = (2 if gate is not None else 1), No, B32m.w_exp
         g.B2_split, g.sB23k, g.sB23p, g.sB23n = _p(B32m), B32m.stride(0), B32m.stride(1), B32m.stride(2)
         g.bias2 = _p(bias2m)
-        assert act == 1 and ln is not None and ln[0] is None
+        assert act == (2 if gate is not None else 1) and ln is not None and ln[0] is None
     if c_planes:
         L = Cout.shape[4]
         Lp = pair[1] if pair is not None else L
@@ -292,7 +293,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
     g.tune = GEMM_TUNE if tune is None else tune
     if RANGE_CHECK and g.exact != 1:
         g.range_flag = range_word(Cout.device).data_ptr()
-        g.range_tag = RANGE_TAGS['pair_transition' if mlp is not None else 'tri_mul_tail' if dual is not None else 'ipa_pair_init' if out_ln is not None
+        g.range_tag = RANGE_TAGS[('tri_attn' if gate is not None else 'pair_transition') if mlp is not None else 'tri_mul_tail' if dual is not None else 'ipa_pair_init' if out_ln is not None
                                  else 'plane_projection' if c_planes else 'contraction' if a_planes else 'gemm']
     if dual is not None:
         A2, B32, csum2, bias2 = dual
@@ -327,7 +328,7 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         if gate.dim() == 2:
             gate = gate.unsqueeze(0)
         cd, sd = (1, 2) if g.c_transposed else (2, 1)
-        assert gate.shape == (nb, M if c_planes else Cout.shape[1], N) and gate.stride(cd) == 1, 'gate must be laid out like Cout'
+        assert gate.shape == (nb, M if c_planes else Cout.shape[1], N) and gate.stride(cd) == 1, 'gate must be laid out like Cout (mlp: (M, N) rows)'
         g.gate, g.sGb, g.sGm, g.gate_sigmoid = _p(_f32(gate)), (gate.stride(0) if nb > 1 else 0), gate.stride(sd), int(gate_sigmoid)
     if resid is not None:
         if resid.dim() == 2:
@@ -488,10 +489,10 @@ def tri_mul_fwd(pack, z_in, z_out, mask_f, B, L, outgoing, workspace):
     return z_out
 
 
-def tri_attn_pack(qkvg, pair, out):
+def tri_attn_pack(qkv, gate, pair, out):
     p = AbxTriAttnPack()
-    p.qkvg, p.pair, p.out = qkvg.c, pair.c, out.c
-    p._keep = (qkvg, pair, out)
+    p.qkv, p.gate, p.pair, p.out = qkv.c, gate.c, pair.c, out.c
+    p._keep = (qkv, gate, pair, out)
     return p
 
 
@@ -520,16 +521,19 @@ def tri_attn_kernel_name(L, exact=None, bias_vec=True):
 
 
 def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):
-    """qkvg (B*L*L, 4*H*D) = [q|k|v|gate]; biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
+    """qkvg (B*L*L, 4*H*D) = [q|k|v|gate], or (B*L*L, 3*H*D) = [q|k|v]: no gate (the gated tail applies it: gemm(..., mlp=, gate=));
+    biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
     already laid out [b,h,q,k] for this orientation (bias_is_qk=True; then (B,H,L,Lp) with rows padded to Lp % 4 == 0 floats gives
     the kernel 16-byte bias loads for any L); out (B*L*L, H*D)."""
     lib = _lib.load()
     W = qkvg.shape[1]
-    assert W == 4 * H * D and qkvg.is_contiguous() and out.is_contiguous() and biasT.is_contiguous()
+    assert W in (3 * H * D, 4 * H * D) and qkvg.is_contiguous() and out.is_contiguous() and biasT.is_contiguous()
     a = AbxTriAttn()
     es = qkvg.element_size()
     base = qkvg.data_ptr()
-    a.q, a.k, a.v, a.gate = base, base + H * D * es, base + 2 * H * D * es, base + 3 * H * D * es
+    a.q, a.k, a.v = base, base + H * D * es, base + 2 * H * D * es
+    if W == 4 * H * D:
+        a.gate = base + 3 * H * D * es
     a.sb = L * L * W
     a.ss, a.sl = (L * W, W) if per_row else (W, L * W)
     a.bias = _p(biasT)

@@ -144,7 +144,11 @@ typedef struct AbxGemm {
      * fp32 with inline LayerNorm (ln_csum, ln_stats NULL), act = 1; N % 16 == 0 = hidden width; C / resid have N2 <= 192 columns;
      * B2_split = planes of the second layer's weights [N/16][2][N2][16] (strides sB23k / sB23p / sB23n) whose 16 k of every k-tile
      * are stored in the order 0-3, 8-11, 4-7, 12-15 (the accumulator layout of the first GEMM feeds the second one from
-     * registers); C may alias resid and A (a block reads its rows before it writes them). */
+     * registers); C may alias resid and A (a block reads its rows before it writes them).
+     * mlp = 2, the gated tail of the TriangleAttention (seqformer.py:300-312) in the same shape:
+     *     C = (sigmoid(LN(A) B + bias) * gate) B2 + bias2 (+ resid)
+     * act = 2; gate = the attention output [M][N] fp32 rows (sGm, sGb; 16-byte aligned), N = gate channels (N % 16 == 0); B2_split
+     * in the permuted k order as above; C may alias resid and A. */
     int mlp, N2;
     /* LayerNorm over the N OUTPUT columns (gamma, beta; eps), applied right after bias / alpha / act and before rowscale / gate /
      * resid: Linear -> LayerNorm without a round trip of the rows through HBM (score_network.py:117-120).  Needs a kernel whose
@@ -500,12 +504,15 @@ int abx_tri_mul_fwd(const AbxTriMulPack* w, const float* z_in, float* z_out, con
                     void* workspace, int* range_flag, int range_tag, hipStream_t stream);
 
 /* TriangleAttention block (seqformer.py:506-550 + Attention.forward :272-312), starting node (per_row = 1) or ending node:
- * z <- z + proj_out(attention(LN(z))) in place on (B, L*L, 192).  qkvg: [proj_q | proj_k | proj_v | gate] with `norm` folded;
- * pair: proj_pair (192 -> 4 heads) with `norm` folded; out: attn.proj_out.  Launches: q|k|v|gate GEMM, bias GEMM, bias transpose /
- * pad (ending node or L % 4 != 0), abx_tri_attn_fwd, output GEMM + residual.  exact here is two bits: bit 0 the three GEMMs, bit 1 the
- * attention kernel (a small complex runs exact GEMMs - too few rows for the split tiles - with the split-f16 attention, which has no
- * size limit: exact = 1; everything exact, L <= 389: exact = 3). */
-typedef struct AbxTriAttnPack { AbxLinearPack qkvg, pair, out; } AbxTriAttnPack;
+ * z <- z + proj_out(sigmoid(gate(LN z)) * attention(LN(z))) in place on (B, L*L, 192).  qkv: [proj_q | proj_k | proj_v] with `norm` folded;
+ * gate: attn.gate with `norm` folded; pair: proj_pair (192 -> 4 heads) with `norm` folded; out: attn.proj_out packed with
+ * ABX_PACK_PERMUTE_K16.  Launches (exact = 0): q | k | v GEMM with the pair bias in its grid (abx_gemm_side), bias transpose / pad (ending
+ * node or L % 4 != 0), abx_tri_attn_fwd without a gate, then ONE gated tail (AbxGemm.mlp = 2): the gate projection, sigmoid, the product
+ * with the attention output, the output projection and the residual - the gate never exists in memory.  With exact GEMMs the tail is two
+ * launches (gate projection * attention output into the workspace, output projection + residual).  exact here is two bits: bit 0 the
+ * GEMMs, bit 1 the attention kernel (a small complex runs exact GEMMs - too few rows for the split tiles - with the split-f16
+ * attention, which has no size limit: exact = 1; everything exact: exact = 3). */
+typedef struct AbxTriAttnPack { AbxLinearPack qkv, gate, pair, out; } AbxTriAttnPack;
 long long abx_tri_attn_block_workspace_bytes(int B, int L);
 int abx_tri_attn_block_fwd(const AbxTriAttnPack* w, float* z, const float* mask, int B, int L, int per_row, int exact, void* workspace,
                            int* range_flag, int range_tag, hipStream_t stream);

@@ -1544,3 +1544,127 @@ def test_gemm_narrow_split_tile(ops, N, K, transposed, ln):
         ops.gemm(x.to(DEV), wt, out, B3=w3, exact=2, **kw)
         got = out
     check(got, ref, 5e-6, f'narrow split gemm N={N}')
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 5: the A-stationary, N-walking GEMM (csrc/gemm_as.hip) and the gated tail of the triangle attention (AbxGemm.mlp = 2)
+AS_OFF = 2048        # AbxGemm.tune bit 11: keep the tile kernels of gemm3.hip
+
+
+@pytest.mark.parametrize('L,Bc', [(72, 13), (65, 16), (118, 5)])
+def test_gemm_as_plain_and_side_equal_the_tile_kernels(ops, L, Bc):
+    """The K = 192 LayerNorm projections on the A-stationary kernel (a block owns 64 rows, splits them once, walks all column tiles;
+    seqformer.py:520-531): q | k | v (N = 576) with the pair bias (N = 4, (b, h, i, j) store) in the free half of its ragged last column tile,
+    and a 768-wide projection without a side - BIT-IDENTICAL to the tile kernels (same pieces, same product order, same statistics), and
+    against fp64.  L = 65 / 118: ragged last 64-row block (and a side whose 4-row store groups straddle samples for odd L * L)."""
+    ge = g(1900 + L)
+    LL, K = L * L, 192
+    z = (torch.randn(Bc, LL, K, generator=ge) * 1.3 + 0.2)
+    z[0, 5] = 1e3 + torch.randn(K, generator=ge)                  # |mean| >> sigma: the shifted statistics
+    z = z.to(DEV)
+    Wb = (torch.randn(K, 4, generator=ge) / K ** 0.5).to(DEV)
+    bb, csb, W3b = torch.randn(4, generator=ge).to(DEV), Wb.sum(0).contiguous(), ops.split_weights(Wb)
+    x = z.double().cpu()
+    ln = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    for N, side in ((576, True), (768, False), (576, False)):
+        Wq = (torch.randn(K, N, generator=ge) / K ** 0.5).to(DEV)
+        bq, csq, W3q = torch.randn(N, generator=ge).to(DEV), Wq.sum(0).contiguous(), ops.split_weights(Wq)
+        outs = []
+        for tune in (0, AS_OFF):
+            q = torch.full((Bc * LL, N), float('nan'), device=DEV)
+            bT = torch.full((Bc, 4, LL), float('nan'), device=DEV)
+            kq = dict(bias=bq, ln=(None, csq), B3=W3q, exact=2, tune=tune)
+            if side:
+                ops.gemm_side(ops.gemm(z.view(Bc * LL, K), Wq, q, defer=True, **kq),
+                              ops.gemm(z, Wb, bT.transpose(1, 2), defer=True, bias=bb, ln=(None, csb), B3=W3b, exact=2, tune=tune))
+            else:
+                ops.gemm(z.view(Bc * LL, K), Wq, q, **kq)
+            outs.append((q, bT))
+        assert torch.equal(outs[0][0], outs[1][0]), (N, side, float((outs[0][0] - outs[1][0]).abs().max()))
+        check(outs[0][0], (ln @ Wq.double().cpu() + bq.double().cpu()).reshape(Bc * LL, N), 5e-6, f'projection N={N} L={L}')
+        if side:
+            assert torch.equal(outs[0][1], outs[1][1])
+            check(outs[0][1], (ln @ Wb.double().cpu() + bb.double().cpu()).transpose(1, 2), 5e-6, f'side bias L={L}')
+
+
+@pytest.mark.parametrize('L,Bc', [(128, 5), (118, 6), (72, 14)])
+def test_gemm_as_glu_equals_the_tile_kernel(ops, L, Bc):
+    """The gated projections of the triangle multiplication (glu + plane output in (8 i x 16 k) row blocks + pair mask, both variants;
+    seqformer.py:480-485) on the A-stationary kernel: plane images identical to the tile kernel's.  L = 118 / 72: padded pair rows
+    (L % 8 != 0 or ceil4(L) % 16 != 0: predicated stores, the conservative waits)."""
+    ge = g(1950 + L)
+    K, C_ = 192, 256
+    LL = L * L
+    Lp = (L + 3) // 4 * 4
+    KT = (Lp + 15) // 16
+    z = (torch.randn(Bc, LL, K, generator=ge) * 1.5 + 0.3).to(DEV)
+    W = (torch.randn(K, 2 * C_, generator=ge) / K ** 0.5).to(DEV)
+    b, cs, W3 = torch.randn(2 * C_, generator=ge).to(DEV), W.sum(0).contiguous(), ops.split_weights(W)
+    pm = (torch.rand(Bc * L * Lp, generator=ge) > 0.15).float().to(DEV)
+    for outgoing in (True, False):
+        imgs = []
+        for tune in (0, AS_OFF):
+            lrp = torch.zeros(Bc, C_, KT, 2, L, 16, device=DEV, dtype=torch.int16)
+            ops.gemm(z, W, lrp, bias=b, ln=(None, cs), B3=W3, exact=2, tune=tune, rowscale=pm, glu=True, c_split_nA=128, c_split_tile=True,
+                     a_pair_transpose=0 if outgoing else L, pair=(L, Lp), a_pair=True)
+            imgs.append(lrp)
+        assert torch.equal(imgs[0], imgs[1]), (L, outgoing, int((imgs[0] != imgs[1]).sum()))
+        assert int((imgs[0] != 0).sum()) > 0.5 * imgs[0].numel()
+
+
+@pytest.mark.parametrize('M,inplace', [(128 * 300, True), (128 * 257 + 37, False), (4224 + 5, True)])
+def test_gemm_gated_tail(ops, M, inplace):
+    """AbxGemm.mlp = 2, the tail of the triangle attention in ONE kernel (seqformer.py:300-312): out = (sigmoid(LN(z) Wg + bg) * o) Wo + bo + z
+    - the gate never exists in memory - against fp64 and against the two-launch split-f16 path (gate projection * o, then the output
+    projection); ragged last row tile, in place over z."""
+    ge = g(1970 + M % 7)
+    K = 192
+    z = torch.randn(M, K, generator=ge) * 2 + 0.7
+    z[3] = 1e3 + torch.randn(K, generator=ge)
+    o = torch.randn(M, K, generator=ge) * 1.5
+    Wg, bg = torch.randn(K, K, generator=ge) / K ** 0.5, 0.3 * torch.randn(K, generator=ge)
+    Wo, bo = torch.randn(K, K, generator=ge) / K ** 0.5, 0.1 * torch.randn(K, generator=ge)
+    ga, be = 1 + 0.1 * torch.randn(K, generator=ge), 0.1 * torch.randn(K, generator=ge)
+    w1, cs1, bi1 = fold_ln(Wg, bg, ga, be)
+    wot = Wo.t().contiguous().to(DEV)
+    zd, od = z.clone().to(DEV), o.to(DEV)
+    out = zd if inplace else torch.full((M, K), float('nan'), device=DEV)
+    ops.gemm(zd, w1, out, bias=bi1, ln=(None, cs1), B3=ops.split_weights(w1), act=2, gate=od, resid=zd, exact=2,
+             mlp=(ops.split_weights(ops.permute_k16(wot)), bo.to(DEV)))
+    x = z.double()
+    ln = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5) * ga.double() + be.double()
+    ref = (torch.sigmoid(ln @ Wg.double().t() + bg.double()) * o.double()) @ Wo.double().t() + bo.double() + z.double()
+    check(out, ref, 3e-6, 'gated tail vs fp64')
+    z2 = z.clone().to(DEV)
+    hid = torch.empty(M, K, device=DEV)
+    ops.gemm(z2, w1, hid, bias=bi1, ln=(None, cs1), B3=ops.split_weights(w1), act=2, gate=od, gate_sigmoid=False, exact=2)
+    out2 = torch.empty(M, K, device=DEV)
+    ops.gemm(hid, wot, out2, bias=bo.to(DEV), B3=ops.split_weights(wot), resid=z2, exact=2)
+    check(out, out2, 2e-6, 'gated tail vs two launches')
+
+
+def test_gated_tail_flags_an_operand_beyond_the_split_range(ops):
+    """A gated attention output beyond the activation range of the tail's second GEMM (|gate * o| >= 4094) becomes NaN in exactly its
+    row and sets the range word (the caller then repeats on the exact kernels); every other row is what the clean input gives."""
+    ge = g(1990)
+    M, K = 128 * 260, 192
+    z, o = torch.randn(M, K, generator=ge).to(DEV), torch.randn(M, K, generator=ge).to(DEV)
+    Wg, Wo = (torch.randn(K, K, generator=ge) / K ** 0.5).to(DEV), (torch.randn(K, K, generator=ge) / K ** 0.5).to(DEV)
+    bg, bo, cs = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV), Wg.sum(0).contiguous()
+    w3, wo3 = ops.split_weights(Wg), ops.split_weights(ops.permute_k16(Wo))
+    word = ops.range_word(DEV)
+    outs = []
+    for bad in (False, True):
+        od = o.clone()
+        if bad:
+            od[777, 5] = 3.0e4
+        out = torch.empty(M, K, device=DEV)
+        word.zero_()
+        ops.gemm(z, Wg, out, bias=bg, ln=(None, cs), B3=w3, act=2, gate=od, resid=z, exact=2, mlp=(wo3, bo))
+        outs.append(out)
+        assert (int(word.item()) != 0) == bad
+    assert bool(torch.isnan(outs[1][777]).all())
+    keep = torch.ones(M, dtype=torch.bool, device=DEV)
+    keep[777] = False
+    assert torch.equal(outs[0][keep], outs[1][keep])
+    word.zero_()
