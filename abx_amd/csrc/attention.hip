@@ -30,54 +30,68 @@ constexpr int LDV = 52;       // V row stride: 4*52 mod 32 == 16 -> lane groups 
 constexpr int TRI_THREADS = 768;      // 12 waves = 3 per SIMD: softmax VALU / LDS latency of one wave hide under the others' MFMAs
 constexpr float LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn a) {
+// KC: keys per staged chunk (== L: the whole row once, the round-1 form; otherwise a multiple of 64).  A row longer than the LDS holds (L > 389) is
+// walked in key chunks: the 12 waves take 12 query tiles at a time through ALL chunks (online softmax across chunks, state in
+// registers), re-staging the chunks for every group of 12 query tiles - the exact kernel is the fallback of the split-f16 one, the
+// re-reads are the price of having no length limit (seqformer.py:272-312 has none).
+__global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn a, const int KC) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.L;
     float* Ks = smem;
-    float* Vs = smem + (((size_t)L * LDK + 3) & ~(size_t)3);      // keep V rows 16-byte aligned
+    float* Vs = smem + (((size_t)KC * LDK + 3) & ~(size_t)3);     // keep V rows 16-byte aligned
+    float* Ms = Vs + (size_t)KC * LDV;                            // [KC + 1]: key classes of the chunk's slots, [KC] = any key masked
     const int h = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 15, g = lane >> 4;
+    const int nchunk = (L + KC - 1) / KC;
 
     const long long base = (long long)b * a.sb + (long long)s * a.ss + (long long)h * TD;
-    // ---- stage K, V of this (b, s, h) in LDS --------------------------------------------------------------
-    for (int idx = tid; idx < L * (TD / 4); idx += TRI_THREADS) {
-        const int key = idx / (TD / 4), c4 = idx % (TD / 4);
-        const long long off = base + (long long)key * a.sl + c4 * 4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(a.k + off);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(a.v + off);
-        float* kd = Ks + key * LDK + c4;                     // element d = c4*4 + j goes to [g = j][kd = c4]
-        kd[0] = kv[0]; kd[12] = kv[1]; kd[24] = kv[2]; kd[36] = kv[3];
-        *reinterpret_cast<f32x4*>(Vs + key * LDV + c4 * 4) = vv;
-    }
-    // additive key mask for every key slot of the padded tiles: 0 (valid), finfo.min marker (masked), -inf (beyond L)
-    float* Ms = Vs + (size_t)L * LDV;
-    const int Lpad = ((L + 63) / 64) * 64;
-    {
-        const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
-        if (tid == 0) Ms[Lpad] = 0.f;
-        __syncthreads();
+    const float* km = a.keymask ? a.keymask + (long long)b * a.km_sb : nullptr;
+    // does the sample mask any key?  (decides the clamp-free path, as a whole-row property like before)
+    // (through a slot of the dynamic LDS: __syncthreads_or would add static LDS, and the kernel asks for all 160 KB dynamically)
+    float* flag = Ms + ((KC + 63) / 64) * 64;
+    if (tid == 0) *flag = 0.f;
+    __syncthreads();
+    if (km) {
         bool any_masked = false;
-        for (int key = tid; key < Lpad; key += TRI_THREADS) {
-            const float mv = key < L ? ((!km || km[key] != 0.f) ? 0.f : 1.f) : 2.f;
-            Ms[key] = mv;
-            any_masked |= mv == 1.f;
-        }
-        if (any_masked) Ms[Lpad] = 1.f;            // benign race: every writer stores the same value
+        for (int key = tid; key < L; key += TRI_THREADS) any_masked |= km[key] == 0.f;
+        if (any_masked) *flag = 1.f;                             // benign race: every writer stores the same value
     }
     __syncthreads();
-    const bool has_mask = Ms[Lpad] != 0.f;
+    const bool has_mask = *flag != 0.f;
+    // ---- stage K, V and the key classes of chunk c: 0 (valid), 1 (masked: the reference REPLACES the logit by finfo.min), 2 (beyond L)
+    auto stage = [&](int c) {
+        const int c0 = c * KC, nk = min(KC, L - c0);
+        for (int idx = tid; idx < nk * (TD / 4); idx += TRI_THREADS) {
+            const int key = idx / (TD / 4), c4 = idx % (TD / 4);
+            const long long off = base + (long long)(c0 + key) * a.sl + c4 * 4;
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(a.k + off);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(a.v + off);
+            float* kd = Ks + key * LDK + c4;                     // element d = c4*4 + j goes to [g = j][kd = c4]
+            kd[0] = kv[0]; kd[12] = kv[1]; kd[24] = kv[2]; kd[36] = kv[3];
+            *reinterpret_cast<f32x4*>(Vs + key * LDV + c4 * 4) = vv;
+        }
+        const int npad = ((nk + 63) / 64) * 64;
+        for (int key = tid; key < npad; key += TRI_THREADS)
+            Ms[key] = key < nk ? ((!km || km[c0 + key] != 0.f) ? 0.f : 1.f) : 2.f;
+    };
+    if (nchunk == 1) {
+        stage(0);
+        __syncthreads();
+    }
 
     const float* biasb = a.bias ? a.bias + (long long)b * a.bias_sb + (long long)h * a.bias_sh : nullptr;
-    const int nqt = (L + 15) / 16, nkt = (L + 63) / 64;
+    const int nqt = (L + 15) / 16;
     const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && (L % 4 == 0) &&
                           ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
     const float qscale = a.scale * LOG2E;                       // softmax evaluated in base 2: exp(x) = exp2(x log2 e)
 
-    for (int qt = wave; qt < nqt; qt += TRI_THREADS / 64) {
+    for (int qg = 0; qg < nqt; qg += TRI_THREADS / 64) {
+        const int qt = qg + wave;
+        const bool has_tile = qt < nqt;                          // (a wave without a tile still joins the chunk barriers)
         // ---- Q fragment (B operand of the swapped product): lane holds Q[q][kd*4 + g], pre-scaled
         const int qrow = qt * 16 + lq;
-        const bool qok = qrow < L;
+        const bool qok = has_tile && qrow < L;
         float qf[12];
         {
             const float* qp = a.q + base + (long long)(qok ? qrow : 0) * a.sl + g;
@@ -90,17 +104,17 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // one 64-key tile.  FAST: the tile lies fully inside [0, L) and no key is masked -> no clamps, no mask arithmetic,
-        // LDS addresses are a per-tile base plus compile-time offsets.
-        auto tile = [&](const int kt, auto fast_tag) {
+        // one 64-key tile of the staged chunk (first key c0, nk keys).  FAST: the tile lies fully inside the chunk and no key is masked
+        // -> no clamps, no mask arithmetic, LDS addresses are a per-tile base plus compile-time offsets.
+        auto tile = [&](const int c0, const int nk, const int kt, auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
-            const int k0 = kt * 64;
+            const int k0 = kt * 64;                               // chunk-local
             // ---- bias of this tile: issued first so the loads fly under the QK^T MFMAs
             float bz[4][4];
-            if (bias_vec && (FAST || k0 + 64 <= L)) {            // 4 consecutive keys per lane -> one 16-B load
+            if (bias_vec && (FAST || k0 + 64 <= nk)) {           // 4 consecutive keys per lane -> one 16-B load (c0 % 64 == 0)
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + k0 + sub * 16 + g * 4);
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(brow + c0 + k0 + sub * 16 + g * 4);
                     bz[sub][0] = t4[0]; bz[sub][1] = t4[1]; bz[sub][2] = t4[2]; bz[sub][3] = t4[3];
                 }
             } else {
@@ -108,8 +122,8 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = FAST ? k0 + sub * 16 + g * 4 + r : min(k0 + sub * 16 + g * 4 + r, L - 1);
-                        bz[sub][r] = brow ? brow[(long long)key * a.bias_sk] : 0.f;
+                        const int key = FAST ? k0 + sub * 16 + g * 4 + r : min(k0 + sub * 16 + g * 4 + r, nk - 1);
+                        bz[sub][r] = brow ? brow[(long long)(c0 + key) * a.bias_sk] : 0.f;
                     }
             }
             f32x4 sc[4];
@@ -118,16 +132,16 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
                 const f32x4* kp = reinterpret_cast<const f32x4*>(
-                    FAST ? kbase + sub * 16 * LDK : Ks + min(k0 + sub * 16 + lq, L - 1) * LDK + g * 12);
+                    FAST ? kbase + sub * 16 * LDK : Ks + min(k0 + sub * 16 + lq, nk - 1) * LDK + g * 12);
                 const f32x4 ka = kp[0], kb4 = kp[1], kc = kp[2];
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 c0a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kd = 0; kd < 4; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kd], qf[kd], c0, 0, 0, 0);
+                for (int kd = 0; kd < 4; ++kd) c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[kd], qf[kd], c0a, 0, 0, 0);
 #pragma unroll
-                for (int kd = 0; kd < 4; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kb4[kd], qf[4 + kd], c0, 0, 0, 0);
+                for (int kd = 0; kd < 4; ++kd) c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(kb4[kd], qf[4 + kd], c0a, 0, 0, 0);
 #pragma unroll
-                for (int kd = 0; kd < 4; ++kd) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[kd], qf[8 + kd], c0, 0, 0, 0);
-                sc[sub] = c0;
+                for (int kd = 0; kd < 4; ++kd) c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[kd], qf[8 + kd], c0a, 0, 0, 0);
+                sc[sub] = c0a;
             }
             // this lane: keys k0 + sub*16 + g*4 + r (r = 0..3) of query column lq
             float mx = -INFINITY;
@@ -184,16 +198,26 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float* vp = FAST ? vbase + (sub * 16 + r) * LDV
-                                           : Vs + min(k0 + sub * 16 + g * 4 + r, L - 1) * LDV + lq;   // p == 0 for keys >= L
+                                           : Vs + min(k0 + sub * 16 + g * 4 + r, nk - 1) * LDV + lq;   // p == 0 for keys beyond the row
 #pragma unroll
                     for (int d = 0; d < 3; ++d)
                         o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[d * 16], sc[sub][r], o[d], 0, 0, 0);
                 }
             }
         };
-        const int nfast = has_mask ? 0 : L / 64;
-        for (int kt = 0; kt < nfast; ++kt) tile(kt, std::true_type{});
-        for (int kt = nfast; kt < nkt; ++kt) tile(kt, std::false_type{});
+        for (int c = 0; c < nchunk; ++c) {
+            const int c0 = c * KC, nk = min(KC, L - c0);
+            if (nchunk > 1) {
+                __syncthreads();                                // every wave has left the chunk staged before
+                stage(c);
+                __syncthreads();
+            }
+            if (has_tile) {
+                const int nkt = (nk + 63) / 64, nfast = has_mask ? 0 : nk / 64;
+                for (int kt = 0; kt < nfast; ++kt) tile(c0, nk, kt, std::true_type{});
+                for (int kt = nfast; kt < nkt; ++kt) tile(c0, nk, kt, std::false_type{});
+            }
+        }
         // ---- normalise, gate, store.  O^T layout: column = query lq, rows d = dblk*16 + g*4 + r
         if (qok) {
             const float inv = 1.0f / l_run;
@@ -1270,10 +1294,13 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         if (prod) return launch(&tri_attn4_kernel<2, 192, true, TRI_THREADS, true>, lds_of(192, true));
         return launch(&tri_attn4_kernel<2, 128, true, TRI_THREADS, false>, lds_of(128, true));
     }
-    const size_t lds = ((((size_t)a.L * LDK + 3) & ~(size_t)3) + (size_t)a.L * LDV + (size_t)((a.L + 63) / 64) * 64 + 4) * sizeof(float);
-    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: L too large for the single-stage K/V LDS layout of the exact kernel (L <= 389)");
+    // exact fp32 kernel: the whole row's K / V in LDS when it fits (L <= 389), key chunks of 320 otherwise (no length limit)
+    auto lds_of_exact = [](int kc) { return ((((size_t)kc * LDK + 3) & ~(size_t)3) + (size_t)kc * LDV + (size_t)((kc + 63) / 64) * 64 + 4) * sizeof(float); };
+    const int kc = lds_of_exact(a.L) <= 160 * 1024 ? a.L : 320;      // (chunks start at multiples of 64: aligned bias loads)
+    const size_t lds = lds_of_exact(kc);
+    ABX_REQUIRE(lds <= 160 * 1024, "abx_tri_attn_fwd: internal: exact-kernel LDS layout");
     if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(tri_attn_kernel), 160 * 1024, "abx_tri_attn_fwd")) return rc;
-    hipLaunchKernelGGL(tri_attn_kernel, dim3(a.H, a.S, a.B), dim3(TRI_THREADS), lds, st, a);
+    hipLaunchKernelGGL(tri_attn_kernel, dim3(a.H, a.S, a.B), dim3(TRI_THREADS), lds, st, a, kc);
     return abx_check_launch("abx_tri_attn_fwd");
 }
 

@@ -22,6 +22,8 @@
 // 75 KB of LDS, two blocks per CU: one block's prologue and its last, un-overlapped epilogue run under the other block's walk.
 // The arithmetic of every output element is that of gemm3_kernel (same pieces, same three product terms per k-step in the same
 // order, same statistics code in the same order): results are bit-identical to the tile kernels.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -621,7 +623,8 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(const AbxGemm g, const 
 // Returns 1 when the problem is not served here (the caller goes on to the tile kernels of gemm3.hip).
 int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, int* rc) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (g.tune & 2048) return 1;                                // benchmarking: the tile kernels
+    static const bool off = getenv("ABX_NO_GEMM_AS") != nullptr;          // (A / B measurements: always the tile kernels)
+    if (off || (g.tune & 2048)) return 1;                       // tune bit 11: the tile kernels for this call
     if (g.exact == 1 || !g.B_split || !g.b_f16 || g.A_split || !g.A || g.sAk != 1 || g.K != AS_NK * 16) return 1;
     if (g.A2 || g.out_ln_w || g.mlp || g.ln_stats || g.gate || g.resid || g.batch_inner || !g.ln_csum || !g.bias) return 1;
     if (g.act != 0 || g.alpha != 1.0f) return 1;

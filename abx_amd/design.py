@@ -241,6 +241,8 @@ def main(argv=None):
     # a sample's trajectory independent of where and with whom it runs, so both schemes write the same files.
     plan = None
     if (world > 1 or a.force_collective) and len(jobs) >= 2 and not a.shard_samples:
+        if a.min_block < 1:
+            raise SystemExit('--min_block must be >= 1')
         plan = sampler.plan_work_units([float(load_job(ji)['L']) ** 3 for ji in range(len(jobs))], N, world, min_block=a.min_block, force=a.force_collective)
     if plan is None:
         work = [(ji, sampler.shard_sample_ids(N, rank, world)) for ji in range(len(jobs))]
@@ -311,7 +313,7 @@ def main(argv=None):
         if plan is not None:
             row = torch.zeros(n, 4 + maxLab, dtype=torch.float64)
             row[:, 0], row[:, 1], row[:, 3] = ji, torch.tensor(ids, dtype=torch.float64), Lab
-            row[:, 2] = local['pLDDT'].double().mean(1).cpu()
+            row[:, 2] = local['pLDDT'].float().mean(1).double().cpu()       # (the float32 mean of the sample-sharded path: same TSV digits)
             row[:, 4:4 + Lab] = local['seq'].double().cpu()
             set_rows.append(row)
             continue

@@ -36,7 +36,7 @@ class GraphedSteps:
     def _body(self, first=False):
         b = self.batch
         if torch.cuda.is_current_stream_capturing():
-            ops.range_word(self.rig.device).zero_()              # (captured: every replay starts from a clear range word)
+            ops.range_words(self.rig.device).zero_()              # (captured: every replay starts from a clear range word)
         if not first:        # step 0 keeps the batch's own float32 rigids_t (sample_ref): the reference's step-0 dtype quirk
             b['rigids_t'], b['seq_t'] = self.rig, self.seq
         sampler.set_t_feats(b, self.D, self.t, self.ones)
@@ -78,7 +78,10 @@ class GraphedSteps:
         g.replay()
         # range safety of the split-f16 kernels: the eager path repeats a flagged pass on the exact kernels (model/abx.py); a replayed
         # graph cannot branch, and the step has overwritten its own self-conditioning input by now, so here it is an error with the remedy
-        bits = int(ops.range_word(self.rig.device).item()) if ops.RANGE_CHECK else 0
+        bits = 0
+        if ops.RANGE_CHECK:
+            for v in ops.range_words(self.rig.device).tolist():       # (one word per network pass: ops.RANGE_SLOT)
+                bits |= v
         if bits:
             raise FloatingPointError(f'step {k}: an activation left the operand range of the split-f16 kernels ({", ".join(ops.range_names(bits))}); '
                                      'run this trajectory without use_graph: the eager path repeats such a pass on the exact fp32 kernels')

@@ -62,7 +62,10 @@ class ScoreNetwork(nn.Module):
         self._engine_key = None
         self._engine_serial = 0
         self._bufs = {}
-        self.range_log = []              # calls that left the split-f16 operand ranges and were repeated on the exact kernels
+        self.range_log = []              # calls that left the split-f16 operand ranges and were repeated with the flagged op class exact
+        self.range_sticky_after = 2      # flagged calls after which the flagged classes STAY on the exact kernels (no more repeats)
+        self._sticky_tags = 0            # op classes (ops.RANGE_TAGS bits) that run exact from now on
+        self._flagged_calls = 0
         self._pinned = set()
         self._n_calls = 0
 
@@ -89,7 +92,7 @@ class ScoreNetwork(nn.Module):
         key = (B, L)
         held = 0
         if self._engine is not None:        # what a previous decision allocated: the named scratch buffers and the op-group workspaces
-            held = sum(b.numel() * b.element_size() for b in list(self._engine.ws.bufs.values()) + list(self._engine._blk_ws.values()))
+            held = sum(b.numel() * b.element_size() for b in list(self._engine.ws.bufs.values()) + [v[0] for v in self._engine._blk_ws.values()])
         need = _WORKSPACE_BYTES_PER_PAIR * L * L
         hit = self._auto_chunks.get(key)
         if hit is not None and hit * need <= held * 1.05:
@@ -126,58 +129,102 @@ class ScoreNetwork(nn.Module):
         # (keyed by the identity AND version of the context tensors: a caller that refills one dict with another complex of the same
         # shape, in place or by replacing the tensors, gets fresh embeddings)
         ctx = tuple((batch[k].data_ptr(), batch[k]._version) for k in ('seq', 'fixed_mask', 'atom14_gt_positions'))
+        from abx_amd import ops
+        # Range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag): the kernels OR the bit of their op class into the
+        # device's range word when a value they store is not finite - what an activation beyond their operand ranges becomes (the
+        # reference's plain fp32 contractions have no such range: seqformer.py:260-312, 443-504).
+        word = ops.range_words(device) if ops.RANGE_CHECK and not ops.GEMM_EXACT else None
+        capturing = torch.cuda.is_current_stream_capturing()
+        P = eng.P
+        P.exact_tags = self._sticky_tags
         skey = (id(self), self._engine_serial, B, L, shared, ctx)
         hit = batch.get('_static')
         if hit is None or hit[0] != skey:
-            hit = (skey, eng.static_embeddings(batch, shared))
+            # the cached embeddings are built by range-tagged GEMMs too: their own clean word, and a rebuild on the exact kernels when
+            # they set it (one host synchronisation per complex)
+            if word is not None and not capturing:
+                word.zero_()
+            ops.RANGE_SLOT = 0
+            emb = eng.static_embeddings(batch, shared)
+            if word is not None and not capturing and any(word.tolist()):
+                self._sticky_tags |= ops.RANGE_TAGS['gemm']
+                P.exact_tags = self._sticky_tags
+                self.range_log.append({'call': self._n_calls + 1, 'ops': ['gemm'], 'where': 'static embeddings', 'L': L, 'B': B, 'sticky': True})
+                emb = eng.static_embeddings(batch, shared)
+            hit = (skey, emb)
             batch['_static'] = hit
         self._static = hit[1]
         num_recycle = self._model_conf.num_recycle
         self._n_calls += 1
-        from abx_amd import ops
 
         def passes():
-            batch.update(is_recycling=True)
-            for _ in range(num_recycle):
-                r = self._pass(eng, batch, final=False)
-                prev = get_prev(batch, r, self._model_conf)
-                batch.update(seq_t=r['heads']['sequence_module']['seq_0'])
-                batch.update(prev)
-            batch.update(is_recycling=False)
-            return self._pass(eng, batch, final=bool(compute_loss))
+            # (every pass reports to its own range word: a pass that left the range hands NaN rows to ALL classes of the next one
+            # through the recycled representations, so only the first flagged pass says which class it was)
+            try:
+                batch.update(is_recycling=True)
+                for i in range(num_recycle):
+                    ops.RANGE_SLOT = min(i, ops.RANGE_SLOTS - 1)
+                    r = self._pass(eng, batch, final=False)
+                    prev = get_prev(batch, r, self._model_conf)
+                    batch.update(seq_t=r['heads']['sequence_module']['seq_0'])
+                    batch.update(prev)
+                batch.update(is_recycling=False)
+                ops.RANGE_SLOT = min(num_recycle, ops.RANGE_SLOTS - 1)
+                return self._pass(eng, batch, final=bool(compute_loss))
+            finally:
+                ops.RANGE_SLOT = 0
 
-        # Range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag): the kernels OR a bit into the device's range word
-        # when a value they store is not finite - what an activation beyond their operand ranges becomes (the reference's plain fp32
-        # contractions have no such range: seqformer.py:260-312, 443-504).  The word is read ONCE per call (one host synchronisation; a
-        # read per pass cost 18 % of a 32-sample trajectory step, whose kernels are short enough for the launch thread to be exposed
-        # after every drain); the call's inputs - the self-conditioning tensors of the previous call, the tokens - stay intact until then
-        # (the representation buffers rotate three ways and the call's input buffer is pinned), and a flagged call is repeated on the
-        # exact fp32-MFMA kernels, so a caller never sees the contract: results are the reference's either way.  Inside a hipGraph capture
-        # the word only accumulates (abx_amd.graph checks it after each replay).
-        word = ops.range_word(device) if ops.RANGE_CHECK and not ops.GEMM_EXACT else None
-        capturing = torch.cuda.is_current_stream_capturing()
+        # The word is read ONCE per call (one host synchronisation; a read per pass cost 18 % of a 32-sample trajectory step, whose kernels
+        # are short enough for the launch thread to be exposed after every drain); the call's inputs - the self-conditioning tensors of
+        # the previous call, the tokens - stay intact until then (the representation buffers rotate three ways and the call's input buffer
+        # is pinned).  A flagged call is repeated with the FIRST flagged op class of the pass (ops.RANGE_ORDER: every class behind it only
+        # saw its NaN rows) on the exact fp32-MFMA kernels and everything else still on the split-f16 ones; if the repeat flags a later
+        # class, that one joins, and so on (at most one repeat per class).  After `range_sticky_after` flagged calls the classes found
+        # so far stay exact for the rest of the module's life (a checkpoint whose activations sit beyond the range would otherwise pay split
+        # + exact on every call), logged once.  A caller never sees the contract: results are the reference's either way.  All samples of
+        # a call share the arithmetic switch, so a sample's low-order bits depend on its batch mates IN A FLAGGED CALL ONLY.  Inside a
+        # hipGraph capture the word only accumulates (abx_amd.graph checks it after each replay).
         start = {k: batch.get(k) for k in ('seq_t', 'prev_pos', 'prev_seq', 'prev_pair')}
         self._pinned = {v.data_ptr() for k, v in start.items() if k != 'seq_t' and torch.is_tensor(v)}
         try:
             with torch.no_grad():
-                if word is not None and not capturing:
-                    word.zero_()
-                ret = passes()
-                if word is not None and not capturing:
-                    bits = int(word.item())
-                    if bits:
-                        self.range_log.append({'call': self._n_calls, 'ops': ops.range_names(bits), 'L': L, 'B': B})
-                        if L > 389 and (bits & ops.RANGE_TAGS['tri_attn']):
-                            raise FloatingPointError('triangle attention operands left the split-f16 range (|k|, |v| < 4095, |q| scale < 5600) or '
-                                                     f'are not finite, and the exact fp32 kernel serves L <= 389 only (L = {L})')
-                        batch.update(start)
-                        ops.GEMM_EXACT = True
-                        try:
-                            ret = passes()
-                        finally:
-                            ops.GEMM_EXACT = False
+                tags, entry = self._sticky_tags, None
+                for _attempt in range(len(ops.RANGE_ORDER) + 1):
+                    P.exact_tags = tags
+                    if word is not None and not capturing:
+                        word.zero_()
+                    ret = passes()
+                    if word is None or capturing:
+                        break
+                    per_pass = word.tolist()
+                    bits = 0
+                    for v in per_pass:
+                        bits |= v
+                    if not bits:
+                        break
+                    # the first flagged pass names the class (a class that is exact already does not report: `skip`)
+                    first = ops.first_range_tag(next(v for v in per_pass if v), skip=tags)
+                    if entry is None:
+                        entry = {'call': self._n_calls, 'ops': ops.range_names(bits), 'exact_ops': [], 'L': L, 'B': B, 'repeats': 0}
+                        self.range_log.append(entry)
+                    if not first:       # every flagged class is exact already: the values are not finite for another reason (inputs, weights)
+                        break
+                    tags |= first
+                    entry['exact_ops'] += ops.range_names(first)
+                    entry['repeats'] += 1
+                    batch.update(start)
+                if entry is not None:
+                    self._flagged_calls += 1
+                    if self._flagged_calls >= self.range_sticky_after and (tags & ~self._sticky_tags):
+                        self._sticky_tags |= tags
+                        entry['sticky'] = True
+                        import logging
+                        logging.getLogger('abx_amd').warning(
+                            'split-f16 operand ranges left in %d calls: the op classes %s run on the exact fp32-MFMA kernels from now on',
+                            self._flagged_calls, ops.range_names(self._sticky_tags))
         finally:
             self._pinned = set()
+            P.exact_tags = self._sticky_tags
         return ret
 
     def _esm_embed(self, batch):

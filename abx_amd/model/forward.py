@@ -33,6 +33,10 @@ class Packed:
         self._ln_cache = {}
         self._split_cache = {}
         self.gemm_mode = 0           # set per pass by Engine.run_chunk (ops.gemm_mode(L))
+        # op classes (bits of ops.RANGE_TAGS) that run on the exact fp32-MFMA kernels although the complex is large enough for the split-f16
+        # ones: set by ScoreNetwork when such a class left the split ranges (per class, not per call: everything else stays split-f16)
+        self.exact_tags = 0
+        self.plain_class = 'gemm'    # range class of the plain GEMMs being issued: 'gemm' in front of the pair stack, 'gemm_late' behind it
 
         def lin(name, key=None):
             key = key or name
@@ -76,6 +80,10 @@ class Packed:
 
     def ln(self, name):
         return self.sd[name + '.weight'], self.sd[name + '.bias']
+
+    def exact(self, *classes):
+        """True when the ops of (one of) the named range classes must run on the exact kernels in this pass."""
+        return ops.GEMM_EXACT or self.gemm_mode != 2 or any(self.exact_tags & ops.RANGE_TAGS[c] for c in classes)
 
     def ln_linear(self, key, ln_name):
         """LayerNorm folded into the following Linear for abx_gemm's algebraic-LN epilogue:
@@ -221,7 +229,8 @@ class Workspace:
 
 
 def _lin(P, name, x, out, narrow=False, **kw):
-    kw.setdefault('exact', P.gemm_mode)
+    kw.setdefault('exact', 1 if P.exact(P.plain_class) else 2)
+    kw.setdefault('range_class', P.plain_class)
     w3 = P.split(name)
     if narrow and w3 is None and kw['exact'] == 2:
         w3 = P.split_narrow(P.wt[name], name)
@@ -231,7 +240,8 @@ def _lin(P, name, x, out, narrow=False, **kw):
 def _ln_lin(P, name, ln_name, stats, x, out, narrow=False, **kw):
     """out = epi(LN(x) @ W^T + b) with the LayerNorm folded into the GEMM epilogue."""
     wt, csum, bias, w3 = P.ln_linear(name, ln_name)
-    kw.setdefault('exact', P.gemm_mode)
+    kw.setdefault('exact', 1 if P.exact(P.plain_class) else 2)
+    kw.setdefault('range_class', P.plain_class)
     if narrow and w3 is None and kw['exact'] == 2:
         w3 = P.split_narrow(wt, (name, ln_name))
     return ops.gemm(x, wt, out, bias=bias, ln=(stats, csum), B3=w3, **kw)
@@ -258,6 +268,23 @@ class Engine:
         # squared distogram breaks exactly as torch computes them on the host (common_modules.py:108-109)
         self.sq_breaks = torch.square(torch.linspace(pp.min_bin, pp.max_bin, steps=pp.num_bins - 1)).to(device)
 
+    def _block_workspace(self, group, Bc, L):
+        """Workspace of an op group ('attn' / 'mul') for a chunk of Bc samples: one buffer per (group, L), sized for the largest chunk
+        asked for so far.  The tri-mul workspace's operand-image region must read zero in its pad k-tiles and its layout depends on the
+        chunk size: switching sizes re-zeroes it (only when ceil4(L) % 16 != 0: otherwise there are no pad k-tiles)."""
+        key = (group, L)
+        hit = self._blk_ws.get(key)
+        if hit is None or hit[1] < Bc:
+            self._blk_ws = {k: v for k, v in self._blk_ws.items() if k[0] != group}       # another L (another complex): release first
+            buf = ops.tri_attn_block_workspace(Bc, L, self.dev) if group == 'attn' else ops.tri_mul_workspace(Bc, L, self.dev)
+            hit = [buf, Bc, Bc]
+            self._blk_ws[key] = hit
+        elif group == 'mul' and hit[2] != Bc:
+            if ((L + 3) // 4 * 4) % 16 != 0:
+                ops.tri_mul_workspace_init(hit[0], Bc, L)
+            hit[2] = Bc
+        return hit[0]
+
     # ------------------------------------------------------------------------------------------------------------
     # trajectory-invariant encoders (encoder.py:123-269 + seqformer.py:177-206)
     # ------------------------------------------------------------------------------------------------------------
@@ -268,6 +295,7 @@ class Engine:
         seq = batch['seq'][sl].long().contiguous()
         B, L = seq.shape
         P.gemm_mode = ops.gemm_mode(L)
+        P.plain_class = 'gemm'
         Lab = batch['anchor_flag'].shape[1]
         mask = torch.logical_and(batch['mask'][sl], batch['fixed_mask'][sl].bool())
         mask_f = mask.float().contiguous()
@@ -340,6 +368,7 @@ class Engine:
         Bc = b1 - b0
         L, Lab = st['L'], st['Lab']
         P.gemm_mode = ops.gemm_mode(L)
+        P.plain_class = 'gemm'
         packs = P.block_packs()          # (built once; both ways of issuing the op groups below read these buffers)
         blocks = packs if self.block_api else None
         M1, M2, LL = Bc * L, Bc * L * L, L * L
@@ -374,13 +403,12 @@ class Engine:
         s2 = seq_act.view(M1, WS_)
         z2 = pair_act.view(M2, WZ)
         z3 = pair_act.view(Bc, LL, WZ)
-        if self.block_api and (P.gemm_mode == 2 or L <= 389):
-            # the 768-wide scratch IS the q | k | v | gate region at the head of the triangle-attention block workspace (no second copy)
-            key = ('attn', Bc, L)
-            if key not in self._blk_ws:
-                self._blk_ws = {k: v for k, v in self._blk_ws.items() if k[0] != 'attn'}
-                self._blk_ws[key] = ops.tri_attn_block_workspace(Bc, L, self.dev)
-            w768 = self._blk_ws[key][:M2 * 768 * 4].view(torch.float32).view(M2, 768)
+        if self.block_api:
+            # the 768-wide scratch IS the q | k | v (+ exact-path hidden) region at the head of the triangle-attention block workspace (no
+            # second copy).  One workspace per (group, L), sized for the LARGEST chunk seen and reused by smaller ones (the last chunk of a
+            # batch that the chunk size does not divide: keyed by the chunk size the multi-GB buffers were freed and re-allocated twice per pass)
+            attn_ws = self._block_workspace('attn', Bc, L)
+            w768 = attn_ws[:M2 * 768 * 4].view(torch.float32).view(M2, 768)
         else:
             w768 = ws.get('w768', (M2, 768))
         w384 = ws.get('w384', (M2 * 384,))
@@ -419,7 +447,7 @@ class Engine:
         # up to 4 (m' = i*Lp + j), so that plane rows, float4 stores and the channel-major product stay 16-byte aligned; the
         # projections read / the output projection writes the unpadded pair tensor through the row maps a_pair / c_pair, and
         # the padded row scale zeroes the pad columns of the contraction operands.
-        planes = P.gemm_mode == 2
+        planes = not P.exact('plane_projection', 'contraction', 'tri_mul_tail')
         Lp = (L + 3) // 4 * 4
         LLp = L * Lp
         pad = (L, Lp) if Lp != L else None
@@ -427,13 +455,9 @@ class Engine:
             pre = P_BLK + name + '.'
             if blocks is not None and planes:
                 # one call of the C ABI per module: out-of-place (z3 -> the 768-wide workspace -> z3 for the two variants)
-                key = ('mul', Bc, L)
-                if key not in self._blk_ws:
-                    self._blk_ws = {k: v for k, v in self._blk_ws.items() if k[0] != 'mul'}
-                    self._blk_ws[key] = ops.tri_mul_workspace(Bc, L, self.dev)
                 zb = w768.view(-1)[:Bc * LL * 192].view(Bc, LL, 192)
                 zin, zout = (z3, zb) if outgoing else (zb, z3)
-                ops.tri_mul_fwd(blocks[name], zin, zout, mask_f, Bc, L, outgoing, self._blk_ws[key])
+                ops.tri_mul_fwd(blocks[name], zin, zout, mask_f, Bc, L, outgoing, self._block_workspace('mul', Bc, L))
                 continue
             # sigmoid(left_gate | right_gate) channel-major like the projections they gate; sigmoid(final_gate) row-major
             GT = w768.view(-1)[:Bc * 256 * LL].view(Bc, 256, LL)
@@ -485,16 +509,19 @@ class Engine:
         # ---------------- triangle attention (seqformer.py:506-550)
         for name, per_row in (('triangle_attention_starting_node', True), ('triangle_attention_ending_node', False)):
             pre = P_BLK + name + '.'
-            if blocks is not None and (P.gemm_mode == 2 or L <= 389):
-                key = ('attn', Bc, L)
-                ops.tri_attn_block_fwd(blocks[name], z2, mask_f, Bc, L, per_row, self._blk_ws[key], exact=P.gemm_mode != 2)
+            ax = P.exact('tri_attn')                       # (small complexes: exact GEMMs - too few rows for the split tiles - and the
+            if blocks is not None:                          # split-f16 attention, which has no size limit; a flagged class: all exact)
+                flagged = bool(P.exact_tags & ops.RANGE_TAGS['tri_attn'])
+                ops.tri_attn_block_fwd(blocks[name], z2, mask_f, Bc, L, per_row, attn_ws, exact=ax, attn_exact=ops.GEMM_EXACT or flagged)
                 continue
+            am = 1 if ax else 2
+            ae = True if (P.exact_tags & ops.RANGE_TAGS['tri_attn']) else None
             # q | k | v and the pair bias (b, h, i, j) read the same LayerNorm(z) rows: one launch, the bias columns in the free half of the
             # projection's last column tile (ops.gemm_side; two launches when the pair does not qualify - exact arithmetic, small problems)
             bT = ws.get('biasT', (Bc, 4, LL))
             qkv = w768.view(-1)[:M2 * 576].view(M2, 576)
-            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True),
-                          _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True))
+            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True, exact=am),
+                          _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True, exact=am))
             o = w384[:M2 * 192].view(M2, 192)
             # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
             # i.e. the transpose (2 MB per sample); starting node: a padded copy only when L % 4 != 0
@@ -504,26 +531,28 @@ class Engine:
                 bT = bT2
             else:
                 bT = bT.view(Bc, 4, L, L)
-            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True)       # (no gate: the tail applies it)
-            if P.gemm_mode == 2:
+            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True, exact=ae)       # (no gate: the tail applies it)
+            if not ax:
                 # gate projection, sigmoid, * attention output, output projection, + residual in ONE kernel (AbxGemm.mlp = 2)
-                _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, z2, act=2, gate=o, resid=z2, mlp=P.mlp_second(pre + 'attn.proj_out'))
+                _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, z2, act=2, gate=o, resid=z2, mlp=P.mlp_second(pre + 'attn.proj_out'), exact=2)
             else:
                 hid = w768.view(-1)[M2 * 576:M2 * 768].view(M2, 192)
-                _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, hid, act=2, gate=o, gate_sigmoid=False)
-                _lin(P, pre + 'attn.proj_out', hid, z2, resid=z2)
+                _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, hid, act=2, gate=o, gate_sigmoid=False, exact=1)
+                _lin(P, pre + 'attn.proj_out', hid, z2, resid=z2, exact=1)
         # ---------------- pair transition
         pre = P_BLK + 'pair_transition.transition.'
+        tx = P.exact('pair_transition')
         if blocks is not None:
-            ops.transition_fwd(*blocks['pair_transition'], z2, exact=P.gemm_mode != 2, workspace=w768)
-        elif P.gemm_mode == 2:
+            ops.transition_fwd(*blocks['pair_transition'], z2, exact=tx, workspace=w768)
+        elif not tx:
             # LayerNorm -> Linear -> ReLU -> Linear + residual in ONE kernel: the 768-wide hidden never travels through HBM
-            _ln_lin(P, pre + '1', pre + '0', None, z2, z2, act=1, resid=z2, mlp=P.mlp_second(pre + '3'))
+            _ln_lin(P, pre + '1', pre + '0', None, z2, z2, act=1, resid=z2, mlp=P.mlp_second(pre + '3'), exact=2)
         else:
-            _ln_lin(P, pre + '1', pre + '0', None, z2, w768, act=1)
-            _lin(P, pre + '3', w768, z2, resid=z2)
+            _ln_lin(P, pre + '1', pre + '0', None, z2, w768, act=1, exact=1)
+            _lin(P, pre + '3', w768, z2, resid=z2, exact=1)
 
         # ================= IpaScore (score_network.py:83-196)
+        P.plain_class = 'gemm_late'
         ic = cfg.heads.diffusion_module.IPA
         NC = ic.num_channel
         s_pre = ws.get('i_a', (M1, NC))
@@ -533,11 +562,11 @@ class Engine:
         s = ws.get('i_s', (M1, NC))
         _lin(P, P_IPA + 'proj_seq', s0, s)
         zi = w384[:M2 * 128].view(M2, 128)
-        if P.gemm_mode == 2:
+        if not P.exact('ipa_pair_init'):
             # Linear -> LayerNorm in one kernel (the 128 output channels of a row sit in one wave tile of the split-f16 GEMM)
-            _lin(P, P_IPA + 'proj_init_pair_act', z2, zi, out_ln=P.ln(P_IPA + 'init_pair_layer_norm'))
+            _lin(P, P_IPA + 'proj_init_pair_act', z2, zi, out_ln=P.ln(P_IPA + 'init_pair_layer_norm'), exact=2)
         else:
-            _lin(P, P_IPA + 'proj_init_pair_act', z2, zi)
+            _lin(P, P_IPA + 'proj_init_pair_act', z2, zi, exact=1)
             ops.layernorm(zi, *P.ln(P_IPA + 'init_pair_layer_norm'), out=zi)
         bias2d = w384[M2 * 128:M2 * 140].view(M2, 12)
         _lin(P, P_IPA + 'attention_module.proj_pair', zi, bias2d, alpha=P.ipa_w2d, narrow=True)
@@ -553,7 +582,7 @@ class Engine:
         h1 = ws.get('i_h1', (M1, NC)); h2 = ws.get('i_h2', (M1, NC))
         upd = ws.get('i_upd', (M1, 6))
         tail = None
-        if P.gemm_mode == 2 and NC == 256:
+        if not P.exact('ipa_tail', 'gemm_late') and NC == 256:
             wb = lambda n: (P.split(P_IPA + n), P.b[P_IPA + n])
             tail = (wb('attention_module.final_proj'), P.ln(P_IPA + 'attention_layer_norm'), wb('transition_module.0'),
                     wb('transition_module.2'), wb('transition_module.4'), P.ln(P_IPA + 'transition_layer_norm'))
@@ -570,7 +599,7 @@ class Engine:
                 # depend on how many samples share the launch
                 part = None
                 if self.ipa_splitk and ifeat.shape[1] % (16 * self.ipa_splitk) == 0:
-                    part = ops.gemm_splitk(ifeat, tail[0][0], ws.get('i_part', (self.ipa_splitk, M1, NC)))
+                    part = ops.gemm_splitk(ifeat, tail[0][0], ws.get('i_part', (self.ipa_splitk, M1, NC)), range_class='gemm_late')
                 ops.ipa_tail(ifeat, s, *tail, affine=(P.wt[P_IPA + 'affine_update'], P.b[P_IPA + 'affine_update']),
                              rigid=(fixed.reshape(-1), init_q, init_t, cur_q, cur_t, cur_R, delta_q, ic.position_scale), partial=part)
                 continue
@@ -590,7 +619,7 @@ class Engine:
         logits = st['logits'][b0:b1]
         pl = ws.get('h_pl', (M1, 50))
         # torsion ResNet + SequenceHead MLP (+ PredictedLDDTHead MLP on the last pass) in ONE launch: 13 (18) launches otherwise
-        heads = P.heads_pack() if (self.fused_heads and P.gemm_mode == 2 and NC == 256 and ic.torsion.num_residual_block == 2 and
+        heads = P.heads_pack() if (self.fused_heads and not P.exact('heads_tail', 'gemm_late') and NC == 256 and ic.torsion.num_residual_block == 2 and
                                    logits.is_contiguous()) else None
         if heads is not None:
             ops.heads_tail(s, s0, heads[0], heads[1], heads[2], un, logits.view(M1, 20), pl if final else None)

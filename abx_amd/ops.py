@@ -34,24 +34,52 @@ GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
 # abx_amd.model.abx.ScoreNetwork clears the word before a network call, reads it after, and repeats the call on the exact fp32-MFMA
 # kernels when it is set, so the range contract of the fast path never reaches a caller as a wrong or non-finite result.
 RANGE_TAGS = {'gemm': 1, 'contraction': 2, 'plane_projection': 4, 'tri_mul_tail': 8, 'pair_transition': 16, 'ipa_pair_init': 32,
-              'tri_attn': 64, 'ipa_tail': 128, 'heads_tail': 256}
+              'tri_attn': 64, 'ipa_tail': 128, 'heads_tail': 256, 'gemm_late': 512}     # gemm / gemm_late: the plain GEMMs in front of / behind the pair stack
 RANGE_CHECK = not bool(__import__('os').environ.get('ABX_NO_RANGE_CHECK'))     # (A / B measurements of the probe's cost)
 _range_words = {}
 
 
-def range_word(device):
-    """The int32 [1] range word of a device (created on first use, zero)."""
+RANGE_SLOTS = 4
+RANGE_SLOT = 0       # which of the device's range words the launches issued now report to (ScoreNetwork: one word per network pass, so that
+                     # the pass - and with ops.RANGE_ORDER the op class - that left the range FIRST is known from one read-back per call)
+
+
+def range_words(device):
+    """The int32 [RANGE_SLOTS] range words of a device (created on first use, zero)."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     w = _range_words.get(idx)
     if w is None:
-        w = torch.zeros(1, dtype=torch.int32, device=torch.device('cuda', idx))
+        w = torch.zeros(RANGE_SLOTS, dtype=torch.int32, device=torch.device('cuda', idx))
         _range_words[idx] = w
     return w
 
 
+def range_word(device):
+    """The first range word (int32 [1] view): what every launch reports to unless ops.RANGE_SLOT says otherwise."""
+    return range_words(device)[0:1]
+
+
+def range_ptr(device):
+    """Device address of the range word in use (ops.RANGE_SLOT)."""
+    return range_words(device).data_ptr() + 4 * RANGE_SLOT
+
+
 def range_names(bits):
     return [n for n, b in RANGE_TAGS.items() if bits & b]
+
+
+# order in which the op classes appear in a network pass: a class that left its range hands NaN rows to every class after it, so of the
+# bits a call sets only the FIRST one names an op that needs the exact kernels (abx_amd.model.abx.ScoreNetwork.forward)
+RANGE_ORDER = ('gemm', 'plane_projection', 'contraction', 'tri_mul_tail', 'tri_attn', 'pair_transition', 'ipa_pair_init', 'gemm_late', 'ipa_tail', 'heads_tail')
+
+
+def first_range_tag(bits, skip=0):
+    """The bit of the earliest op class of a pass among `bits` that is not in `skip`, or 0."""
+    for n in RANGE_ORDER:
+        if bits & RANGE_TAGS[n] & ~skip:
+            return RANGE_TAGS[n]
+    return 0
 
 
 GEMM_EXACT = False   # True: every GEMM on the exact fp32 MFMA kernel (v_mfma_f32_32x32x2_f32); default: large problems on the
@@ -90,6 +118,31 @@ def gemm_kernel_name(M, N, K, batch, a_kcontig=True, b_ncontig=True, transposed=
     else:
         cfg = (128, 128, 64, 64, 3)
     return f'gemm_kernel<{cfg[0]}, {cfg[1]}, {cfg[2]}, {cfg[3]}, 16, {b(a_kcontig)}, {b(b_ncontig)}, {b(transposed)}, {cfg[4]}>'
+
+
+def gemm_as_kernel_name(g, side=None):
+    """Name of the A-stationary kernel instantiation (csrc/gemm_as.hip) that abx_gemm / abx_gemm_side launch for a filled descriptor, or
+    None when the problem goes to the tile kernels (mirror of abx_gemm_as_dispatch; alignment is taken for granted: the tensors of
+    model/forward.py are 16-byte aligned)."""
+    if GEMM_EXACT or (g.tune & 2048) or g.exact == 1 or not g.B_split or not g.b_f16 or g.A_split or not g.A or g.sAk != 1 or g.K != 192:
+        return None
+    if g.A2 or g.out_ln_w or g.mlp or g.ln_stats or g.gate or g.resid or g.batch_inner or not g.ln_csum or not g.bias or g.act != 0 or g.alpha != 1.0:
+        return None
+    ntm = (g.M + 63) // 64
+    if g.N < 256 or ntm * g.batch < 1024:
+        return None
+    if g.glu:
+        if side is not None or not g.C_split or not g.c_split_tile or not g.c_transposed or g.N % 128 != 0 or not g.a_pair or g.pair_Lp <= 0:
+            return None
+        return 'gemm_as_kernel<1, false, 0>'
+    if g.c_transposed or g.C_split or g.rowscale or g.a_pair_transpose > 0 or g.pair_Lp != 0 or g.batch != 1 or g.N % 64 != 0:
+        return None
+    if side is not None:
+        s2 = side
+        if g.N % 128 != 64 or not s2.B_split or not s2.c_transposed or s2.N > 32 or s2.K != g.K or s2.M * s2.batch != g.M or s2.act != 0 or s2.exact == 1:
+            return None
+        return 'gemm_as_kernel<0, true, 0>'
+    return 'gemm_as_kernel<0, false, 0>'
 
 
 SPLIT_MIN_L = 64
@@ -176,7 +229,7 @@ def _weight_planes(w3, N, K=None, what='B3'):
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
          resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0, c_split_tile=False,
-         defer=False):
+         defer=False, range_class=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -292,9 +345,9 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         g.b_f16, g.b_exp = 1, B3.w_exp
     g.tune = GEMM_TUNE if tune is None else tune
     if RANGE_CHECK and g.exact != 1:
-        g.range_flag = range_word(Cout.device).data_ptr()
+        g.range_flag = range_ptr(Cout.device)
         g.range_tag = RANGE_TAGS[('tri_attn' if gate is not None else 'pair_transition') if mlp is not None else 'tri_mul_tail' if dual is not None else 'ipa_pair_init' if out_ln is not None
-                                 else 'plane_projection' if c_planes else 'contraction' if a_planes else 'gemm']
+                                 else 'plane_projection' if c_planes else 'contraction' if a_planes else (range_class or 'gemm')]
     if dual is not None:
         A2, B32, csum2, bias2 = dual
         if A2.dim() == 2:
@@ -447,7 +500,7 @@ class LinearPack:
 
 def _range_args(exact, name):
     if RANGE_CHECK and not exact:
-        return range_word(torch.device('cuda', torch.cuda.current_device())).data_ptr(), RANGE_TAGS[name]
+        return range_ptr(torch.device('cuda', torch.cuda.current_device())), RANGE_TAGS[name]
     return None, 0
 
 
@@ -478,6 +531,11 @@ def tri_mul_workspace(B, L, device):
     ws = ws[(-ws.data_ptr()) % 256:]
     check(lib.abx_tri_mul_workspace_init(_p(ws), B, L, _stream()), 'abx_tri_mul_workspace_init')
     return ws
+
+
+def tri_mul_workspace_init(ws, B, L):
+    """Zero the operand-image region of a tri-mul workspace for the layout of B samples (a buffer reused with another chunk size)."""
+    check(_lib.load().abx_tri_mul_workspace_init(_p(ws), B, L, _stream()), 'abx_tri_mul_workspace_init')
 
 
 def tri_mul_fwd(pack, z_in, z_out, mask_f, B, L, outgoing, workspace):
@@ -551,7 +609,7 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.exact = int(GEMM_EXACT if exact is None else exact)
     a.tune = int(tune)
     if RANGE_CHECK and not a.exact:
-        a.range_flag, a.range_tag = range_word(out.device).data_ptr(), RANGE_TAGS['tri_attn']
+        a.range_flag, a.range_tag = range_ptr(out.device), RANGE_TAGS['tri_attn']
     if clock_probe is not None:
         assert clock_probe.dtype == torch.int64 and clock_probe.numel() >= 2
         a.clock_probe = _p(clock_probe)
@@ -579,7 +637,7 @@ def ipa_pair(attn_ws, z, feat, B, L):
     check(_lib.load().abx_ipa_pair(_p(attn_ws), _p(z), _p(feat), B, L, _stream()), 'abx_ipa_pair')
 
 
-def gemm_splitk(A, w3, partial):
+def gemm_splitk(A, w3, partial, range_class='gemm'):
     """K-slice products of A (M, K) fp32 rows against split_weights planes w3 of a (K, N) weight: partial[s] = A[:, s*Ks:(s+1)*Ks] @
     W[s*Ks:(s+1)*Ks] for the S = partial.shape[0] slices (Ks = K / S a multiple of 16), ONE abx_gemm launch with batch = slice (operand
     windows by batch strides; split-f16 arithmetic).  The caller adds the slices in a fixed order (abx_ipa_tail's `partial` input): a
@@ -598,7 +656,7 @@ def gemm_splitk(A, w3, partial):
     g.M, g.N, g.K, g.batch = M, N, Ks, S
     g.alpha, g.exact = 1.0, 2
     if RANGE_CHECK:
-        g.range_flag, g.range_tag = range_word(A.device).data_ptr(), RANGE_TAGS['gemm']
+        g.range_flag, g.range_tag = range_ptr(A.device), RANGE_TAGS[range_class]
     check(_lib.load().abx_gemm(C.byref(g), _stream()), 'abx_gemm(split-K)')
     return partial
 
@@ -631,7 +689,7 @@ def ipa_tail(feat, s, w_final, ln1, w_t0, w_t2, w_t4, ln2, eps=1e-5, affine=None
         a.init_q, a.init_t, a.cur_q, a.cur_t, a.cur_R, a.delta_q = [_p(_f32(t)) for t in (init_q, init_t, cur_q, cur_t, cur_R, delta_q)]
         a.pscale = float(pscale)
     if RANGE_CHECK:
-        a.range_flag, a.range_tag = range_word(s.device).data_ptr(), RANGE_TAGS['ipa_tail']
+        a.range_flag, a.range_tag = range_ptr(s.device), RANGE_TAGS['ipa_tail']
     check(_lib.load().abx_ipa_tail(C.byref(a), _stream()), 'abx_ipa_tail')
     return s
 
@@ -681,7 +739,7 @@ def heads_tail(s, s0, torsion, seq_head, plddt_head, un, logits, pl=None, eps=1e
         a.pl = _p(_f32(pl))
     a.ln_eps = float(eps)
     if RANGE_CHECK:
-        a.range_flag, a.range_tag = range_word(s.device).data_ptr(), RANGE_TAGS['heads_tail']
+        a.range_flag, a.range_tag = range_ptr(s.device), RANGE_TAGS['heads_tail']
     check(_lib.load().abx_heads_tail(C.byref(a), _stream()), 'abx_heads_tail')
 
 

@@ -48,6 +48,7 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
         if opt_step < 1.0:
             steps = steps[steps <= opt_step + eps]
     batch.pop('_static', None)          # trajectory-invariant embeddings: rebuilt once per trajectory from THIS batch
+    log_start = len(getattr(model, 'range_log', None) or [])     # (the model's range log is cumulative: report this trajectory's part)
     traj = []
     with torch.no_grad():
         if sc_conf.embed.embed_self_conditioning and self_condition and len(steps) > 0:
@@ -105,8 +106,8 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
                          f'(grid of {num_t} points on [{min_t}, 1])')
     check_finite(batch['rigids_t'], traj[-1]['atom14_results'])
     log = getattr(model, 'range_log', None)
-    if log:
-        traj[-1]['range_fallbacks'] = list(log)         # passes repeated on the exact kernels (which call, which op classes)
+    if log and len(log) > log_start:
+        traj[-1]['range_fallbacks'] = list(log[log_start:])     # calls of THIS trajectory repeated with an op class on the exact kernels
     return traj
 
 
@@ -163,7 +164,7 @@ def plan_work_units(costs, num_samples, world_size, min_block=50, force=False):
     of each complex keeps every GPU busy)."""
     units = []
     for j, c in enumerate(costs):
-        nb = max(1, num_samples // min_block)
+        nb = max(1, num_samples // max(1, int(min_block)))
         for r in range(nb):
             ids = shard_sample_ids(num_samples, r, nb)
             if ids:

@@ -86,24 +86,30 @@ class OpTimer:
             M, K = A.shape[-2], A.shape[-1]
             N = B.shape[-1]
             c_planes = C.dtype == torch.int16
-            if kw.get('mlp') is not None:       # fused transition: both layers' flops, rows in + rows out of HBM
+            if kw.get('mlp') is not None:       # fused transition / gated attention tail: both layers' flops, rows in + rows out of HBM
                 N2 = kw['mlp'][0].shape[2]
-                return 'gemm3_mlp_kernel<2>', 2.0 * nb * M * N * (K + N2), 4.0 * nb * M * (K + 2 * N2) + 4.0 * N * (K + N2)
+                if kw.get('gate') is not None:  # (z rows for the gate and the residual once, the attention output, the rows out)
+                    return 'gemm3_gtail_kernel', 2.0 * nb * M * N * (K + N2), 4.0 * nb * M * (K + N + N2) + 4.0 * N * (K + N2)
+                return 'gemm3_mlp_kernel<2>', 2.0 * nb * M * N * (K + N2), 4.0 * nb * M * (K + N2) + 4.0 * N * (K + N2)
+            desc = self.saved['gemm'](*args, **dict(kw, defer=True))            # the filled descriptor, nothing launched
+            kas = self.ops.gemm_as_kernel_name(desc)
+            if kas is not None:                 # A-stationary kernel (glu: N / 2 output channels as 4-byte operand-image elements)
+                return kas, 2.0 * nb * M * N * K, 4.0 * nb * M * K + 4.0 * nb * M * (N // 2 if kw.get('glu') else N) + 4.0 * K * N
             kern = self.ops.gemm_kernel_name(M, N, K, nb, A.stride(-1) == 1, B.stride(-1) == 1, c_planes or C.stride(-1) != 1,
                                              split=kw.get('B3') is not None, exact=kw.get('exact'), dual=kw.get('dual') is not None,
                                              out_ln=kw.get('out_ln') is not None)
             K2 = kw['dual'][0].shape[-1] if kw.get('dual') is not None else 0
             return kern, 2.0 * nb * M * N * (K + K2), 4.0 * nb * (M * (K + K2)) + 4.0 * nb * M * N + 4.0 * (K + K2) * N
-        if name == 'gemm_side':             # (main, side) descriptors in one launch
+        if name == 'gemm_side':             # (main, side) descriptors in one launch: the rows are read once for both products
             fl = sum(2.0 * d.batch * d.M * d.N * d.K for d in args[:2])
-            by = sum(4.0 * d.batch * d.M * (d.K + d.N) for d in args[:2])
-            return 'gemm3_side_kernel', fl, by
+            by = 4.0 * args[0].batch * args[0].M * args[0].K + sum(4.0 * d.batch * d.M * d.N for d in args[:2])
+            return (self.ops.gemm_as_kernel_name(args[0], args[1]) or 'gemm3_side_kernel'), fl, by
         if name == 'gemm_splitk':
             S, M, N = args[2].shape
             return 'gemm3 split-K (K slices as batch)', 2.0 * M * N * args[0].shape[1], 4.0 * M * (args[0].shape[1] + S * N)
         if name == 'tri_attn':
             Bc, L = args[4], args[5]
-            return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (4 * 192 + 192 + 4)
+            return self.ops.tri_attn_kernel_name(L, kw.get('exact')), 4.0 * Bc * L * 4 * L * L * 48, 4.0 * Bc * L * L * (args[0].shape[1] + 192 + 4)
         if name == 'ipa_tail':
             M, K1 = args[0].shape
             return 'ipa_tail_kernel', 2.0 * M * 256 * (K1 + 3 * 256), 4.0 * M * (K1 + 2 * 256) + 4.0 * 256 * (K1 + 3 * 256)
@@ -120,7 +126,7 @@ class OpTimer:
         return name, 0.0, 0.0
 
     def __enter__(self):
-        skip = ('gemm_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table',
+        skip = ('gemm_kernel_name', 'gemm_as_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table',
                 'range_word', 'range_names', 'pad_planes_128')       # (host-side helpers: no launch to time)
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
@@ -549,24 +555,45 @@ def main():
         tot_ms = sum(s[1] for s in summ)
         name, ms, calls, fl, by = summ[0]
         dur = ms / 1e3                      # all launches of the kernel in one step; fl / by are summed over them too
-        if name.startswith('ipa_') and name != 'ipa_tail_kernel':
-            roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
-        elif name.startswith('gemm3_') or name.startswith('tri_attn4') or name.startswith('tri_attn8'):
-            # algorithmic fp32 flops against the matrix-core peak for this arithmetic: every fp32 product costs three f16 MFMA
-            # products, so the ceiling is the dense f16 peak / 3
-            roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_SPLIT_PEAK_TF, 'unit': 'TFLOP/s',
-                    'peak_note': 'dense f16 MFMA peak 2516.6 TF / 3 products per fp32 product (split-f16); '
-                                 f'{fl / dur / 1e12 / MFMA_F32_PEAK_TF:.2f} of the native fp32 MFMA peak 157.3 TF'}
+        # which roof binds is decided by the kernel's ALGORITHMIC intensity against the ridge of its arithmetic:
+        # split-f16 kernels price an fp32 flop at three f16 MFMA products (ceiling = dense f16 peak / 3), everything else at the native
+        # fp32 MFMA / VALU peak; both fractions are reported, `frac` is the binding one
+        split = name.startswith(('gemm3_', 'gemm_as_', 'tri_attn4', 'tri_attn8'))
+        peak_tf = MFMA_SPLIT_PEAK_TF if split else MFMA_F32_PEAK_TF
+        ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+        intensity = fl / by if by else float('inf')
+        frac_mfma, frac_hbm = fl / dur / 1e12 / peak_tf, by / dur / 1e9 / HBM_PEAK_GBS
+        if intensity < ridge:
+            roof = {'bound': 'hbm', 'achieved': by / dur / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': frac_hbm}
         else:
-            roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s'}
+            roof = {'bound': 'mfma', 'achieved': fl / dur / 1e12, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': frac_mfma}
+        roof.update(intensity_flop_per_byte=intensity, ridge_flop_per_byte=ridge, frac_mfma=frac_mfma, frac_hbm=frac_hbm,
+                    achieved_tflops=fl / dur / 1e12, achieved_gbs=by / dur / 1e9,
+                    peak_note=('matrix peak for this arithmetic: dense f16 MFMA 2516.6 TF / 3 products per fp32 product (split-f16) = 838.9 TF'
+                               if split else 'matrix peak: native fp32 MFMA 157.3 TF'))
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc):             # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
-            traffic = json.load(open(pmc)).get(name, {}).get('hbm_bytes_per_launch')
-        roof.update(frac=roof['achieved'] / roof['peak'], traffic=traffic, kernel=name, calls_per_step=calls,
+        pmc_tab = json.load(open(pmc)) if os.path.exists(pmc) else {}
+        if pmc_tab:                         # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
+            traffic = pmc_tab.get(name, {}).get('hbm_bytes_per_launch')
+        roof.update(traffic=traffic, kernel=name, calls_per_step=calls,
                     avg_launch_ms=ms / calls, share_of_step=ms / tot_ms,
                     traffic_source=('profiles/pmc_traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes at the '
                                     'bench geometry (FETCH_SIZE x 2 + WRITE_SIZE); NOT collected in this run') if traffic is not None else None)
+        # whole-step counter traffic: launches of this step x the per-launch HBM bytes of the same PMC table (kernels of the op profile
+        # that the table knows; the share of the step time they cover is reported next to it)
+        if pmc_tab:
+            tb, covered = 0.0, 0.0
+            for nm, ms_, calls_, _, _ in summ:
+                t_ = pmc_tab.get(nm, {}).get('hbm_bytes_per_launch')
+                if t_ is not None:
+                    tb += t_ * calls_
+                    covered += ms_
+            result['step_traffic_bytes'] = tb
+            result['step_traffic_note'] = (f'sum over the kernels of one step of launches x HBM bytes per launch (profiles/pmc_traffic.json, rocprofv3 --pmc '
+                                           f'FETCH_SIZE x 2 + WRITE_SIZE at the bench geometry); covers {covered / tot_ms:.3f} of the step time; algorithmic '
+                                           f'bytes of the step: {B0 * algorithmic_bytes_per_sample_step(L):.4g}')
+            result['step_traffic_over_algorithmic'] = tb / (B0 * algorithmic_bytes_per_sample_step(L))
         result['roofline'] = roof
         # the kernel north_star calls HBM-bound (the IPA pair-slab stream), priced the same way next to the dominant one
         for nm, ms2, calls2, fl2, by2 in summ:

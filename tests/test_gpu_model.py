@@ -278,6 +278,12 @@ def test_out_of_range_activations_fall_back_to_the_exact_kernels(params, cfg, or
     assert len(model.range_log) >= 1, 'the scaled projections did not leave the split range: the test does not test'
     seen = set(sum((e['ops'] for e in model.range_log), []))
     assert 'tri_attn' in seen and ('contraction' in seen or 'tri_mul_tail' in seen), model.range_log
+    # per op class (round 5): only the classes that left the range went exact - the triangle multiplication's contraction first (its
+    # repeat still flagged the attention, which joined) - never the pair transition, the IPA tail or the heads
+    ex = set(model.range_log[-1]['exact_ops'])
+    assert 'tri_attn' in ex and ex & {'contraction', 'plane_projection', 'tri_mul_tail'}, model.range_log
+    assert not ex & {'pair_transition', 'ipa_tail', 'heads_tail', 'ipa_pair_init', 'gemm'}, model.range_log
+    assert model.range_log[-1]['repeats'] == len(model.range_log[-1]['exact_ops'])
     ops.GEMM_EXACT = True
     try:
         rex = cp(model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}))
@@ -298,6 +304,70 @@ def test_out_of_range_activations_fall_back_to_the_exact_kernels(params, cfg, or
     n0 = len(m0.range_log)
     m0({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()})
     assert len(m0.range_log) == n0 == 0, m0.range_log
+
+
+def test_range_fallback_per_op_class_sticky_and_without_a_length_limit(params, cfg, oracle_diffuser, gpu_model):
+    """VERDICT r4 #4 / ADVICE r4: L = 416 (> 389: the exact attention kernel walks such rows in key chunks now - the reference's attention
+    has no length limit, seqformer.py:272-312).  (a) a key channel x 6000 flags the triangle attention: ONE repeat with only that class
+    exact, results = the oracle's; the second flagged call makes the class sticky (logged), the third runs without a repeat.
+    (b) a pair-transition hidden channel beyond 4094 flags that class only (the attention stays on the split-f16 kernel; round 4 aborted
+    here with 'L too large'); results = the forced-exact run of the same model."""
+    from collections import OrderedDict
+    from oracle import abx_oracle as O
+    from abx_amd import sampler, ops
+    from abx_amd.model.abx import ScoreNetwork
+    _, D = gpu_model
+    blk = 'impl.seqformer.seqformer.blocks.0.'
+    w = dict(L_heavy=120, L_light=110, L_antigen=186, cdr=(30, 39))
+    B = 1
+    b = _synthetic_batch(D, w, B=B)
+    assert b['seq'].shape[1] == 416
+    t_ = torch.full((B,), 0.4040404040404041, dtype=torch.float64, device=DEV)
+    b = sampler.set_t_feats(b, D, t_, torch.ones(B, device=DEV))
+    fresh = lambda: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+    cp = lambda d: {k: (cp(v) if isinstance(v, dict) else v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+    # ---- (a) attention
+    big = OrderedDict((k, v.clone()) for k, v in params.items())
+    ta = blk + 'triangle_attention_starting_node.attn.'
+    for h in range(4):
+        big[ta + 'proj_k.weight'][h * 48 + 3] *= 6000.0
+        big[ta + 'proj_q.weight'][h * 48 + 3] /= 6000.0
+    model = ScoreNetwork(cfg.model, D)
+    model.load_state_dict(big, strict=True)
+    model = model.to(DEV).eval()
+    ret = cp(model(fresh()))
+    assert len(model.range_log) == 1, model.range_log
+    e = model.range_log[0]
+    assert e['exact_ops'] == ['tri_attn'] and e['repeats'] == 1 and not e.get('sticky'), e
+    ref = O.score_network(big, _cpu_copy(b), cfg, oracle_diffuser)
+    close(ret['heads']['folding']['rigids'], ref['heads']['folding']['rigids'], 2e-4, 1e-4, 'rigids vs oracle (chunked exact attention)')
+    assert (ret['heads']['sequence_module']['seq_0'].cpu() == ref['heads']['sequence_module']['seq_0']).all()
+    ret2 = cp(model(fresh()))
+    assert len(model.range_log) == 2 and model.range_log[1].get('sticky') and model.range_log[1]['repeats'] == 1, model.range_log
+    ret3 = cp(model(fresh()))
+    assert len(model.range_log) == 2, 'a sticky class must not be flagged (or repeated) again'
+    for r in (ret2, ret3):
+        assert torch.equal(r['heads']['folding']['rigids'], ret['heads']['folding']['rigids'])
+
+    # ---- (b) pair transition: hidden channel 7 scaled up in the first layer, down in the second (the same function)
+    big = OrderedDict((k, v.clone()) for k, v in params.items())
+    tr = blk + 'pair_transition.transition.'
+    big[tr + '1.weight'][7] *= 3.0e4
+    big[tr + '1.bias'][7] *= 3.0e4
+    big[tr + '3.weight'][:, 7] /= 3.0e4
+    model = ScoreNetwork(cfg.model, D)
+    model.load_state_dict(big, strict=True)
+    model = model.to(DEV).eval()
+    ret = cp(model(fresh()))
+    assert len(model.range_log) == 1 and model.range_log[0]['exact_ops'] == ['pair_transition'], model.range_log
+    ops.GEMM_EXACT = True
+    try:
+        rex = cp(model(fresh()))
+    finally:
+        ops.GEMM_EXACT = False
+    close(ret['heads']['folding']['rigids'], rex['heads']['folding']['rigids'], 2e-4, 1e-4, 'rigids vs forced exact')
+    assert torch.equal(ret['heads']['sequence_module']['seq_0'], rex['heads']['sequence_module']['seq_0'])
 
 
 def test_split_f16_short_trajectory_vs_oracle(gpu_model, params, cfg, oracle_diffuser):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Launch ONE of the dominant kernels a few times at the bench geometry, for rocprofv3 --pmc passes (tools/pmc_run.sh).
     python tools/pmc_kernels.py <which> [Bc] [L]
-which: qkvg (LN -> 768, gemm3 128x128)  mlp (fused transition)  trans2 (768 -> 192 + resid, gemm3 128x192)  glu (LN -> glu planes, transposed store)
+which: qkvg (LN -> 768, gemm3 128x128 tiles: tune 2048)  qkv (round 5: LN -> q | k | v 576 + pair-bias side, A-stationary kernel)
+       gtail (gated tail of the triangle attention, AbxGemm.mlp = 2)  mlp (fused transition)  trans2 (768 -> 192 + resid, gemm3 128x192)  glu (LN -> glu planes, transposed store)
        contract (plane x plane)  projout (channel-major A, gate, resid)  tri (triangle attention)  ipa (IPA attention)"""
 import os
 import sys
@@ -22,7 +23,20 @@ if which == 'qkvg':
     z, W = r(M2, 192), r(192, 768) / 14
     C, bias, csum, W3 = torch.empty(M2, 768, device=DEV), r(768), r(768), ops.split_weights(W)
     for _ in range(REPS):
-        ops.gemm(z, W, C, bias=bias, ln=(None, csum), B3=W3, exact=2)
+        ops.gemm(z, W, C, bias=bias, ln=(None, csum), B3=W3, exact=2, tune=2048)
+elif which == 'qkv':
+    z, W, Wp = r(M2, 192), r(192, 576) / 14, r(192, 4) / 14
+    C, bT = torch.empty(M2, 576, device=DEV), torch.empty(Bc, 4, LL, device=DEV)
+    bias, csum, W3, bp, csp, Wp3 = r(576), W.sum(0).contiguous(), ops.split_weights(W), r(4), Wp.sum(0).contiguous(), ops.split_weights(Wp)
+    for _ in range(REPS):
+        ops.gemm_side(ops.gemm(z, W, C, bias=bias, ln=(None, csum), B3=W3, exact=2, defer=True),
+                      ops.gemm(z.view(Bc, LL, 192), Wp, bT.transpose(1, 2), bias=bp, ln=(None, csp), B3=Wp3, exact=2, defer=True))
+elif which == 'gtail':
+    z, o, Wg, Wo = r(M2, 192), r(M2, 192), r(192, 192) / 14, r(192, 192) / 14
+    w3, wo3p = ops.split_weights(Wg), ops.split_weights(ops.permute_k16(Wo))
+    bg, cs, bo = r(192), Wg.sum(0).contiguous(), r(192)
+    for _ in range(REPS):
+        ops.gemm(z, Wg, z, bias=bg, ln=(None, cs), B3=w3, act=2, gate=o, resid=z, exact=2, mlp=(wo3p, bo))
 elif which == 'mlp':
     z, W1, W2 = r(M2, 192), r(192, 768) / 14, r(768, 192) / 28
     W13, W23p = ops.split_weights(W1), ops.split_weights(ops.permute_k16(W2))
@@ -55,7 +69,7 @@ elif which == 'projout':
     for _ in range(REPS):
         ops.gemm(tt.transpose(1, 2), W, z3, bias=r(192), ln=(None, W.sum(0).contiguous()), B3=W3, gate=Gf, gate_sigmoid=False, resid=z3, exact=2)
 elif which == 'tri':
-    x, bT, mask, o = r(M2, 768), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV), torch.empty(M2, 192, device=DEV)
+    x, bT, mask, o = r(M2, 576), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV), torch.empty(M2, 192, device=DEV)       # (q | k | v: no gate since round 5)
     for _ in range(REPS):
         ops.tri_attn(x, bT, mask, o, Bc, L, True, bias_is_qk=True)
 elif which == 'ipa':
