@@ -1258,6 +1258,68 @@ def test_rccl_collective_path_on_one_gpu(tmp_path):
     assert trees['plain'] == trees['rccl'], [k for k in trees['plain'] if trees['plain'][k] != trees['rccl'][k]]
 
 
+def test_configs_3_and_4_at_workload_shape_on_one_gpu(tmp_path):
+    """BASELINE configs 3 / 4 at their per-complex workload (100 samples per complex) on the one GPU a test box has.
+    Config 3 (inference.py:296-373 over a set): `design --name_idx` on the two shipped complexes x 100 samples with the SET-LEVEL schedule
+    (50-sample work units, RCCL initialised through torch.distributed.run, the designs table through the all-gather) writes the same file
+    tree - every PDB and TSV byte - as the sample-sharded scheme of a plain single process: a sample's trajectory does not depend on
+    which unit, block size or gather carried it.  Config 4 (optimize_steps = 10, guidance on, 100 samples of 6ct7): all coordinates
+    finite, only the diffused CDR-H3 window changes against the input, and the guided run differs from the un-guided one."""
+    import subprocess
+    import sys
+    from abx_amd.io.pdb_reader import read_pdb, chain_feature
+    from conftest import GOLDEN
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    launch = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29547']
+    idx = tmp_path / 'test.idx'
+    idx.write_text('6ct7_H_L_S\n6qd7_X_Z_F|E\n')
+    common = ['--name_idx', str(idx), '--data_dir', os.path.join(GOLDEN, 'npz'), '--gpu_list', '0', '--num_samples', '100', '--num_t', '8', '--mode', 'design']
+    trees, outs = {}, {}
+    for tag, cmd in (('set', launch + ['-m', 'abx_amd.design'] + common + ['--min_block', '50', '--force_collective']),
+                     ('shard', [sys.executable, '-m', 'abx_amd.design'] + common + ['--shard_samples'])):
+        od = str(tmp_path / tag)
+        r = subprocess.run(cmd + ['--output_dir', od], env=env, cwd=root, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-4000:]
+        outs[tag] = r.stdout
+        trees[tag] = {os.path.relpath(os.path.join(dp, f), od): open(os.path.join(dp, f), 'rb').read() for dp, _, fs in os.walk(od) for f in fs}
+    assert 'set-level schedule: 4 units' in outs['set'], outs['set'][-1500:]
+    assert sorted(trees['set']) == sorted(trees['shard']) and len(trees['set']) == 2 * 101 + 2
+    assert trees['set'] == trees['shard'], [k for k in trees['set'] if trees['set'][k] != trees['shard'][k]][:5]
+    tsvs = [k for k in trees['set'] if k.endswith('.tsv')]
+    assert len(tsvs) == 2
+    for k in tsvs:
+        rows = trees['set'][k].decode().splitlines()
+        assert len(rows) == 101 and [r.split('\t')[0] for r in rows[1:]] == [str(i) for i in range(100)]
+
+    # ---- config 4: one complex of the set, optimize mode from t = 0.10 with the violation guidance
+    from abx_amd import design
+    src = os.path.join(GOLDEN, 'pdb', '6ct7_H_L_S.pdb')
+    ref_h = chain_feature(read_pdb(src)['H'])
+    coords = {}
+    for tag, extra in (('guided', ['--guidance']), ('plain', [])):
+        out = str(tmp_path / ('opt_' + tag))
+        files = [f for f in design.main(['--pdb_file', src, '--num_samples', '100', '--mode', 'optimize', '--optimize_steps', '10', '--output_dir', out] + extra)
+                 if f.endswith('.pdb')]
+        assert len(files) == 100
+        hs = []
+        for f in files[::9]:
+            ch = read_pdb(f)
+            h = chain_feature(ch['H'])
+            assert list(ch) == ['H', 'L', 'S'] and len(h['str_seq']) == 113
+            assert np.isfinite(h['coords']).all() and float(np.abs(h['coords']).max()) < 500
+            diff = [i for i in range(113) if h['str_seq'][i] != ref_h['str_seq'][i]]
+            assert all(98 <= i <= 100 for i in diff), diff                    # only the diffused window of CDR-H3 may change
+            hs.append(h['coords'][:113, :4].copy())
+        coords[tag] = np.stack(hs)
+    fixed = [i for i in range(113) if not 98 <= i <= 100]
+    # fixed residues stay where they are: the same backbone in every sample, with and without guidance (3 decimals of a PDB file)
+    for tag in coords:
+        assert float(np.nanmax(np.abs(coords[tag][:, fixed] - coords['plain'][:1, fixed]))) < 2.1e-3, tag
+    coords = {k: v[:, 98:101] for k, v in coords.items()}
+    assert np.abs(coords['guided'] - coords['plain']).max() > 1e-3, 'the guidance changed nothing on the diffused residues'
+
+
 def test_results_do_not_depend_on_stale_lds(gpu_model, cfg):
     """No kernel may read LDS it has not written: one ScoreNetwork call (L = 112: split-f16 GEMMs, plane contraction, both
     attentions, IPA) is repeated with the LDS of every CU overwritten (abx_debug_poison_lds: NaN pattern, then large finite
