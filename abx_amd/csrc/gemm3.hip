@@ -563,10 +563,11 @@ __global__ __launch_bounds__(256, MINW) void gemm3_dual_kernel(const AbxGemm g) 
 // A is read from HBM once (the 6 chunk walks of a block hit the L2 / MALL), the hidden never leaves the CU, the output rows are
 // written once: 2 x 192 floats of HBM traffic per pair row instead of 2 x 192 + 2 x 768.
 constexpr int MLP_NH = 768;                                                  // widest hidden layer of the fused transition (LDS table)
-template <bool EDGE>
+// R1: stages of GEMM 1's operand ring (2: a step waits for the tiles it requested at its own start; 3: requested one step earlier, counted waits)
+template <bool EDGE, int R1 = 2>
 __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, int mt, int b) {
     constexpr int BM = 128, BN = 128, WM = 32, WN = 128, BN2 = 192, TN2 = BN2 / 32;
-    constexpr int G1_BYTES = 2 * BM * 64 + 2 * 2 * BN * 32;                  // stages of GEMM 1 (A fp32 + W1 planes)
+    constexpr int G1_BYTES = R1 * (BM * 64 + 2 * BN * 32);                   // stages of GEMM 1 (A fp32 + W1 planes)
     constexpr int B2_IMG = 2 * BN2 * 32;                                     // one k-tile of W2: [2][192][16] f16
     constexpr int NL2 = (B2_IMG + 4095) / 4096;
     char* W2s = reinterpret_cast<char*>(smem) + G1_BYTES;                    // 2 stages
@@ -607,14 +608,14 @@ __device__ __forceinline__ void gemm3_mlp_block(const AbxGemm& g, float* smem, i
         issue_w2(c * (BN / 16), 0);                                          // first W2 k-tile of the chunk: lands under GEMM 1
         f32x16 acc1[1][BN / 32];
         if (c == 0) {
-            gemm3_mainloop<BM, BN, WM, WN, 0, true, true>(g, smem, mt, c, b, acc1, ls, lq, lsh);
+            gemm3_mainloop<BM, BN, WM, WN, 0, true, true, R1>(g, smem, mt, c, b, acc1, ls, lq, lsh);
             // row statistics of this lane's row (the two lane halves hold the two k halves)
             const float invK = 1.0f / (float)g.K;
             const float sm = ls[0] + __shfl_xor(ls[0], 32, 64), sq = lq[0] + __shfl_xor(lq[0], 32, 64);
             dmean = sm * invK;
             rstd = 1.0f / sqrtf(fmaxf(sq * invK - dmean * dmean, 0.f) + g.ln_eps);
         } else {
-            gemm3_mainloop<BM, BN, WM, WN, 0, true, false>(g, smem, mt, c, b, acc1, ls, lq, lsh);
+            gemm3_mainloop<BM, BN, WM, WN, 0, true, false, R1>(g, smem, mt, c, b, acc1, ls, lq, lsh);
         }
         // (the main loop ended with every DMA drained - the W2 tile included - and a block barrier)
         const int hid0 = c * BN;
@@ -702,6 +703,20 @@ __global__ __launch_bounds__(256, MINB) void gemm3_mlp_kernel(const AbxGemm g) {
     probe.finish();
 }
 
+// the same with a three-stage ring for GEMM 1 (dynamic LDS: 79.9 KB, still two blocks per CU)
+constexpr int MLP3_LDS = 3 * (128 * 64 + 2 * 128 * 32) + 2 * 2 * 192 * 32 + 2 * MLP_NH * 4;
+__global__ __launch_bounds__(256, 2) void gemm3_mlp3_kernel(const AbxGemm g) {
+    extern __shared__ __attribute__((aligned(16))) float mlp3_smem[];
+    const int ntm = (g.M + 127) / 128;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
+    const ClockProbe probe(g.clock_probe);
+    if ((mt + 1) * 128 <= g.M && g.N2 == 192) gemm3_mlp_block<false, 3>(g, mlp3_smem, mt, b);
+    else gemm3_mlp_block<true, 3>(g, mlp3_smem, mt, b);
+    probe.finish();
+}
 
 // Gated tail of the TriangleAttention (seqformer.py:300-312: gate = sigmoid(gate_proj(LN z)), out = proj_out(gate * o), z += out) for 128
 // rows per block, in the shape of the fused transition above:
@@ -1313,7 +1328,10 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
             return 0;
         }
         const long long mt = ((long long)g.M + 127) / 128;
-        if ((g.tune >> 4) & 1) hipLaunchKernelGGL(gemm3_mlp_kernel<1>, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);       // benchmarking
+        if ((g.tune >> 5) & 1) {                                                                                                   // benchmarking
+            if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm3_mlp3_kernel), MLP3_LDS, "abx_gemm(mlp)")) { *rc = e; return 0; }
+            hipLaunchKernelGGL(gemm3_mlp3_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), MLP3_LDS, st, g);
+        } else if ((g.tune >> 4) & 1) hipLaunchKernelGGL(gemm3_mlp_kernel<1>, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);       // benchmarking
         else hipLaunchKernelGGL(gemm3_mlp_kernel<2>, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(mlp)");
         return 0;

@@ -17,9 +17,13 @@ def two():
     ops.gemm(hid, W2, out, bias=b2, B3=W23, resid=z, exact=2)
 def fused():
     ops.gemm(z, W1, out, bias=b1, ln=(None, cs1), B3=W13, act=1, resid=z, exact=2, mlp=(W23p, b2))
+def fused3():
+    ops.gemm(z, W1, out, bias=b1, ln=(None, cs1), B3=W13, act=1, resid=z, exact=2, mlp=(W23p, b2), tune=32)
 def fused1():
     ops.gemm(z, W1, out, bias=b1, ln=(None, cs1), B3=W13, act=1, resid=z, exact=2, mlp=(W23p, b2), tune=16)
 fl = 2.0 * M2 * 768 * 384
-for name, fn in (('two launches', two), ('fused mlp (2 blocks/CU)', fused), ('fused mlp (1 block/CU, 327 regs)', fused1), ('two launches', two), ('fused mlp (2 blocks/CU)', fused), ('fused mlp (1 block/CU, 327 regs)', fused1)):
+ref = None
+fused(); ref = out.clone(); fused3(); print('3-stage ring identical:', bool(torch.equal(ref, out)))
+for name, fn in (('two launches', two), ('fused mlp (2 blocks/CU)', fused), ('fused mlp, 3-stage GEMM 1 ring', fused3), ('fused mlp (2 blocks/CU)', fused), ('fused mlp, 3-stage GEMM 1 ring', fused3)):
     ms = timeit(fn, reps=7)
     print(f'{name:34s} Bc={Bc} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)

@@ -10,7 +10,7 @@ DEV = 'cuda:0'
 Bc, L = int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 352
 LL, M2 = L * L, Bc * L * L
 r = lambda *s: torch.randn(*s, device=DEV)
-x, bT, mask = r(M2, 768), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV)
+x, bT, mask = r(M2, 576), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV)          # (round 5: q | k | v only: no gate)
 if len(sys.argv) > 3: mask[:, L - 7:] = 0
 outs = {}
 for per_row in (True, False):

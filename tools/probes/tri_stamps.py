@@ -10,7 +10,8 @@ tune = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 DEV = 'cuda:0'
 LL, M2 = L * L, Bc * L * L
 r = lambda *s: torch.randn(*s, device=DEV)
-x, bT, mask, o = r(M2, 768), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV), torch.empty(M2, 192, device=DEV)
+W = 768 if (len(sys.argv) > 4 and sys.argv[4] == "gate") else 576          # (round 5: q | k | v only, the gated tail applies the gate)
+x, bT, mask, o = r(M2, W), r(Bc, 4, LL), torch.ones(Bc, L, device=DEV), torch.empty(M2, 192, device=DEV)
 ops.tri_attn(x, bT, mask, o, Bc, L, True, bias_is_qk=True, tune=tune)
 NWG = 256
 acc = torch.zeros(16 + NWG * 32, dtype=torch.int64, device=DEV)
@@ -25,7 +26,7 @@ names0 = ['row start -> Q split, first bias issued']
 nch = (n0 - 3) // 2
 for c in range(nch):
     names0 += [f'chunk {c} compute', f'chunk {c} barrier wait']
-names0 += ['epilogue (gate, store)']
+names0 += ['epilogue (normalise, store)']
 for i, nm in enumerate(names0):
     print(f'   {nm:48s} {float(d0[:, i].mean()):9.0f} {float(d0[:, i].min()):9.0f} {float(d0[:, i].max()):9.0f}')
 print(f'   {"row total":48s} {float((w0[:, n0 - 1] - w0[:, 0]).mean()):9.0f}')
