@@ -822,16 +822,21 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
     Row cur;
     long long slot = next_slot(wg, cur);
     int cc = 0;                                                 // chunks consumed so far
+    bool any_masked = false;
+    int b_masked = -1;
     __syncthreads();                                            // the first chunk of the first row is staged
     while (slot >= 0) {
         const int qt0 = cur.part * tpp, nqt = min(nqt_row, qt0 + tpp);
         const int qtA = qt0 + 2 * wave;
         const bool has_tile = qtA < nqt;                        // (a wave without tiles still joins the barriers)
         if (wave == 0) STAMP()
-        bool any_masked = false;                                // wave-uniform: does this sample mask any key?
-        if (cur.km) {
-            for (int j = lane; j < L; j += 64) any_masked |= cur.km[j] == 0.f;
-            any_masked = __any(any_masked);
+        if (cur.b != b_masked) {                                // wave-uniform: does this sample mask any key?  (once per sample: the
+            any_masked = false;                                 // rows of a workgroup walk one (b, h) pair before the next)
+            if (cur.km) {
+                for (int j = lane; j < L; j += 64) any_masked |= cur.km[j] == 0.f;
+                any_masked = __any(any_masked);
+            }
+            b_masked = cur.b;
         }
         // ---- Q fragments (B operand of the swapped product), pre-scaled, split once per row.
         // qf[X][0], [1]: pieces a0, a1 of channels 8g .. 8g+7 (first k-step); qf[X][2]: a0 of channels 32 + 8(g&1) .. (second k-step:

@@ -283,7 +283,7 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
     // ---- prologue.  Column 0: the A burst, statistics + split of its first two k-tiles.  Column 1: the first three weight stages
 #ifdef ABX_AS_STAMP
     // probe build: shader-clock ticks of wave 0 per phase, one record per block behind clock_probe[16]
-    unsigned long long t_wait = 0;
+    unsigned long long t_wait = 0, t_vm = 0, t_bar = 0;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     unsigned long long t_issued = 0, as_t_landed = 0;
 #endif
@@ -498,6 +498,19 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
         constexpr int role = decltype(role_)::value;
         constexpr int set = kt & 1;
         AS_STAMP_PRE
+#if defined(ABX_AS_STAMP) && ABX_AS_STAMP >= 3
+        if constexpr (role == 1 && !EDGE) {
+            // probe build: the streaming wave's wait for its DMA (and, in issue order, for its older stores) apart from the barrier
+            const unsigned long long ta_ = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)"
+                         : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fb[set][0][0]), "+v"(fb[set][0][1]), "+v"(fb[set][1][0]), "+v"(fb[set][1][1])
+                         : "n"(Sched::allow(kt, first)) : "memory");
+            const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+            asm volatile("s_barrier" ::: "memory");
+            t_vm += tb_ - ta_;
+            t_bar += __builtin_amdgcn_s_memtime() - tb_;
+        } else
+#endif
         if constexpr (role == 0) as_rendezvous_free(fa[set], fb[set]);
         else if constexpr (EDGE) as_rendezvous<0>(fa[set], fb[set]);             // (predicated stores: the instruction counts are not exact)
         else as_rendezvous<Sched::allow(kt, first)>(fa[set], fb[set]);
@@ -595,6 +608,10 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
         unsigned long long* rec = g.clock_probe + 16 + (size_t)blockIdx.x * 8;
         rec[0] = t_wait; rec[1] = t_walk1 - t_walk0; rec[2] = t_walk0 - t_begin; rec[3] = t_end - t_walk1;
         rec[4] = t_issued - t_begin; rec[5] = as_t_landed - t_issued; rec[6] = t_end - t_begin; rec[7] = 1ull;
+    }
+    if (g.clock_probe && threadIdx.x == 64) {                    // wave (0, 1): a streaming wave's record behind the blocks' first records
+        unsigned long long* rec = g.clock_probe + 16 + ((size_t)gridDim.x + blockIdx.x) * 8;
+        rec[0] = t_vm; rec[1] = t_bar; rec[7] = 1ull;
     }
 #endif
 }

@@ -25,7 +25,7 @@ bg, csg, Wg3 = r(512), Wg.sum(0).contiguous(), ops.split_weights(Wg)
 lrp = torch.zeros(Bc, 256, L // 16, 2, L, 16, device=DEV, dtype=torch.int16)
 pm = torch.ones(Bc * L * L, device=DEV)
 NBLK = (M2 + 63) // 64 + Bc * 4
-acc = torch.zeros(16 + 8 * NBLK, dtype=torch.int64, device=DEV)
+acc = torch.zeros(16 + 16 * NBLK, dtype=torch.int64, device=DEV)
 
 
 def side(tune):
@@ -45,7 +45,13 @@ for name, fn in (('side', side), ('glu', glu)):
         torch.cuda.synchronize()
         acc.zero_()
         ms = timeit(lambda: fn(abl << 12), reps=3)
-        rec = acc[16:].view(-1, 8).double()
+        nb_launch = (M2 + 63) // 64 if name == 'side' else Bc * ((L + 7) // 8 * 8) * ((L + 15) // 16 * 16) // 64
+        allrec = acc[16:].view(-1, 8).double()
+        rec2 = allrec[nb_launch:2 * nb_launch]
+        rec2 = rec2[rec2[:, 7] > 0]
+        if rec2.shape[0] and float(rec2[:, 0].sum()) > 0:
+            print(f'      streaming wave (0, 1), per block: vmcnt wait {float(rec2[:, 0].mean()):8.0f}  barrier wait {float(rec2[:, 1].mean()):8.0f} ticks')
+        rec = allrec[:nb_launch]
         rec = rec[rec[:, 7] > 0]
         m = rec.mean(0).tolist()
         print(f'{name:5s} {tag:26s} {ms:7.3f} ms  per block ({rec.shape[0]} blocks): total {m[6]:8.0f} = issue {m[4]:6.0f} | burst landed {m[5]:6.0f} | '
