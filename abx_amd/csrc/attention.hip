@@ -271,6 +271,16 @@ __device__ __forceinline__ void split2h_ns(float a, float b, unsigned& p0, unsig
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(p1) : "v"(p0), "v"(b));
 }
 
+// common.h split2b (planes p0 = f16(16 x), p1 = f16(16 x - p0)) on the mixed-precision FMA: 16 x - p0 is exact in fp32, so one
+// rounding to f16 gives the bits of scale - convert - convert back - subtract - convert, in 4 instructions per pair instead of 6
+// (the producer wave of tri_attn8_kernel is what the chunk barrier waits for).  c16 = 16.0f in a VGPR (no literal in VOP3P).
+__device__ __forceinline__ void split2b_mix(float a, float b, float c16, unsigned& p0, unsigned& p1) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(p0) : "v"(a), "v"(c16));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(p0) : "v"(b), "v"(c16));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(p1) : "v"(a), "v"(c16), "v"(p0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(p1) : "v"(b), "v"(c16), "v"(p0));
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -721,6 +731,11 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
         if (r.s >= a.S) return false;                                              // (ragged last row group)
         r.b = bh / a.H;
         r.h = bh % a.H;
+        // (wave-uniform, but the divisions above run on the vector unit: back to scalar registers - the producer wave holds two rows)
+        r.b = __builtin_amdgcn_readfirstlane(r.b);
+        r.h = __builtin_amdgcn_readfirstlane(r.h);
+        r.s = __builtin_amdgcn_readfirstlane(r.s);
+        r.part = __builtin_amdgcn_readfirstlane(r.part);
         r.base = (long long)r.b * a.sb + (long long)r.s * a.ss + (long long)r.h * TD;
         r.km = a.keymask ? a.keymask + (long long)r.b * a.km_sb : nullptr;
         r.biasb = a.bias ? a.bias + (long long)r.b * a.bias_sb + (long long)r.h * a.bias_sh : nullptr;
@@ -734,46 +749,94 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
     const int nchunk = (L + KC4 - 1) / KC4;
     const int nqt_row = (L + 15) / 16, tpp = (nqt_row + a.q_parts - 1) / a.q_parts;
 
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+
     if (wave == NCW) {
         // ================= producer wave: K / V of the chunk after the one being computed, across row boundaries ==============
         // (the last-dispatched wave of the workgroup loses every VALU / LDS issue arbitration against the older computing waves of
         // its SIMD, and it is the one the chunk barrier waits for: static priority)
         __builtin_amdgcn_s_setprio(3);
+        // per-lane constants of the staging: item j of a round is (key kk0[j] + 32 rd, 4-channel group c4) with idx = lane + 64 j =
+        // 12 kk0 + c4 (a round of 6 items advances every key by 384 / 12 = 32): LDS byte offset inside a plane, byte offset inside a row
+        constexpr int NPI = KC4 * (TD / 4) / 64;                // (key, 4-channel) items per lane: 36 (192-key chunks) / 24
+        constexpr int NPF = 6, NRD = NPI / NPF;                 // rounds of 6 items (12 loads of 16 bytes per lane)
+        static_assert(NPI % NPF == 0 && NRD % 2 == 0 && (NPF * 64) % (TD / 4) == 0, "rounds");
+        constexpr int KRD = NPF * 64 / (TD / 4);                // keys a round advances: 32
+        const unsigned sl4 = (unsigned)(a.sl * 4);             // row stride in bytes (< 2^24, rows of one (b, s) slab < 4 GB: the dispatch)
+        float c16 = 16.0f;                                      // (VOP3P takes no literal; a VGPR: see split2b_mix)
+        asm volatile("" : "+v"(c16));
         auto stage = [&](const Row& r, int c0, int buf) __attribute__((always_inline)) {
-            constexpr int NPI = KC4 * (TD / 4) / 64;            // (key, 4-channel) items per lane
-            constexpr int NPF = NPI / 4;                        // in flight per lane: 9 (192-key chunks) / 6, four rounds
             char* Kp = lds + buf * BUF4;
             char* Vp = Kp + 2 * PLN;
-            for (int j0 = 0; j0 < NPI; j0 += NPF) {
-                f32x4 kr[NPF], vr[NPF];
+            // (recomputed per chunk behind an opaque lane id: as invariants of the whole kernel they are hoisted above the wave-role
+            // branch and cost the computing waves 18 registers - spills)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+        int kk0[NPF];
+        unsigned ldo[NPF], gco[NPF];
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int idx = ln + j * 64;
+            kk0[j] = idx / (TD / 4);
+            ldo[j] = (unsigned)(kk0[j] * RST + (idx % (TD / 4)) * 8);
+            gco[j] = (unsigned)((idx % (TD / 4)) * 16);
+        }
+            // wave-uniform slab bases + 32-bit per-lane offsets (scalar-base loads: no 64-bit vector address arithmetic per item)
+            const char* kb = reinterpret_cast<const char*>(a.k + r.base);
+            const char* vb = reinterpret_cast<const char*>(a.v + r.base);
+            // software pipeline over the rounds: the loads of round rd + 1 are in flight while round rd is split and written
+            f32x4 kr[2][NPF], vr[2][NPF];
+            auto issue = [&](int rd, auto set_) __attribute__((always_inline)) {
+                constexpr int set = decltype(set_)::value;
 #pragma unroll
                 for (int j = 0; j < NPF; ++j) {
-                    const int idx = lane + (j0 + j) * 64, kk = idx / (TD / 4), c4 = idx % (TD / 4);
-                    kr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    vr[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (c0 + kk < L) {
-                        const long long off = r.base + (long long)(c0 + kk) * a.sl + c4 * 4;
-                        // read once per launch: non-temporal, so that the K / V stream does not push the pair's bias out of the L2
-                        kr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.k + off));
-                        vr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.v + off));
-                    }
+                    // UNCONDITIONAL loads (a conditional one makes the number of loads in flight unknown to the compiler: it then waits
+                    // for vmcnt(0) before the previous round's values, and the pipeline is gone).  Keys beyond L re-read the last key:
+                    // their logits are clamped to -inf (Msb), their softmax weights are exactly 0 against a finite V row
+                    const unsigned off = __umul24((unsigned)min(c0 + rd * KRD + kk0[j], L - 1), sl4) + gco[j];
+                    // read once per launch: non-temporal, so that the K / V stream does not push the pair's bias out of the L2
+                    kr[set][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kb + off));
+                    vr[set][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vb + off));
                 }
+            };
+            auto convert = [&](int rd, auto set_) __attribute__((always_inline)) {
+                constexpr int set = decltype(set_)::value;
+                const unsigned rdo = (unsigned)(rd * KRD * RST);
 #pragma unroll
                 for (int j = 0; j < NPF; ++j) {
-                    const int idx = lane + (j0 + j) * 64, kk = idx / (TD / 4), c4 = idx % (TD / 4);
                     unsigned a0, a1, b0, b1;
-                    split2b(kr[j][0], kr[j][1], a0, a1);
-                    split2b(kr[j][2], kr[j][3], b0, b1);
-                    char* kd = Kp + kk * RST + c4 * 8;
+                    split2b_mix(kr[set][j][0], kr[set][j][1], c16, a0, a1);
+                    split2b_mix(kr[set][j][2], kr[set][j][3], c16, b0, b1);
+                    char* kd = Kp + rdo + ldo[j];
                     *reinterpret_cast<u32x2*>(kd) = u32x2{a0, b0};
                     *reinterpret_cast<u32x2*>(kd + PLN) = u32x2{a1, b1};
-                    split2b(vr[j][0], vr[j][1], a0, a1);
-                    split2b(vr[j][2], vr[j][3], b0, b1);
-                    char* vd = Vp + kk * RST + c4 * 8;
+                    split2b_mix(vr[set][j][0], vr[set][j][1], c16, a0, a1);
+                    split2b_mix(vr[set][j][2], vr[set][j][3], c16, b0, b1);
+                    char* vd = Vp + rdo + ldo[j];
                     *reinterpret_cast<u32x2*>(vd) = u32x2{a0, b0};
                     *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
                 }
+            };
+            // (a real loop over round pairs; scheduling barriers: the compiler would hoist every round's loads to the top and spill)
+            issue(0, I0{});
+#pragma unroll 1
+            for (int rd = 0; rd < NRD - 2; rd += 2) {           // (every issue unconditional: see above)
+                issue(rd + 1, I1{});
+                __builtin_amdgcn_sched_barrier(0);
+                convert(rd, I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                issue(rd + 2, I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                convert(rd + 1, I1{});
+                __builtin_amdgcn_sched_barrier(0);
             }
+            issue(NRD - 1, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert(NRD - 2, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            convert(NRD - 1, I1{});
+            __builtin_amdgcn_sched_barrier(0);
             // key clamps, applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit by
             // finfo.min: every finite logit is >= finfo.min), -inf beyond L
             for (int t = lane; t < KC4; t += 64)
@@ -816,8 +879,6 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
     const int koff0 = lq * RST + g * 16;                                  // K fragment, channels 8g .. (plane p: + p PLN)
     const int koffc = lq * RST + (g >> 1) * PLN + 64 + (g & 1) * 16;      // channels 32 + 8(g&1) .. of plane g >> 1
     const int voff = (4 * g + (lq >> 2)) * RST + (lq & 3) * 8;            // transposing V reads (see tri_attn4_kernel)
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
 
     Row cur;
     long long slot = next_slot(wg, cur);
@@ -1255,7 +1316,9 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         // (Every query's arithmetic is the same in all variants: results are bit-identical.)  tune bit 0: never the producer wave.
         AbxTriAttn aa = a;
         const int nqt = (a.L + 15) / 16, nw = TRI_THREADS / 64;
-        const bool paired = !(a.tune & 4);                   // tri_attn8_kernel: 11 computing waves x 2 query tiles walked together
+        // tri_attn8_kernel: 11 computing waves x 2 query tiles walked together (its producer addresses a (b, s) slab of K / V with 32-bit
+        // byte offsets and a 24-bit row stride; any other layout takes tri_attn4)
+        const bool paired = !(a.tune & 4) && a.sl * 4 < (1LL << 24) && (long long)a.L * a.sl * 4 < (1LL << 32);
         aa.q_parts = paired ? (nqt + 2 * (nw - 1) - 1) / (2 * (nw - 1)) : (nqt + 2 * nw - 1) / (2 * nw);
         const int tpp = (nqt + aa.q_parts - 1) / aa.q_parts;
         const bool prod = tpp <= 2 * (nw - 1) && !(a.tune & 1);

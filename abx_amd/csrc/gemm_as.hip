@@ -162,8 +162,10 @@ __device__ __forceinline__ void as_conv_ktile(AsConv& c, char* img) {
     *reinterpret_cast<u32x4*>(img + c.wr) = u32x4{q0[0], q0[1], q0[2], q0[3]};
     *reinterpret_cast<u32x4*>(img + c.wr + 1024) = u32x4{q1[0], q1[1], q1[2], q1[3]};
 }
-// (mean - shift, rstd) of the wave's 32 rows -> st
-__device__ __forceinline__ void as_conv_finish(const AsConv& c, float* st, int wm, float eps) {
+// (mean - shift, rstd * cs) of the wave's 32 rows -> st.  cs = the accumulator scale 2^-(a_exp + b_exp) of the split-f16 product: the
+// epilogues compute (rstd cs) (acc - dmean (csum / cs)) instead of rstd (acc cs - dmean csum) - the same bits (every scaling by the
+// power of two is exact and commutes with the roundings), one multiplication less per element
+__device__ __forceinline__ void as_conv_finish(const AsConv& c, float* st, int wm, float eps, float cs) {
     const int lane = threadIdx.x & 63;
     const float ls = c.ls2[0] + c.ls2[1], lq = c.lq2[0] + c.lq2[1];
     const float invK = 1.0f / (float)(AS_NK * 16);
@@ -171,8 +173,34 @@ __device__ __forceinline__ void as_conv_finish(const AsConv& c, float* st, int w
     if (lane < 32) {
         const float dm = sm * invK;
         st[wm * 32 + lane] = dm;
-        st[64 + wm * 32 + lane] = 1.0f / sqrtf(fmaxf(sq * invK - dm * dm, 0.f) + eps);
+        st[64 + wm * 32 + lane] = (1.0f / sqrtf(fmaxf(sq * invK - dm * dm, 0.f) + eps)) * cs;
     }
+}
+
+// 4 x 4 transpose inside every lane quad: lane q of a quad holds x[0 .. 3] = rows 0 .. 3 of column q and receives o[0 .. 3] = columns
+// 0 .. 3 of row q.  Two exchange stages (lane ^ 1, lane ^ 2), each ONE v_cndmask_b32 with a DPP quad_perm source per value (the select
+// and the cross-lane move in one instruction; vcc = the lanes that keep their own value): 8 VALU instructions instead of the 24 the
+// compiler makes of update_dpp + select (a zeroed destination, the move, the select).  The leading s_nop covers the two wait states
+// between the VALU write of x and its DPP read; inside the statement every DPP source is written >= 2 instructions earlier.
+__device__ __forceinline__ void as_quad_transpose(const float (&x)[4], float (&o)[4]) {
+    float a0, a1, a2, a3;
+    asm volatile(
+        "s_nop 1\n\t"
+        "s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\t"                                    // even lanes keep rows 0, 2
+        "v_cndmask_b32_dpp %4, %9, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"               // a0 = even ? x0 : x1 of lane ^ 1
+        "v_cndmask_b32_dpp %6, %11, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"             // a2 = even ? x2 : x3 of lane ^ 1
+        "s_mov_b32 vcc_lo, 0xaaaaaaaa\n\ts_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"                                    // odd lanes keep rows 1, 3
+        "v_cndmask_b32_dpp %5, %8, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"               // a1 = odd ? x1 : x0 of lane ^ 1
+        "v_cndmask_b32_dpp %7, %10, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"             // a3 = odd ? x3 : x2 of lane ^ 1
+        "s_mov_b32 vcc_lo, 0x33333333\n\ts_mov_b32 vcc_hi, 0x33333333\n\t"                                    // lanes 0, 1 of a quad
+        "v_cndmask_b32_dpp %0, %6, %4, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"               // o0 = low ? a0 : a2 of lane ^ 2
+        "v_cndmask_b32_dpp %1, %7, %5, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"               // o1 = low ? a1 : a3 of lane ^ 2
+        "s_mov_b32 vcc_lo, 0xcccccccc\n\ts_mov_b32 vcc_hi, 0xcccccccc\n\t"                                    // lanes 2, 3 of a quad
+        "v_cndmask_b32_dpp %2, %4, %6, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"               // o2 = high ? a2 : a0 of lane ^ 2
+        "v_cndmask_b32_dpp %3, %5, %7, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"                     // o3 = high ? a3 : a1 of lane ^ 2
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])
+        : "vcc");
 }
 
 // ---- operations a COLUMN-1 wave queues behind the weight DMA of a k-step (for its counted waits) -------------------------------------
@@ -318,7 +346,8 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
     }
     __syncthreads();
 
-    const float cs = __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - g.b_exp);
+    const float cs = __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - g.b_exp), inv_cs = __builtin_ldexpf(1.0f, ABX_F16_A_EXP + g.b_exp);
+    // (side operand: its own weight exponent; st holds rstd * cs)
     const float csS = SIDE ? __builtin_ldexpf(1.0f, -ABX_F16_A_EXP - s2.b_exp) : 0.f;
     float* Cb = g.C + (long long)b * g.sCb;
     bool bad = false;
@@ -345,7 +374,7 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
         const float* cc = reinterpret_cast<const float*>(lds + AS_OFF_CONST + (tile_p & 1) * 1024);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            csump[j] = cc[wn * 64 + j * 32 + (lane & 31)];
+            csump[j] = cc[wn * 64 + j * 32 + (lane & 31)] * inv_cs;      // csum / cs (as_conv_finish)
             biasp[j] = cc[128 + wn * 64 + j * 32 + (lane & 31)];
         }
     };
@@ -358,10 +387,9 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
     // PLAIN: slice q = (row quad rq = q >> 1, sub-tile j = q & 1).  A lane holds 4 rows x 1 column; a 4 x 4 transpose inside every
     // lane quad (two DPP quad_perm exchanges) gives it 1 row x 4 consecutive columns: one 16-byte store per lane, 8 lanes = the 128
     // contiguous bytes of a row segment
-    const bool odd1 = (lane & 1) != 0, odd2 = (lane & 2) != 0;
     auto plain_slice = [&](auto q_) __attribute__((always_inline)) {
         constexpr int q = decltype(q_)::value, rq = q >> 1, j = q & 1;
-        float x[4], a[4], o[4];
+        float x[4], o[4];
         const f32x4 dm4 = *reinterpret_cast<const f32x4*>(st_w + 8 * rq), rs4 = *reinterpret_cast<const f32x4*>(st_w + 64 + 8 * rq);
         // (the slice's arithmetic must stay in ITS k-step: the compiler would hoist the pure-VALU part of all eight slices to the head
         // of the tile - one long live range per value, spills; a volatile statement is not moved across the step's rendezvous)
@@ -369,22 +397,12 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // (gemm_epilogue.h epi1 with a folded LayerNorm, alpha == 1, no activation - bit for bit)
-            float v = accp[j][4 * rq + c] * cs;
-            v = rs4[c] * (v - dm4[c] * csump[j]);
-            x[c] = (v + biasp[j]) * 1.0f;
+            const float v = rs4[c] * (accp[j][4 * rq + c] - dm4[c] * csump[j]);       // rs4 = rstd cs, csump = csum / cs
+            x[c] = v + biasp[j];
         }
         // (one class test per slice: a NaN / inf among the four makes their sum NaN / inf - the kernel is instruction-issue bound)
         bad |= __builtin_amdgcn_classf((x[0] + x[1]) + (x[2] + x[3]), 0x207);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[r ^ 1]), 0xB1, 0xf, 0xf, false));
-            a[r] = (odd1 == ((r & 1) != 0)) ? x[r] : t;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[r ^ 2]), 0x4E, 0xf, 0xf, false));
-            o[r] = (odd2 == ((r & 2) != 0)) ? a[r] : t;
-        }
+        as_quad_transpose(x, o);
         const int m = m0 + wm * 32 + 8 * rq + 4 * h + (lane & 3);
         const int n = tile_p * AS_BN + wn * 64 + j * 32 + ((lane & 31) >> 2) * 4;
         if (ABL != 1 && (!EDGE || m < g.M)) *reinterpret_cast<f32x4*>(Cb + (long long)m * g.sCm + n) = (f32x4){o[0], o[1], o[2], o[3]};
@@ -402,16 +420,15 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
         asm volatile("" : "+v"(accp[0][4 * rq]), "+v"(accp[0][4 * rq + 1]), "+v"(accp[0][4 * rq + 2]), "+v"(accp[0][4 * rq + 3]));
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float a = accp[0][4 * rq + c] * cs, gt = accp[1][4 * rq + c] * cs;
-            a = rs4[c] * (a - dm4[c] * csump[0]);
-            gt = rs4[c] * (gt - dm4[c] * csump[1]);
-            a = (a + biasp[0]) * 1.0f;
-            gt = (gt + biasp[1]) * 1.0f;
+            float a = rs4[c] * (accp[0][4 * rq + c] - dm4[c] * csump[0]);        // rs4 = rstd cs, csump = csum / cs
+            float gt = rs4[c] * (accp[1][4 * rq + c] - dm4[c] * csump[1]);
+            a = a + biasp[0];
+            gt = gt + biasp[1];
             v[c] = a * sigmoidf_(gt) * sc4[c];
-            bad |= __builtin_amdgcn_classf(v[c], 0x207);
         }
-        const int n = tile_p * 64 + wn * 32 + (lane & 31);       // output channel
-        if (n < g.c_split_nA) {
+        bad |= __builtin_amdgcn_classf((v[0] + v[1]) + (v[2] + v[3]), 0x207);      // (one class test per slice, as plain_slice)
+        // (the dispatch admits c_split_nA % 32 == 0: the wave's 32 channels are on one side - a scalar branch)
+        if (tile_p * 64 + wn * 32 < g.c_split_nA) {
             split2h(v[0], v[1], gp0[2 * rq], gp1[2 * rq]);
             split2h(v[2], v[3], gp0[2 * rq + 1], gp1[2 * rq + 1]);
         } else {
@@ -459,7 +476,7 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float x = accp[0][4 * rq + c] * csS;
-                    x = rs4[c] * (x - dm4[c] * cS);
+                    x = (rs4[c] * inv_cs) * (x - dm4[c] * cS);
                     v[c] = (x + bS) * s2.alpha;
                     bad |= __builtin_amdgcn_classf(v[c], 0x207);
                 }
@@ -526,7 +543,7 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
             // the next rendezvous); this wave's vector-memory queue holds nothing but the burst
             as_wait_vm<2 * (AS_NK - 3 - kt)>();
             as_conv_ktile<false>(cv, a_half + (kt + 2) * AS_KT);
-            if constexpr (kt == AS_NK - 3) as_conv_finish(cv, st, wm, g.ln_eps);
+            if constexpr (kt == AS_NK - 3) as_conv_finish(cv, st, wm, g.ln_eps, cs);
         }
         if constexpr (kt == 1 && !first) read_consts();
         read_frags((kt + 1) & 1, (kt + 1) % AS_NK, (kt + 1) % 3);
@@ -655,7 +672,7 @@ int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, 
     if (g.N < 256 || ntm * g.batch < 1024) return 1;
     const bool glu = g.glu != 0;
     if (glu) {
-        if (side || !g.C_split || !g.c_split_tile || !g.c_transposed || g.N % 128 != 0 || !g.a_pair || g.pair_Lp <= 0 || g.c_split_L != g.pair_Lp) return 1;
+        if (side || !g.C_split || !g.c_split_tile || !g.c_transposed || g.N % 128 != 0 || !g.a_pair || g.pair_Lp <= 0 || g.c_split_L != g.pair_Lp || g.c_split_nA % 32 != 0) return 1;
         if (!g.c_vec_ok || (reinterpret_cast<uintptr_t>(g.C_split) & 15) != 0 || g.sCb % 8 != 0 || g.sCm % 8 != 0 || g.sCk % 8 != 0 || g.sCp % 8 != 0) return 1;
         if (g.sB3b != 0) return 1;
     } else {
