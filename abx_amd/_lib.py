@@ -115,6 +115,7 @@ class AbxTriAttn(C.Structure):
         ('clock_probe', c_f),
         ('range_flag', c_f), ('range_tag', I),
         ('tune', I),
+        ('bias_log2', I),
         ('q_parts', I), ('row_groups', I),
     ]
 

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
     const bool bias_vec = biasb && a.bias_sk == 1 && (a.bias_sq % 4 == 0) && (L % 4 == 0) &&
                           ((reinterpret_cast<uintptr_t>(biasb) & 15) == 0);
     const float qscale = a.scale * LOG2E;                       // softmax evaluated in base 2: exp(x) = exp2(x log2 e)
+    const float bias_l2 = a.bias_log2 ? 0.0078125f : LOG2E;     // (a bias that arrives as ABX_TRI_BIAS_LOG2 x the pair bias: back to base-2 logits)
 
     for (int qg = 0; qg < nqt; qg += TRI_THREADS / 64) {
         const int qt = qg + wave;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
                 for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                        const float v = fmaf(bz[sub][r], bias_l2, sc[sub][r]);
                         sc[sub][r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(TRI_THREADS) void tri_attn_kernel(const AbxTriAttn 
                     const f32x4 mk = *reinterpret_cast<const f32x4*>(Ms + k0 + sub * 16 + g * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                        float v = fmaf(bz[sub][r], bias_l2, sc[sub][r]);
                         v = mk[r] == 0.f ? v : (mk[r] == 1.f ? ABX_NEG_MAX : -INFINITY);
                         sc[sub][r] = v;
                         mx = fmaxf(mx, v);
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
     const int bias_row = (int)a.bias_sq;                        // readable floats per bias row when bias_sk == 1
     // split-f16 scales: keys / values are staged as 16 x, queries and softmax weights enter as x / 16, so the products need no rescale
     const float qscale = a.scale * LOG2E * 0.0625f;
+    const float bias_l2 = a.bias_log2 ? 0.0078125f : LOG2E;     // (see tri_attn_kernel)
     // wave-uniform: does this sample mask any key?  (12 waves x 64 lanes cover L <= 768 in one pass of the ballot loop)
     bool any_masked = false;
     if (km) {
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(NTH) void tri_attn4_kernel(const AbxTriAttn a) {
 #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[sub][r] = fmaf(bz[sub][r], LOG2E, sc[sub][r]);
+                    for (int r = 0; r < 4; ++r) sc[sub][r] = fmaf(bz[sub][r], bias_l2, sc[sub][r]);
                 }
                 if (clamp) {
 #pragma unroll
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
                 const bool full = nkeys - k0 > 32;              // otherwise: sub-blocks 0, 1 and the first PV step only
                 // next key tile of this row (its bias is requested under the PV work below): first key, or -1
                 const int k_next = kt + 1 < nkt ? c0 + k0 + 64 : (more ? c0 + KC4 : -1);
-                if (BVEC || cur.biasb) {
+                if ((BVEC || cur.biasb) && !a.bias_log2) {      // (bias_log2: the projection applied the factor, AbxGemm.alpha)
 #pragma unroll
                     for (int X = 0; X < 2; ++X)
 #pragma unroll

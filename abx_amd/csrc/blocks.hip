@@ -333,6 +333,9 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
         s2.M = (int)LL; s2.batch = B;
         set_weights(s2, pair, true, exact);
         set_range(s2, range_flag, range_tag, exact);
+        // the split-f16 attention adds the bias to accumulators that hold 2^7 x base-2 logits: the factor goes into this epilogue
+        // (AbxTriAttn.bias_log2: the same product, rounded once, here instead of per key tile in the attention's hot loop)
+        if (!attn_exact) s2.alpha = ABX_TRI_BIAS_LOG2;
         if (int rc = abx_gemm_side(&g, &s2, st)) return rc;
     }
     const float* bias = w.bT;
@@ -354,6 +357,7 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
         a.B = B; a.S = L; a.L = L; a.H = 4; a.D = 48;
         a.scale = 0.14433756729740643f;                     // 48^-0.5
         a.exact = attn_exact;
+        a.bias_log2 = attn_exact ? 0 : 1;
         if (!attn_exact) { a.range_flag = range_flag; a.range_tag = range_tag; }
         if (int rc = abx_tri_attn_fwd(&a, st)) return rc;
     }

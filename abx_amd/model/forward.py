@@ -520,8 +520,11 @@ class Engine:
             # projection's last column tile (ops.gemm_side; two launches when the pair does not qualify - exact arithmetic, small problems)
             bT = ws.get('biasT', (Bc, 4, LL))
             qkv = w768.view(-1)[:M2 * 576].view(M2, 576)
+            # (the split-f16 attention takes the bias in its accumulator units: the factor rides in the projection's epilogue)
+            bl2 = not (ops.GEMM_EXACT if ae is None else ae)
             ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True, exact=am),
-                          _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True, exact=am))
+                          _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True, exact=am,
+                                  alpha=ops.TRI_BIAS_LOG2 if bl2 else 1.0))
             o = w384[:M2 * 192].view(M2, 192)
             # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
             # i.e. the transpose (2 MB per sample); starting node: a padded copy only when L % 4 != 0
@@ -531,7 +534,7 @@ class Engine:
                 bT = bT2
             else:
                 bT = bT.view(Bc, 4, L, L)
-            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True, exact=ae)       # (no gate: the tail applies it)
+            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True, exact=ae, bias_log2=bl2)       # (no gate: the tail applies it)
             if not ax:
                 # gate projection, sigmoid, * attention output, output projection, + residual in ONE kernel (AbxGemm.mlp = 2)
                 _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, z2, act=2, gate=o, resid=z2, mlp=P.mlp_second(pre + 'attn.proj_out'), exact=2)

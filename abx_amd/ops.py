@@ -578,7 +578,12 @@ def tri_attn_kernel_name(L, exact=None, bias_vec=True):
     return 'tri_attn8_kernel<%d, 768, %s>' % (kc, 'true' if bias_vec else 'false')
 
 
-def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0):
+# float(log2 e) * 2^7 (include/abx_hip.h ABX_TRI_BIAS_LOG2): the factor the pair-bias projection applies (gemm(..., alpha=)) when the attention
+# that reads it runs with bias_log2=True
+TRI_BIAS_LOG2 = float(__import__('numpy').float32(1.4426950408889634) * __import__('numpy').float32(128.0))
+
+
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0, bias_log2=False):
     """qkvg (B*L*L, 4*H*D) = [q|k|v|gate], or (B*L*L, 3*H*D) = [q|k|v]: no gate (the gated tail applies it: gemm(..., mlp=, gate=));
     biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
     already laid out [b,h,q,k] for this orientation (bias_is_qk=True; then (B,H,L,Lp) with rows padded to Lp % 4 == 0 floats gives
@@ -608,6 +613,7 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.scale = float(D ** (-0.5))
     a.exact = int(GEMM_EXACT if exact is None else exact)
     a.tune = int(tune)
+    a.bias_log2 = int(bool(bias_log2))              # biasT = TRI_BIAS_LOG2 x the pair bias (AbxTriAttn.bias_log2)
     if RANGE_CHECK and not a.exact:
         a.range_flag, a.range_tag = range_ptr(out.device), RANGE_TAGS['tri_attn']
     if clock_probe is not None:

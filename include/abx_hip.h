@@ -279,15 +279,21 @@ typedef struct AbxTriAttn {
                                                        queries as two pieces of q * scale * log2(e) * 8 (|q * scale| < 5600), softmax weights
                                                        as two pieces of P * 2^8: 3 exact float16 products per fp32 product, fp32 accumulate;
                                                        an operand beyond its range gives NaN in its output rows, never a wrong number;
-                                                       1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32, L <= 389) */
+                                                       1: exact fp32 MFMA kernel (v_mfma_f32_16x16x4_f32; keys in chunks: any L) */
     unsigned long long* clock_probe;                /* diagnostics, optional DEVICE [2] (see AbxGemm.clock_probe; split-f16 kernels) */
     int* range_flag; int range_tag;                 /* see AbxGemm.range_flag: set when a query row's output is not finite (split-f16 kernels) */
     int tune;                                       /* 0 = library default (persistent workgroups, two query tiles per wave walked together);
                                                        bit 1: the other key-chunk size (128 <-> 192; bit-identical results); bit 2: the round-3
                                                        kernel tri_attn4 (one workgroup per row, one query tile at a time; with bit 0: without
                                                        its producer wave) - benchmarking and cross-checks: its accumulation order differs */
+    int bias_log2;                                  /* 1: `bias` holds ABX_TRI_BIAS_LOG2 x the pair bias - the projection that wrote it applied the
+                                                       factor (AbxGemm.alpha), so the split-f16 kernel adds it to its accumulators as it is: the
+                                                       same bits as the multiplication in the kernel (one rounding of the same product), 32 vector
+                                                       instructions less per pair of query tiles and key tile.  abx_tri_attn_block_fwd does this. */
     int q_parts, row_groups;                        /* filled by the library */
 } AbxTriAttn;
+/* float(log2 e) * 2^7: base-2 logits in the accumulator units of tri_attn8_kernel */
+#define ABX_TRI_BIAS_LOG2 (1.4426950408889634f * 128.0f)
 int abx_tri_attn_fwd(const AbxTriAttn* desc, hipStream_t stream);
 
 /* Sequence attention with pair bias (seqformer.py:314-356 + Attention.forward split_first=False :278-312).

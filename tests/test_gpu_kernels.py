@@ -635,6 +635,33 @@ def test_tri_attn_variants_bit_identical(ops, L):
         assert float((outs[tune] - oe).abs().max()) < 5e-6 * float(oe.abs().max()) + 5e-6, tune
 
 
+@pytest.mark.parametrize('L', [97, 352])
+def test_tri_attn_bias_in_accumulator_units(ops, L):
+    """AbxTriAttn.bias_log2: a bias the projection already multiplied by ABX_TRI_BIAS_LOG2 (float(log2 e) * 2^7, AbxGemm.alpha) gives the
+    paired-tile kernel the bits of the plain bias (the same product, rounded once, outside the kernel's hot loop); the exact kernel and
+    the round-3 kernel scale it back to base-2 logits: their results move by the rounding of the product only."""
+    B, H, D = 1, 4, 48
+    C = H * D
+    gen = torch.Generator(device=DEV).manual_seed(400 + L)
+    x = torch.randn(B * L * L, 3 * C, device=DEV, generator=gen)
+    biasT = torch.randn(B, H, L, L, device=DEV, generator=gen) * 3
+    mask = (torch.rand(B, L, device=DEV, generator=gen) > 0.1).float()
+    mask[:, 0] = 1
+    scaled = biasT * ops.TRI_BIAS_LOG2
+    for tune in (0, 2):
+        o0 = torch.full((B * L * L, C), float('nan'), device=DEV)
+        o1 = torch.full((B * L * L, C), float('nan'), device=DEV)
+        ops.tri_attn(x, biasT, mask, o0, B, L, True, tune=tune)
+        ops.tri_attn(x, scaled, mask, o1, B, L, True, tune=tune, bias_log2=True)
+        assert torch.equal(o0, o1), tune
+    for kw in (dict(tune=4), dict(exact=True)):
+        o0 = torch.empty(B * L * L, C, device=DEV)
+        o1 = torch.empty(B * L * L, C, device=DEV)
+        ops.tri_attn(x, biasT, mask, o0, B, L, True, **kw)
+        ops.tri_attn(x, scaled, mask, o1, B, L, True, bias_log2=True, **kw)
+        assert float((o0 - o1).abs().max()) < 2e-6 * float(o0.abs().max()) + 2e-6, kw
+
+
 @pytest.mark.parametrize('L,per_row', [(416, True), (560, False), (752, True)])
 def test_tri_attn_long_rows(ops, L, per_row):
     """Rows with more than 24 query tiles are dealt to several workgroups (AbxTriAttn.q_parts: 416 -> 2 x 13 tiles and 560 -> 2 x 18
