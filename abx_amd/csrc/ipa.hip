@@ -105,6 +105,14 @@ __host__ __device__ inline size_t ipa_logits_floats(int L) {
     return lgf > redf ? lgf : redf;
 }
 
+#ifdef IPA_STAMP
+// probe build (tools/probes/kb_ipa_stamps.py): shader-clock stamps of thread 0 at the phase boundaries of 1024 workgroups in the middle
+// of the grid
+__device__ unsigned long long ipa_stamp_buf[1024 * 8];
+#define ISTAMP(k) { if (threadIdx.x == 0 && blockIdx.x >= 4096 && blockIdx.x < 5120) ipa_stamp_buf[(blockIdx.x - 4096) * 8 + (k)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define ISTAMP(k) {}
+#endif
 // ---- kernel 1: attention weights + scalar / point outputs ----------------------------------------------------------------
 // One workgroup per (b, IQ = 12 query residues, group of 4 heads); two workgroups per CU (78 KB of LDS each at L = 352) so that
 // the load-latency-bound phases of one overlap the arithmetic of the other.  12 queries share every K / V record fetched.
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
     const int i0 = iblk * IQ;
     const int niq = min(IQ, L - i0);
 
+    ISTAMP(0)
     // ---- phase A: scalar + point logits.  A wave takes 64 keys of ONE head per task; the Q records of the block are
     // wave-uniform and come through the scalar cache as (query pair, channel) float2, so every product is one packed FMA
     // over two queries with the key channel broadcast: no LDS traffic, 22 VALU instructions per (key, head, query pair)
@@ -173,7 +182,9 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
             }
         }
     }
+    ISTAMP(1)
     __syncthreads();
+    ISTAMP(2)
     // ---- pair bias and mask: thread per (iq, j), the 4 heads of the group in one 16-byte load
     for (int idx = tid; idx < niq * L; idx += IPA_THREADS) {
         const int iq = idx / L, j = idx - iq * L;
@@ -198,6 +209,7 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
     };
     if (jg < NJG) load_round(jg);
     __syncthreads();
+    ISTAMP(3)
     // ---- softmax over j, one wave per query: its 4 head rows together (interleaved reductions); the normalised weights go
     // back to LDS (phase B1) and to HBM as [i][head group][j][4], 16 contiguous bytes per lane
     for (int iq = wave; iq < niq; iq += IPA_THREADS / 64) {
@@ -231,6 +243,7 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
         }
     }
     __syncthreads();
+    ISTAMP(4)
     // ---- phase B1: scalar + point outputs; the V records of the next 4 keys are in flight while the current 4 are consumed
     {
         f32x4 acc[IQ];
@@ -259,6 +272,7 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
         }
         // fold the key groups through the (now free) logits region in three rounds, (g, g + 6), then (g, g + 3), then
         // (g0 + g1) + g2: fixed order, no long shuffle chains (their live ranges spilled)
+        ISTAMP(5)
         float* red = lg;                                    // [6 key groups][40 items][IQ][4] (+ padding)
         auto slot_of = [&](int g) { return red + (size_t)g * RED_G + (size_t)item * RED_I; };     // padded strides: distinct banks
         __syncthreads();                                    // every wave has consumed its weights
@@ -309,6 +323,7 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
         }
         __syncthreads();
     }
+    ISTAMP(6)
     // ---- tail: scalar copy, points to the local frame, norms ----------------------------------------------------------
     for (int idx = tid; idx < niq * HG * SV; idx += IPA_THREADS) {
         const int iq = idx / (HG * SV), r = idx % (HG * SV);
@@ -333,6 +348,7 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
         for (int r = 0; r < 3; ++r) fo[H * SV + r * (H * PV) + n] = loc[r];
         fo[H * SV + 3 * H * PV + n] = sqrtf(loc[0] * loc[0] + loc[1] * loc[1] + loc[2] * loc[2] + 1e-8f);
     }
+    ISTAMP(7)
 }
 
 // ---- kernel 2: attention over the pair slab, out[b,i,h,:] = sum_j attn[b,i,j,h] * z[b,i,j,:] --------------------------------
@@ -443,6 +459,12 @@ extern "C" int abx_ipa_weights(const float* qpack, const float* kpack, const flo
                        rots, trans, point_weights, attn_ws, feat, B, L);
     return abx_check_launch("abx_ipa_weights");
 }
+
+#ifdef IPA_STAMP
+extern "C" int abx_ipa_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ipa_stamp_buf), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 extern "C" int abx_ipa_pair(const float* attn_ws, const float* z, float* feat, int B, int L, hipStream_t st) {
     ABX_REQUIRE(attn_ws && z && feat && B > 0 && L > 0 && (long long)B * L < (1ll << 31), "abx_ipa_pair: bad args");
