@@ -798,8 +798,13 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
                     // their logits are clamped to -inf (Msb), their softmax weights are exactly 0 against a finite V row
                     const unsigned off = __umul24((unsigned)min(c0 + rd * KRD + kk0[j], L - 1), sl4) + gco[j];
                     // read once per launch: non-temporal, so that the K / V stream does not push the pair's bias out of the L2
+#ifdef TRI8_TEMPORAL                                                    // (probe: plain loads)
+                    kr[set][j] = *reinterpret_cast<const f32x4*>(kb + off);
+                    vr[set][j] = *reinterpret_cast<const f32x4*>(vb + off);
+#else
                     kr[set][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kb + off));
                     vr[set][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vb + off));
+#endif
                 }
             };
             auto convert = [&](int rd, auto set_) __attribute__((always_inline)) {
