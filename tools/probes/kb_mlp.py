@@ -27,3 +27,7 @@ fused(); ref = out.clone(); fused3(); print('3-stage ring identical:', bool(torc
 for name, fn in (('two launches', two), ('fused mlp (2 blocks/CU)', fused), ('fused mlp, 3-stage GEMM 1 ring', fused3), ('fused mlp (2 blocks/CU)', fused), ('fused mlp, 3-stage GEMM 1 ring', fused3)):
     ms = timeit(fn, reps=7)
     print(f'{name:34s} Bc={Bc} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == 'occ1':     # the one-block-per-CU instantiation (tune bit 4): how much the second resident block is worth
+    for name, fn in (('fused mlp (1 block/CU)', fused1), ('fused mlp (2 blocks/CU)', fused)):
+        ms = timeit(fn, reps=7)
+        print(f'{name:34s} Bc={Bc} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
