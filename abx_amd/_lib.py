@@ -242,6 +242,11 @@ class AbxHipError(RuntimeError):
     pass
 
 
+def library_path():
+    """Path of the shared object that load() binds (ABX_HIP_LIB or the in-tree build)."""
+    return LIB_PATH
+
+
 def load():
     """Load the library (raises if it has not been built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
     global _lib

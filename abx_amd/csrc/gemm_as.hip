@@ -668,7 +668,12 @@ int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, 
     if ((long long)(g.K / 16) * g.sB3k >= (1LL << 31)) return 1;
     const long long ntm = ((long long)g.M + AS_BM - 1) / AS_BM;
     if (ntm * g.batch >= (1LL << 31)) return 1;
-    // the walk pays from two N-tiles on; small problems keep the tile kernels (more blocks than CUs matter more there)
+    // the walk pays from two N-tiles on; small problems keep the tile kernels (more blocks than CUs matter more there).
+    // INVARIANT: this choice depends on the LAUNCH size, also under exact == 2 where the caller has fixed the arithmetic class so that a
+    // sample's bits do not depend on how many samples share a launch - batch / chunk / shard invariance of the network therefore rests on
+    // this kernel being BIT-IDENTICAL to the tile kernels of gemm3.hip (test_gemm_as_*: edge and non-edge shapes, with / without a side,
+    // a_relu, and test_gemm_as_dispatch_threshold_is_bit_invariant across this very threshold).  A change that gives that up must gate
+    // the kernel on L (the complex) instead of M (the launch).
     if (g.N < 256 || ntm * g.batch < 1024) return 1;
     const bool glu = g.glu != 0;
     if (glu) {

@@ -306,7 +306,8 @@ def main(argv=None):
             t_done = time.perf_counter()
             TIMINGS.append(dict(complex=cname, L=int(L), samples=n, mode=a.mode, opt_step=opt_step, read_and_featurise_s=t_feat - t_job,
                                 sampling_s=t_samp - t_feat, writer_tail_s=t_done - t_samp, files=len(new_files),
-                                range_fallbacks=len(traj[-1].get('range_fallbacks', []))))
+                                range_fallbacks=len(traj[-1].get('range_fallbacks', [])),
+                                range_sticky_ops=list(traj[-1].get('range_sticky_ops', []))))
             local = {'seq': traj[-1]['seq'], 'pLDDT': traj[-1]['pLDDT']}
         else:                                                   # more ranks than samples: join the gather with zero-row blocks
             local = {'seq': torch.zeros(0, Lab, dtype=torch.int64, device=dev), 'pLDDT': torch.zeros(0, Lab, device=dev)}

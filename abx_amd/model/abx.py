@@ -64,8 +64,11 @@ class ScoreNetwork(nn.Module):
         self._bufs = {}
         self.range_log = []              # calls that left the split-f16 operand ranges and were repeated with the flagged op class exact
         self.range_sticky_after = 2      # flagged calls after which the flagged classes STAY on the exact kernels (no more repeats)
-        self._sticky_tags = 0            # op classes (ops.RANGE_TAGS bits) that run exact from now on
-        self._flagged_calls = 0
+        self._sticky_tags = 0            # op classes (ops.RANGE_TAGS bits) that run exact from now on - for the CURRENT complex
+        self._flagged_calls = 0          # flagged calls on the current complex
+        self._complex_sig = None         # what `_sticky_tags` / `_flagged_calls` belong to (see _scope_range_state)
+        self.forced_exact_ops = ()       # op classes (ops.RANGE_TAGS names) pinned to the exact kernels for the module's life (bench.py
+                                         # --exact-class: what a checkpoint whose activations leave the split range would cost)
         self._pinned = set()
         self._n_calls = 0
 
@@ -110,6 +113,34 @@ class ScoreNetwork(nn.Module):
             self._bufs[name] = b
         return b
 
+    def _scope_range_state(self, batch, L):
+        """Sticky exact classes and the flagged-call count belong to ONE complex: a flag history of an earlier complex, sample
+        block or rank must not change the low-order bits of a later one.  Called where the trajectory-invariant embeddings are rebuilt (a
+        new batch dict): the complex is identified by the CONTENT of sample 0's context (length, sequence, fixed mask, coordinates - four
+        small reductions, one read-back next to the one the range word of the embeddings costs anyway), so a fresh dict of the same
+        complex keeps its history and another complex starts clean."""
+        seq0 = batch['seq'][0].to(torch.float64)
+        pos = torch.arange(1, L + 1, device=seq0.device, dtype=torch.float64)
+        sig = (L,) + tuple(torch.stack([(seq0 * pos).sum(), (batch['fixed_mask'][0].to(torch.float64) * pos).sum(),
+                                        batch['atom14_gt_positions'][0].to(torch.float64).sum()]).tolist())
+        if sig != self._complex_sig:
+            self._complex_sig = sig
+            self._sticky_tags = self._forced_tags()
+            self._flagged_calls = 0
+
+    def _forced_tags(self):
+        from abx_amd import ops
+        bits = 0
+        for n in self.forced_exact_ops:
+            bits |= ops.RANGE_TAGS[n]
+        return bits
+
+    @property
+    def range_sticky_ops(self):
+        """Names of the op classes that run on the exact kernels for the current complex."""
+        from abx_amd import ops
+        return ops.range_names(self._sticky_tags)
+
     # ---- forward ----------------------------------------------------------------------------------------------------
     def forward(self, input_feats, compute_loss=True):
         batch = input_feats
@@ -136,10 +167,14 @@ class ScoreNetwork(nn.Module):
         word = ops.range_words(device) if ops.RANGE_CHECK and not ops.GEMM_EXACT else None
         capturing = torch.cuda.is_current_stream_capturing()
         P = eng.P
+        self._sticky_tags |= self._forced_tags()
         P.exact_tags = self._sticky_tags
         skey = (id(self), self._engine_serial, B, L, shared, ctx)
         hit = batch.get('_static')
         if hit is None or hit[0] != skey:
+            if not capturing:
+                self._scope_range_state(batch, L)
+                P.exact_tags = self._sticky_tags
             # the cached embeddings are built by range-tagged GEMMs too: their own clean word, and a rebuild on the exact kernels when
             # they set it (one host synchronisation per complex)
             if word is not None and not capturing:
@@ -149,7 +184,8 @@ class ScoreNetwork(nn.Module):
             if word is not None and not capturing and any(word.tolist()):
                 self._sticky_tags |= ops.RANGE_TAGS['gemm']
                 P.exact_tags = self._sticky_tags
-                self.range_log.append({'call': self._n_calls + 1, 'ops': ['gemm'], 'where': 'static embeddings', 'L': L, 'B': B, 'sticky': True})
+                self.range_log.append({'call': self._n_calls + 1, 'ops': ['gemm'], 'where': 'static embeddings', 'L': L, 'B': B, 'sticky': True,
+                                       'sticky_set': ops.range_names(self._sticky_tags)})
                 emb = eng.static_embeddings(batch, shared)
             hit = (skey, emb)
             batch['_static'] = hit
@@ -180,8 +216,9 @@ class ScoreNetwork(nn.Module):
         # is pinned).  A flagged call is repeated with the FIRST flagged op class of the pass (ops.RANGE_ORDER: every class behind it only
         # saw its NaN rows) on the exact fp32-MFMA kernels and everything else still on the split-f16 ones; if the repeat flags a later
         # class, that one joins, and so on (at most one repeat per class).  After `range_sticky_after` flagged calls the classes found
-        # so far stay exact for the rest of the module's life (a checkpoint whose activations sit beyond the range would otherwise pay split
-        # + exact on every call), logged once.  A caller never sees the contract: results are the reference's either way.  All samples of
+        # so far stay exact for the rest of THIS COMPLEX (a checkpoint whose activations sit beyond the range would otherwise pay split
+        # + exact on every call; _scope_range_state starts the next complex clean, so that its bits do not depend on what ran before it on
+        # this rank), logged once and carried in the trajectory's metadata (`range_fallbacks` / `range_sticky_ops`).  A caller never sees the contract: results are the reference's either way.  All samples of
         # a call share the arithmetic switch, so a sample's low-order bits depend on its batch mates IN A FLAGGED CALL ONLY.  Inside a
         # hipGraph capture the word only accumulates (abx_amd.graph checks it after each replay).
         start = {k: batch.get(k) for k in ('seq_t', 'prev_pos', 'prev_seq', 'prev_pair')}
@@ -218,6 +255,7 @@ class ScoreNetwork(nn.Module):
                     if self._flagged_calls >= self.range_sticky_after and (tags & ~self._sticky_tags):
                         self._sticky_tags |= tags
                         entry['sticky'] = True
+                        entry['sticky_set'] = ops.range_names(self._sticky_tags)
                         import logging
                         logging.getLogger('abx_amd').warning(
                             'split-f16 operand ranges left in %d calls: the op classes %s run on the exact fp32-MFMA kernels from now on',

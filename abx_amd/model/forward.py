@@ -522,9 +522,10 @@ class Engine:
             qkv = w768.view(-1)[:M2 * 576].view(M2, 576)
             # (the split-f16 attention takes the bias in its accumulator units: the factor rides in the projection's epilogue)
             bl2 = not (ops.GEMM_EXACT if ae is None else ae)
-            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True, exact=am),
+            # (range class 'tri_attn' as abx_tri_attn_block_fwd tags them: the tag of a launch follows the switch that sets its arithmetic)
+            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True, exact=am, range_class='tri_attn'),
                           _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True, exact=am,
-                                  alpha=ops.TRI_BIAS_LOG2 if bl2 else 1.0))
+                                  alpha=ops.TRI_BIAS_LOG2 if bl2 else 1.0, range_class='tri_attn'))
             o = w384[:M2 * 192].view(M2, 192)
             # bias[b,h,q,k] key-contiguous in rows of Lp floats (16-byte loads for any L).  Ending node: bias[b,h,q,k] = P[b,k,q,h],
             # i.e. the transpose (2 MB per sample); starting node: a padded copy only when L % 4 != 0

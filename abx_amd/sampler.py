@@ -108,6 +108,9 @@ def sample_fn(data_init, config, diffuser, model, mode='design', num_t=100, min_
     log = getattr(model, 'range_log', None)
     if log and len(log) > log_start:
         traj[-1]['range_fallbacks'] = list(log[log_start:])     # calls of THIS trajectory repeated with an op class on the exact kernels
+        # the classes that ended up sticky-exact for this complex: a digest that differs between two placements of the same samples
+        # (different batch mates in a flagged call, a different flag history per rank) is explained by these two entries
+        traj[-1]['range_sticky_ops'] = list(getattr(model, 'range_sticky_ops', []))
     return traj
 
 

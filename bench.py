@@ -57,6 +57,18 @@ def algorithmic_flops_per_sample_step(L):
     return 3 * 2 * (1.064e6 * L * L + 1024.0 * L ** 3 + 12.4e6 * L + 1088.0 * L * L)
 
 
+def library_stamp():
+    """Size and sha256 of the libabx_hip.so this process runs on (what profiles/pmc_traffic.json is stamped with)."""
+    import hashlib
+    from abx_amd import _lib
+    path = _lib.library_path()
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 20), b''):
+            h.update(blk)
+    return {'lib_bytes': os.path.getsize(path), 'lib_sha256': h.hexdigest()}
+
+
 def model_parameter_shapes(cfg):
     """Names and shapes of the 190 ScoreNetwork parameters, from the module tree itself (the checkpoint contract)."""
     from abx_amd.model.abx import ScoreNetwork
@@ -123,11 +135,15 @@ class OpTimer:
         if name == 'ipa_weights':
             Bc, L = args[10], args[11]
             return 'ipa_weights_kernel', 2.0 * Bc * L * L * 12 * (28 + 40), 4.0 * Bc * L * L * (12 + 12)
+        if name == 'assemble_pair':     # 320 channel reads (prev_pair 192 + static 128, shared over the samples) + 192 written per pair
+            Bc, L = args[8], args[9]
+            return 'assemble_pair192_kernel', 0.0, 4.0 * Bc * L * L * (192 + 192 + 2) + 4.0 * L * L * 128
         return name, 0.0, 0.0
 
     def __enter__(self):
         skip = ('gemm_kernel_name', 'gemm_as_kernel_name', 'gemm_split_eligible', 'tri_attn_kernel_name', 'gemm_mode', 'ipa_qpack_numel', 'permute_k16', 'atom14_mask_table', 'vdw_radius_table',
-                'range_word', 'range_names', 'pad_planes_128')       # (host-side helpers: no launch to time)
+                'range_word', 'range_names', 'range_ptr', 'range_words', 'first_range_tag', 'pad_planes_128', 'weights_to_float',
+                'planes_to_float')       # (host-side helpers: no launch to time)
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
             if callable(fn) and not isinstance(fn, type) and not name.startswith('_') and name not in skip and getattr(fn, '__module__', '') == self.ops.__name__:
@@ -363,6 +379,9 @@ def main():
     ap.add_argument('--samples', type=int, default=100, help='samples of the complex: in total (strong scaling) or per GPU (weak)')
     ap.add_argument('--scaling', choices=['strong', 'weak'], default='strong')
     ap.add_argument('--chunk', type=int, default=0, help='samples per pair-stack launch (0 = as many as fit: the whole per-GPU batch)')
+    ap.add_argument('--exact-class', default='', help='comma-separated op classes (abx_amd.ops.RANGE_TAGS: tri_attn, pair_transition, '
+                    'plane_projection, ...) pinned to the exact fp32-MFMA kernels: the price of a checkpoint whose activations leave the '
+                    'split-f16 operand range in that class (the sticky state of ScoreNetwork)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-op-profile', action='store_true')
     ap.add_argument('--no-weak', action='store_true', help='N > 1: skip the additional weak-scaling measurement')
@@ -414,6 +433,7 @@ def main():
     model.load_state_dict(params, strict=True)
     model = model.to(dev).eval()
     model.max_chunk = args.chunk or None
+    model.forced_exact_ops = tuple(c for c in args.exact_class.split(',') if c)
 
     w = synthetic.WORKLOADS[args.workload]
     cx = synthetic.make_complex(seed=1, **w)
@@ -530,6 +550,7 @@ def main():
                                f'{total} samples of one complex over {world} GPU(s), 1 step = ScoreNetwork (3 passes) + get_prev '
                                '+ reverse, seeded random weights, ESM off', 'L': L, 'samples_total': total,
                    'samples_per_rank': per_rank, 'chunk': args.chunk or 'auto', 'parallelism': f'sample-shard x{world}, no collective in the step'},
+        'exact_classes': list(model.forced_exact_ops), 'range_fallbacks': len(model.range_log),
         'finite': st['finite'], 'rccl_ranks': rccl_ranks, 'gather_ms': gather_ms, 'result_digest': hd.hexdigest(),
         # a T = 100 trajectory is 100 steps + the self-conditioning warm-up call; this is the rate with that call inside the wall
         'selfcond_warmup_call_ms': st.get('selfcond_call_ms'),
@@ -571,21 +592,32 @@ def main():
                     achieved_tflops=fl / dur / 1e12, achieved_gbs=by / dur / 1e9,
                     peak_note=('matrix peak for this arithmetic: dense f16 MFMA 2516.6 TF / 3 products per fp32 product (split-f16) = 838.9 TF'
                                if split else 'matrix peak: native fp32 MFMA 157.3 TF'))
-        traffic = None
+        # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md; tools/pmc_traffic.py).  The table is stamped
+        # with the library it was collected on and its geometry (`_meta`): a table that belongs to another build or another batch is
+        # reported as stale, and the whole-step sum is only formed at the table's own geometry (launch bytes scale with the rows)
         pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         pmc_tab = json.load(open(pmc)) if os.path.exists(pmc) else {}
-        if pmc_tab:                         # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/README.md)
-            traffic = pmc_tab.get(name, {}).get('hbm_bytes_per_launch')
+        meta = pmc_tab.pop('_meta', None) if pmc_tab else None
+        lib_now = library_stamp()
+        same_build = bool(meta) and meta.get('lib_sha256') == lib_now['lib_sha256']
+        same_geometry = bool(meta) and int(meta.get('samples', -1)) == B0 and int(meta.get('L', -1)) == L
+        traffic_stale = bool(pmc_tab) and not (same_build and same_geometry)
+        result['traffic_table'] = {'file': 'profiles/pmc_traffic.json' if pmc_tab else None, 'meta': meta, 'running_library': lib_now,
+                                   'same_build': same_build, 'same_geometry': same_geometry}
+        result['traffic_stale'] = traffic_stale
+        per_launch = (lambda nm: pmc_tab.get(nm, {}).get('hbm_bytes_per_launch')) if (pmc_tab and (same_geometry or not meta)) else (lambda nm: None)
+        traffic = per_launch(name)
         roof.update(traffic=traffic, kernel=name, calls_per_step=calls,
                     avg_launch_ms=ms / calls, share_of_step=ms / tot_ms,
                     traffic_source=('profiles/pmc_traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes at the '
-                                    'bench geometry (FETCH_SIZE x 2 + WRITE_SIZE); NOT collected in this run') if traffic is not None else None)
+                                    'bench geometry (FETCH_SIZE x 2 + WRITE_SIZE); NOT collected in this run'
+                                    + ('; STALE: collected on another build of the library' if not same_build else '')) if traffic is not None else None)
         # whole-step counter traffic: launches of this step x the per-launch HBM bytes of the same PMC table (kernels of the op profile
         # that the table knows; the share of the step time they cover is reported next to it)
-        if pmc_tab:
+        if pmc_tab and (same_geometry or not meta):
             tb, covered = 0.0, 0.0
             for nm, ms_, calls_, _, _ in summ:
-                t_ = pmc_tab.get(nm, {}).get('hbm_bytes_per_launch')
+                t_ = per_launch(nm)
                 if t_ is not None:
                     tb += t_ * calls_
                     covered += ms_
@@ -594,11 +626,43 @@ def main():
                                            f'FETCH_SIZE x 2 + WRITE_SIZE at the bench geometry); covers {covered / tot_ms:.3f} of the step time; algorithmic '
                                            f'bytes of the step: {B0 * algorithmic_bytes_per_sample_step(L):.4g}')
             result['step_traffic_over_algorithmic'] = tb / (B0 * algorithmic_bytes_per_sample_step(L))
+        elif pmc_tab:
+            result['step_traffic_note'] = (f'not formed: profiles/pmc_traffic.json was collected at {meta.get("samples")} samples of L = {meta.get("L")}, '
+                                           f'this run has {B0} of L = {L} (bytes per launch scale with the rows)')
+        # the whole roofline picture: every kernel that takes >= 2 % of the step, priced like the dominant one
+        kernels = []
+        for nm, ms_, calls_, fl_, by_ in summ:
+            if ms_ < 0.02 * tot_ms:
+                continue
+            sp = nm.startswith(('gemm3_', 'gemm_as_', 'tri_attn4', 'tri_attn8'))
+            pk = MFMA_SPLIT_PEAK_TF if sp else MFMA_F32_PEAK_TF
+            d_ = ms_ / 1e3
+            ent = {'kernel': nm, 'calls_per_step': calls_, 'avg_launch_ms': ms_ / calls_, 'share_of_step': ms_ / tot_ms,
+                   'arithmetic': 'split-f16 (peak 838.9 TF)' if sp else 'fp32 (peak 157.3 TF)'}
+            if by_:
+                inten, rdg = (fl_ / by_), pk * 1e12 / (HBM_PEAK_GBS * 1e9)
+                ent.update(bound='hbm' if inten < rdg else 'mfma', intensity_flop_per_byte=inten,
+                           frac_hbm=by_ / d_ / 1e9 / HBM_PEAK_GBS, frac_mfma=(fl_ / d_ / 1e12 / pk) if fl_ else None,
+                           algorithmic_bytes_per_launch=by_ / calls_)
+                ent['frac'] = ent['frac_hbm'] if ent['bound'] == 'hbm' else ent['frac_mfma']
+                t_ = per_launch(nm)
+                ent['traffic_bytes_per_launch'] = t_
+                ent['traffic_over_algorithmic'] = (t_ / (by_ / calls_)) if t_ else None
+            kernels.append(ent)
+        result['roofline_kernels'] = kernels
+        priced = [k for k in kernels if k.get('frac') is not None]
+        if priced:
+            worst = min(priced, key=lambda k: k['frac'])
+            result['roofline_furthest_below_roof'] = {'kernel': worst['kernel'], 'bound': worst['bound'], 'frac': worst['frac']}
+            rat = [k for k in priced if k.get('traffic_over_algorithmic')]
+            if rat:
+                wr = max(rat, key=lambda k: k['traffic_over_algorithmic'])
+                result['roofline_worst_traffic_ratio'] = {'kernel': wr['kernel'], 'traffic_over_algorithmic': wr['traffic_over_algorithmic']}
         result['roofline'] = roof
         # the kernel north_star calls HBM-bound (the IPA pair-slab stream), priced the same way next to the dominant one
         for nm, ms2, calls2, fl2, by2 in summ:
             if nm == 'ipa_pair_kernel':
-                tr2 = json.load(open(pmc)).get(nm, {}).get('hbm_bytes_per_launch') if os.path.exists(pmc) else None
+                tr2 = per_launch(nm)
                 result['roofline_ipa_pair_slab'] = {
                     'bound': 'hbm', 'achieved': by2 / (ms2 / 1e3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': by2 / (ms2 / 1e3) / 1e9 / HBM_PEAK_GBS, 'traffic': tr2, 'kernel': nm, 'calls_per_step': calls2,

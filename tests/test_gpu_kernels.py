@@ -1578,7 +1578,7 @@ def test_gemm_narrow_split_tile(ops, N, K, transposed, ln):
 AS_OFF = 2048        # AbxGemm.tune bit 11: keep the tile kernels of gemm3.hip
 
 
-@pytest.mark.parametrize('L,Bc', [(72, 13), (65, 16), (118, 5)])
+@pytest.mark.parametrize('L,Bc', [(72, 13), (65, 16), (118, 5), (128, 4)])
 def test_gemm_as_plain_and_side_equal_the_tile_kernels(ops, L, Bc):
     """The K = 192 LayerNorm projections on the A-stationary kernel (a block owns 64 rows, splits them once, walks all column tiles;
     seqformer.py:520-531): q | k | v (N = 576) with the pair bias (N = 4, (b, h, i, j) store) in the free half of its ragged last column tile,
@@ -1612,6 +1612,42 @@ def test_gemm_as_plain_and_side_equal_the_tile_kernels(ops, L, Bc):
         if side:
             assert torch.equal(outs[0][1], outs[1][1])
             check(outs[0][1], (ln @ Wb.double().cpu() + bb.double().cpu()).transpose(1, 2), 5e-6, f'side bias L={L}')
+
+
+def test_gemm_as_dispatch_threshold_is_bit_invariant(ops):
+    """abx_gemm picks the A-stationary kernel by LAUNCH SIZE (>= 1024 blocks of 64 rows) even when the caller fixed the
+    arithmetic class (exact = 2), so batch / chunk invariance of the network rests on the two kernel families being bit-identical.  The
+    same rows through a launch of 1 024 blocks (A-stationary kernel) and of 1 023 blocks (tile kernels; the last block of rows dropped)
+    must agree in every bit - with a side projection and without one, at a non-edge shape (M % 128 == 0).  (relu-on-load cannot reach
+    the A-stationary kernel: it needs a folded LayerNorm, and abx_gemm rejects LayerNorm + a_relu - asserted below.)
+    Any change to gemm_as.hip has to keep this test green, or gate the kernel on L instead of M."""
+    ge = g(1930)
+    K, N = 192, 576
+    M1, M0 = 1024 * 64, 1023 * 64
+    z = (torch.randn(M1, K, generator=ge) * 1.2 + 0.1).to(DEV)
+    Wq = (torch.randn(K, N, generator=ge) / K ** 0.5).to(DEV)
+    bq, csq, W3q = torch.randn(N, generator=ge).to(DEV), Wq.sum(0).contiguous(), ops.split_weights(Wq)
+    Wb = (torch.randn(K, 4, generator=ge) / K ** 0.5).to(DEV)
+    bb, csb, W3b = torch.randn(4, generator=ge).to(DEV), Wb.sum(0).contiguous(), ops.split_weights(Wb)
+    for side in (False, True):
+        outs = []
+        for M in (M1, M0):
+            q = torch.full((M, N), float('nan'), device=DEV)
+            bT = torch.full((1, 4, M), float('nan'), device=DEV)
+            kq = dict(bias=bq, ln=(None, csq), B3=W3q, exact=2)
+            if side:
+                ops.gemm_side(ops.gemm(z[:M], Wq, q, defer=True, **kq),
+                              ops.gemm(z[:M].view(1, M, K), Wb, bT.transpose(1, 2), defer=True, bias=bb, ln=(None, csb), B3=W3b, exact=2))
+            else:
+                ops.gemm(z[:M], Wq, q, **kq)
+            outs.append((q, bT))
+        assert torch.isfinite(outs[0][0]).all()
+        assert torch.equal(outs[0][0][:M0], outs[1][0]), (side, float((outs[0][0][:M0] - outs[1][0]).abs().max()))
+        if side:
+            assert torch.equal(outs[0][1][:, :, :M0], outs[1][1])
+    from abx_amd._lib import AbxHipError
+    with pytest.raises(AbxHipError, match='exclusive'):
+        ops.gemm(z, Wq, torch.empty(M1, N, device=DEV), bias=bq, ln=(None, csq), B3=W3q, exact=2, a_relu=True)
 
 
 @pytest.mark.parametrize('L,Bc', [(128, 5), (118, 6), (72, 14)])

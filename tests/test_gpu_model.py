@@ -1479,3 +1479,58 @@ def test_op_group_entry_points_equal_the_descriptor_level_path(gpu_model, cfg):
     W2p = W2t.view(48, 16, 192)[:, perm, :].reshape(768, 192).double()
     got = ops.weights_to_float(l2.planes).cpu().double()
     assert float((got - W2p).abs().max()) <= 2.0 ** -22 * float(W2p.abs().max())
+
+
+def _visible_gpus():
+    try:
+        return torch.cuda.device_count()
+    except Exception:          # noqa: BLE001 (no driver: 0 devices)
+        return 0
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason='needs >= 2 MI355X (one rank per device over RCCL); skipped on 1-GPU boxes')
+def test_multi_gpu_rccl_one_rank_per_device(tmp_path):
+    """the N-rank RCCL path on REAL devices (the reference only stubs it: inference.py:59-82, 389-394).  Wakes up on a box
+    with >= 2 GPUs (N = min(count, 8)), one device per rank, backend 'nccl' (= RCCL over xGMI):
+      * `bench.py --gpus N` (it starts its own ranks) reports rccl_ranks == N, per-rank shards that add up, and the result digest of the
+        1-GPU run of the same 16 samples - per-sample noise keys make a sample's trajectory independent of where it runs, and the
+        arithmetic class of every kernel is fixed by L, not by the batch, so the gathered final state must be byte-identical;
+      * `abx_amd.design --gpu_list 0 .. N-1` on the two shipped complexes (npz entries), set-level schedule and --shard_samples: the
+        output tree is byte-for-byte the single-process tree."""
+    import json
+    import subprocess
+    import sys
+    from conftest import GOLDEN
+    N = min(_visible_gpus(), 8)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    args = ['--steps', '1', '--warmup', '0', '--samples', '16', '--workload', 'L256', '--no-cpu-baseline', '--no-op-profile', '--no-weak']
+    out = {}
+    for tag, n in (('one', 1), ('many', N)):
+        r = subprocess.run([sys.executable, 'bench.py', '--gpus', str(n)] + args, env=env, cwd=root, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-4000:]
+        out[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    many = out['many']
+    assert many['n_gpus'] == N and many['rccl_ranks'] == N and many['gather_ms'] is not None, many
+    assert sum(many['config']['samples_per_rank']) == 16 and len(many['config']['samples_per_rank']) == N
+    assert many['finite'] and len(many['result_digest']) == 64
+    assert many['result_digest'] == out['one']['result_digest'], 'the gathered final state depends on the placement of the samples'
+    # the design driver on the listed GPUs: files of every rank + the gathered designs table against the single-process tree
+    idx = tmp_path / 'test.idx'
+    idx.write_text('6ct7_H_L_S\n6qd7_X_Z_F|E\n')
+    ns = max(4, N)
+    common = ['--name_idx', str(idx), '--data_dir', os.path.join(GOLDEN, 'npz'), '--num_samples', str(ns), '--num_t', '3', '--mode', 'design']
+    gl = ['--gpu_list'] + [str(g) for g in range(N)]
+    trees = {}
+    for tag, extra in (('one', ['--gpu_list', '0']), ('set', gl + ['--min_block', str(max(1, ns // 2))]), ('shard', gl + ['--shard_samples'])):
+        od = str(tmp_path / tag)
+        r = subprocess.run([sys.executable, '-m', 'abx_amd.design'] + common + extra + ['--output_dir', od], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, tag + r.stdout[-2000:] + r.stderr[-4000:]
+        trees[tag] = {os.path.relpath(os.path.join(dp, f), od): open(os.path.join(dp, f), 'rb').read() for dp, _, fs in os.walk(od) for f in fs}
+    for tag in ('set', 'shard'):
+        assert sorted(trees[tag]) == sorted(trees['one']), (tag, sorted(set(trees[tag]) ^ set(trees['one'])))
+        diff = [k for k in trees['one'] if trees['one'][k] != trees[tag][k]]
+        assert not diff, (tag, diff)

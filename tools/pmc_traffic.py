@@ -5,7 +5,10 @@ the same bench command -> profiles/pmc_traffic.json, read by bench.py for roofli
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py --steps 1 ...
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic.json
 Corrections (MI355X_MICROARCH.md, HBM section; checked against a known byte count in profiles/r01c_pmc_gemm.txt):
-FETCH_SIZE is in KB and counts 128-byte requests as 64 bytes on gfx950 -> bytes = KB * 1024 * 2; WRITE_SIZE bytes = KB * 1024."""
+FETCH_SIZE is in KB and counts 128-byte requests as 64 bytes on gfx950 -> bytes = KB * 1024 * 2; WRITE_SIZE bytes = KB * 1024.
+The table is stamped (`_meta`) with the library it was collected on (size, sha256 of abx_amd/csrc/libabx_hip.so or $ABX_HIP_LIB) and
+whatever `key=value` pairs follow the three paths (bench geometry: samples=100 L=352; git_commit=<hash> from the calling side - the GPU
+box has no .git): bench.py reports `traffic_stale` when the running library or the geometry differ."""
 import csv
 import glob
 import json
@@ -39,7 +42,15 @@ def collect(d, counter):
     return acc
 
 
-def main(fetch_dir, write_dir, out):
+def library_stamp():
+    import hashlib
+    path = os.environ.get('ABX_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'abx_amd', 'csrc', 'libabx_hip.so')
+    if not os.path.exists(path):
+        return {}
+    return {'lib_bytes': os.path.getsize(path), 'lib_sha256': hashlib.sha256(open(path, 'rb').read()).hexdigest()}
+
+
+def main(fetch_dir, write_dir, out, *meta):
     fe, wr = collect(fetch_dir, 'FETCH_SIZE'), collect(write_dir, 'WRITE_SIZE')
     res = {}
     for k in sorted(set(fe) | set(wr)):
@@ -47,10 +58,16 @@ def main(fetch_dir, write_dir, out):
         w = sum(wr.get(k, [0])) / max(len(wr.get(k, [])), 1) * 1024
         res[k] = {'launches': len(fe.get(k, [])), 'hbm_read_bytes_per_launch': f, 'hbm_write_bytes_per_launch': w,
                   'hbm_bytes_per_launch': f + w}
+    stamp = library_stamp()
+    for kv in meta:
+        k, _, v = kv.partition('=')
+        stamp[k] = int(v) if v.isdigit() else v
+    res['_meta'] = stamp
     json.dump(res, open(out, 'w'), indent=1)
+    del res['_meta']
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:12]:
         print(f"{k[:70]:70s} n={v['launches']:5d} read {v['hbm_read_bytes_per_launch'] / 1e6:9.1f} MB write {v['hbm_write_bytes_per_launch'] / 1e6:9.1f} MB")
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:])

@@ -1,5 +1,6 @@
 # One profiling round on the GPU box (bash tools/probes/prof_round.sh <tag>): headline bench with CPU baseline, the per-GPU batch sizes of
 # strong scaling, rocprofv3 kernel stats + HBM traffic passes of the same command, in-kernel clocks, counter passes of the dominant kernels.
+# GIT_COMMIT=<hash> in the environment stamps profiles/pmc_traffic.json (the GPU box has no .git: pass it from the calling side).
 TAG=${1:-r04}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
@@ -11,7 +12,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --steps 1 --
 python tools/rocprof_summary.py $(find $O/prof -name "*results.db" | head -1) $O/kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-op-profile > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-op-profile > $O/pmc_write.log 2>&1
-python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json samples=100 L=352 git_commit=${GIT_COMMIT:-unknown} > $O/pmc_traffic.log 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/prof
 python tools/probes/clock_probe.py 3 > $O/clock.txt 2>&1
 bash tools/pmc_run.sh tri ${TAG}_tri; python tools/pmc_reduce.py gpurun_out/${TAG}_tri tri_attn8 > $O/pmc_triattn8.txt
