@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_mlp3_kernel(const AbxGemm g) {
 //   GEMM 2 streams the W_o planes (k order permuted inside every 16-tile like the fused transition's second layer).
 constexpr int GT_NG = 192;                                                   // gate channels (LDS table)
 template <bool EDGE>
-__device__ __forceinline__ void gemm3_gtail_block(const AbxGemm& g, float* smem, int mt, int b) {
+__device__ __forceinline__ void gemm3_gtail2w_block(const AbxGemm& g, float* smem, int mt, int b) {
     constexpr int BM = 128, BN = 96, WM = 32, WN = 96, BN2 = 192, TN2 = BN2 / 32;
     constexpr int G1_BYTES = 2 * BM * 64 + 2 * 2 * BN * 32;                  // stages of GEMM 1 (A fp32 + gate-weight planes)
     constexpr int B2_IMG = 2 * BN2 * 32;                                     // one k-tile of W_o: [2][192][16] f16
@@ -881,6 +881,167 @@ __device__ __forceinline__ void gemm3_gtail_block(const AbxGemm& g, float* smem,
 
 constexpr int GT_LDS = 2 * 128 * 64 + 2 * 2 * 96 * 32 + 2 * 2 * 192 * 32 + 3 * 128 * 64 + 2 * GT_NG * 4;      // 79 360 bytes (two blocks per CU)
 
+// the round-5 form (two walks over the z rows, one per gate chunk of 96): AbxGemm.tune bit 6, kept for A / B runs and as a cross-check
+// (test_gemm_gated_tail_walk_variants_bit_identical)
+__global__ __launch_bounds__(256, 2) void gemm3_gtail2w_kernel(const AbxGemm g) {
+    extern __shared__ __attribute__((aligned(16))) float gt_smem[];
+    const int ntm = (g.M + 127) / 128;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
+    const ClockProbe probe(g.clock_probe);
+    if ((mt + 1) * 128 <= g.M && g.N2 == 192) gemm3_gtail2w_block<false>(g, gt_smem, mt, b);
+    else gemm3_gtail2w_block<true>(g, gt_smem, mt, b);
+    probe.finish();
+}
+
+// Round 6: ONE walk over the z rows.  The board's power limit holds the clock of every large kernel (profiles/r06a_power_limit.txt), so
+// what a launch costs is its energy, and the two-walk form paid the whole A side of GEMM 1 twice: 2 x 98 KB of z rows per block from the
+// fabric (the second walk misses the 4 MB L2: 64 resident blocks x 98 KB per XCD), 2 x 12 k-steps of fragment reads, LayerNorm partial
+// sums and f16 splits.  Here:
+//   GEMM 1   all 192 gate channels in one main loop (128 x 192 tile, swapped operands: gate^T[channel][row], lane = row), 96 accumulator
+//            registers - GEMM 2's accumulators do not exist yet;
+//   GEMM 2   in two PASSES over the output columns (0 .. 95, then 96 .. 191), 48 accumulator registers each.  Pass A turns the gate
+//            accumulators into the operand pieces of sigmoid(gate) * o k-tile by k-tile (the G stream, as before) and KEEPS them (the 96
+//            registers the gate accumulators leave); pass B replays them against the other half of W_o.  Each pass streams its half of
+//            the W_o planes [2][96][16] per k-tile (the same bytes as one pass over 192 columns), and ends with its own epilogue.
+// Every accumulator sees the products of the two-walk form in the same order: bit-identical results.
+constexpr int GT1_G1 = 2 * 128 * 64 + 2 * 2 * 192 * 32;                      // stages of GEMM 1: A fp32 + the gate-weight planes, 40 960
+constexpr int GT1_W2 = 2 * 96 * 32;                                          // one k-tile of a W_o half: [2][96][16] f16, 6 144
+constexpr int GT1_OFF_G = GT1_G1, GT1_OFF_W2 = GT1_OFF_G + 3 * 128 * 64, GT1_OFF_CST = GT1_OFF_W2 + 2 * GT1_W2;
+constexpr int GT1_LDS = GT1_OFF_CST + 2 * GT_NG * 4;                         // 79 360 bytes (two blocks per CU)
+template <bool EDGE>
+__device__ __forceinline__ void gemm3_gtail_block(const AbxGemm& g, float* smem, int mt, int b) {
+    constexpr int BM = 128, BN = 192, WM = 32, BH = 96, TH = BH / 32, NKT = BN / 16;
+    char* lds = reinterpret_cast<char*>(smem);
+    char* Gs = lds + GT1_OFF_G;                                              // 3 stages of G k-tiles (HBM: requested two steps ahead)
+    char* W2s = lds + GT1_OFF_W2;                                            // 2 stages; beyond the epilogue's scratch (52 KB from the base)
+    float* cst = reinterpret_cast<float*>(lds + GT1_OFF_CST);
+    for (int i = threadIdx.x; i < GT_NG; i += 256) {
+        cst[i] = i < g.N ? g.ln_csum[i] : 0.f;
+        cst[GT_NG + i] = (i < g.N && g.bias) ? g.bias[i] : 0.f;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5;
+    const int m0 = mt * BM;
+    // W_o half-tiles: 6 chunks of 1 KB per k-tile - waves 0 .. 2 fetch two each, wave 3 none (its counted waits below only ever leave the
+    // G pair in flight, which is the newest pair of every wave)
+    unsigned offs2[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) plane_sources<BH, 2>(g.sB23p, g.sB23n, half * BH, g.N2, offs2[half]);
+    const char* base2 = reinterpret_cast<const char*>(g.B2_split);
+    const long long step2 = g.sB23k * 2;
+    auto issue_w2 = [&](int half, int ktile) {                               // k-tile kt of the W_o half -> stage kt & 1
+        if (wave == 3) return;
+        char* dst = W2s + (ktile & 1) * GT1_W2 + wave * 2048;
+        const char* src = base2 + ktile * step2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(src + vgpr32(offs2[half][i]), dst + i * 1024);
+    };
+    unsigned offsG[2];
+    const char* baseG = reinterpret_cast<const char*>(g.gate + (long long)b * g.sGb + (long long)m0 * g.sGm);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 16 + (lane >> 2), p = lane & 3;
+        const int kq = p ^ ((r >> 2) & 3);
+        const int gri = min(m0 + r, g.M - 1) - m0;
+        offsG[i] = (unsigned)(((long long)gri * g.sGm + kq * 4) * 4);
+    }
+    const int nkt2 = g.N / 16;                                               // k-tiles of GEMM 2 (N % 16 == 0; <= NKT)
+    auto issue_g = [&](int ktile) {                                          // k-tile kt of G -> stage kt % 3; beyond the end: the last one again
+        const int kt = min(ktile, nkt2 - 1);
+        char* dg = Gs + (ktile % 3) * (BM * 64) + wave * 2048;
+        const char* sg = baseG + kt * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(sg + vgpr32(offsG[i]), dg + i * 1024);
+    };
+    const int offB2 = plane_off<BH>(0, lane & 31, h);
+    const int grow = wave * WM + (lane & 31), gx = (grow >> 2) & 3;
+    const int offG0 = grow * 64 + ((h ^ gx) << 4), offG1 = grow * 64 + (((2 + h) ^ gx) << 4);
+    const bool rows_live = m0 + wave * WM < g.M;
+
+    // ---- GEMM 1: gate^T for all gate channels; the first W_o half-tile and the first two G k-tiles land under it
+    issue_w2(0, 0);
+    issue_g(0);
+    issue_g(1);
+    float ls[1], lq[1], lsh[1] = {0.f};
+    f32x16 acc1[1][BN / 32];
+    gemm3_mainloop<BM, BN, WM, BN, 0, true, true>(g, smem, mt, 0, b, acc1, ls, lq, lsh);
+    const float invK = 1.0f / (float)g.K;
+    const float sm = ls[0] + __shfl_xor(ls[0], 32, 64), sq = lq[0] + __shfl_xor(lq[0], 32, 64);
+    const float dmean = sm * invK;
+    const float rstd = 1.0f / sqrtf(fmaxf(sq * invK - dmean * dmean, 0.f) + g.ln_eps);
+
+    AbxGemm g2 = g;
+    g2.N = g.N2; g2.bias = g.bias2; g2.ln_csum = nullptr; g2.ln_stats = nullptr; g2.act = 0; g2.alpha = 1.0f; g2.gate = nullptr;
+    const float cs2 = __builtin_ldexpf(1.0f, -4 - g.b2_exp);
+    u32x4 hfa[NKT][2];                                                       // the pieces of sigmoid(gate) * o, k-tile by k-tile (pass A -> pass B)
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};                      // smallest first: a1 p0, a0 p1, a0 p0
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 acc2[1][TH];
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][t][r] = 0.f;
+        if (half == 1) issue_w2(1, 0);                                       // (requested after the barrier that ended pass A's last step)
+#pragma unroll
+        for (int kg = 0; kg < NKT; ++kg) {
+            const bool more = (kg + 1) * 16 < g.N && kg + 1 < NKT;
+            if (half == 1 && kg == 0) wait_vm_and_barrier<0>();               // pass B's first half-tile has landed
+            // requests of this step, W_o first: the wait at its end leaves the two newest instructions - the G tile - in flight
+            if (more) {
+                issue_w2(half, kg + 1);
+                if (half == 0) issue_g(kg + 2);
+            }
+            if (half == 0) {
+                const int j = kg >> 1, s2 = kg & 1;
+                const char* gs = Gs + (kg % 3) * (BM * 64);
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(gs + offG0), o1 = *reinterpret_cast<const f32x4*>(gs + offG1);
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int hc = j * 32 + 8 * (2 * s2 + q) + 4 * h;        // 4 consecutive gate channels
+                    const int hcl = min(hc, GT_NG - 4);
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(cst + hcl), bi = *reinterpret_cast<const f32x4*>(cst + GT_NG + hcl);
+                    const f32x4 ov = q ? o1 : o0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = rstd * (acc1[0][j][8 * s2 + 4 * q + e] - dmean * cs[e]) + bi[e];
+                        v[4 * q + e] = (hc + e < g.N) ? ov[e] * sigmoidf_(x) : 0.f;
+                    }
+                }
+                // unlifted pieces of v 2^4 (split2b): |gate * o| < 4094, else NaN -> the range probe -> the exact kernels
+                unsigned q0[4], q1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2b(v[2 * e], v[2 * e + 1], q0[e], q1[e]);
+                hfa[kg][0] = u32x4{q0[0], q0[1], q0[2], q0[3]};
+                hfa[kg][1] = u32x4{q1[0], q1[1], q1[2], q1[3]};
+            }
+            const char* ws = W2s + (kg & 1) * GT1_W2 + offB2;
+            if (rows_live && kg * 16 < g.N) {
+                u32x4 wb[TH][2];
+#pragma unroll
+                for (int t = 0; t < TH; ++t)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) wb[t][p] = *reinterpret_cast<const u32x4*>(ws + t * 1024 + p * (BH * 32));
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int t = 0; t < TH; ++t) acc2[0][t] = mfma_split(hfa[kg][TA[term]], wb[t][TB[term]], acc2[0][t]);
+            }
+            if (more && half == 0) wait_vm_and_barrier<2>();
+            else wait_vm_and_barrier<0>();                                   // (pass B, or the last k-tile: nothing but W_o was requested)
+        }
+#pragma unroll
+        for (int t = 0; t < TH; ++t) acc2[0][t] *= cs2;
+        // (every DMA has landed and every wave is past its last stage read: the scratch of the epilogue overlays the GEMM 1 stages and
+        // the head of the G ring, not the W_o stages - pass B's first half-tile is requested above, after this epilogue)
+        gemm_epilogue<BM, BH, WM, BH, EDGE, false>(g2, smem, smem + 2 * BM, acc2, m0, half * BH, b, false);
+        if (half == 0) __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm3_gtail_kernel(const AbxGemm g) {
     extern __shared__ __attribute__((aligned(16))) float gt_smem[];
     const int ntm = (g.M + 127) / 128;
@@ -889,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_gtail_kernel(const AbxGemm g) {
     const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
     const ClockProbe probe(g.clock_probe);
-    if ((mt + 1) * 128 <= g.M && g.N2 == 192) gemm3_gtail_block<false>(g, gt_smem, mt, b);
+    if ((mt + 1) * 128 <= g.M && g.N2 == 192 && g.N == 192) gemm3_gtail_block<false>(g, gt_smem, mt, b);
     else gemm3_gtail_block<true>(g, gt_smem, mt, b);
     probe.finish();
 }
@@ -1311,8 +1472,14 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
             return 0;
         }
         const long long mt = ((long long)g.M + 127) / 128;
-        if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm3_gtail_kernel), GT_LDS, "abx_gemm(gated tail)")) { *rc = e; return 0; }
-        hipLaunchKernelGGL(gemm3_gtail_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), GT_LDS, st, g);
+        if (g.tune & 64) {                                                   // tune bit 6: the two-walk form of round 5 (A / B runs, cross-check)
+            if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm3_gtail2w_kernel), GT_LDS, "abx_gemm(gated tail)")) { *rc = e; return 0; }
+            hipLaunchKernelGGL(gemm3_gtail2w_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), GT_LDS, st, g);
+            *rc = abx_check_launch("abx_gemm(gated tail, two walks)");
+            return 0;
+        }
+        if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm3_gtail_kernel), GT1_LDS, "abx_gemm(gated tail)")) { *rc = e; return 0; }
+        hipLaunchKernelGGL(gemm3_gtail_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), GT1_LDS, st, g);
         *rc = abx_check_launch("abx_gemm(gated tail)");
         return 0;
     }

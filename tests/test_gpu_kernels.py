@@ -1706,6 +1706,29 @@ def test_gemm_gated_tail(ops, M, inplace):
     check(out, out2, 2e-6, 'gated tail vs two launches')
 
 
+@pytest.mark.parametrize('M', [128 * 300, 128 * 257 + 37, 4224 + 5])
+def test_gemm_gated_tail_walk_variants_bit_identical(ops, M):
+    """Round 6: the gated tail walks the z rows ONCE (all 192 gate channels in one main loop, GEMM 2 in two passes over the output columns
+    that replay the kept operand pieces) instead of once per gate chunk.  Every accumulator receives the same products in the same order
+    as in the two-walk kernel of round 5 (AbxGemm.tune bit 6): the outputs must be equal bit for bit, ragged last row tile included."""
+    ge = g(1985 + M % 5)
+    K = 192
+    z = (torch.randn(M, K, generator=ge) * 2 + 0.7).to(DEV)
+    o = (torch.randn(M, K, generator=ge) * 1.5).to(DEV)
+    Wg, bg = torch.randn(K, K, generator=ge) / K ** 0.5, 0.3 * torch.randn(K, generator=ge)
+    Wo, bo = torch.randn(K, K, generator=ge) / K ** 0.5, 0.1 * torch.randn(K, generator=ge)
+    ga, be = 1 + 0.1 * torch.randn(K, generator=ge), 0.1 * torch.randn(K, generator=ge)
+    w1, cs1, bi1 = fold_ln(Wg, bg, ga, be)
+    w13, wo3p = ops.split_weights(w1), ops.split_weights(ops.permute_k16(Wo.t().contiguous().to(DEV)))
+    outs = []
+    for tune in (0, 64):
+        out = torch.full((M, K), float('nan'), device=DEV)
+        ops.gemm(z, w1, out, bias=bi1, ln=(None, cs1), B3=w13, act=2, gate=o, resid=z, exact=2, mlp=(wo3p, bo.to(DEV)), tune=tune)
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 def test_gated_tail_flags_an_operand_beyond_the_split_range(ops):
     """A gated attention output beyond the activation range of the tail's second GEMM (|gate * o| >= 4094) becomes NaN in exactly its
     row and sets the range word (the caller then repeats on the exact kernels); every other row is what the clean input gives."""

@@ -20,8 +20,8 @@ hid = torch.empty(M2, 192, device=DEV)
 z1, o1 = z[:1].expand(M2, 192), o[:1].expand(M2, 192)
 
 
-def fused(zz, oo):
-    ops.gemm(zz, Wg, out, bias=bg, ln=(None, cs), B3=w3, act=2, gate=oo, resid=z, exact=2, mlp=(wo3p, bo))
+def fused(zz, oo, tune=0):
+    ops.gemm(zz, Wg, out, bias=bg, ln=(None, cs), B3=w3, act=2, gate=oo, resid=z, exact=2, mlp=(wo3p, bo), tune=tune)
 
 
 def two():
@@ -34,8 +34,10 @@ def outproj():
 
 
 fl = 2.0 * M2 * 192 * 384
-for name, fn in (('gated tail', lambda: fused(z, o)), ('gated tail, o rows collapsed', lambda: fused(z, o1)), ('gated tail, z rows collapsed', lambda: fused(z1, o)),
+for name, fn in (('gated tail (one walk, round 6)', lambda: fused(z, o)), ('gated tail, two walks (round 5: tune 64)', lambda: fused(z, o, 64)),
+                 ('gated tail (one walk, round 6)', lambda: fused(z, o)), ('gated tail, two walks (round 5: tune 64)', lambda: fused(z, o, 64)),
+                 ('two walks, z rows collapsed', lambda: fused(z1, o, 64)), ('gated tail, o rows collapsed', lambda: fused(z, o1)), ('gated tail, z rows collapsed', lambda: fused(z1, o)),
                  ('gated tail, both collapsed', lambda: fused(z1, o1)), ('two launches (gate * o, out proj)', two), ('out proj + resid alone', outproj),
                  ('gated tail', lambda: fused(z, o))):
     ms = timeit(fn, reps=7)
-    print(f'{name:36s} Bc={Bc} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
+    print(f'{name:42s} Bc={Bc} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
