@@ -427,6 +427,80 @@ __device__ __forceinline__ void gemm3_dual_block(const AbxGemm& g, float* smem, 
     gemm_epilogue<BM, BN, WM, WN, EDGE, false, false, true, TGO>(g, st_lds, smem + 4 * BM, acc, mt * BM, nt * BN, b, stats, &acc2, st_lds + 2 * BM);
 }
 
+// Round 6: the same dual GEMM with ONE walk over the rows of z.  The 128 x 96 tiles above give every row tile two blocks (one per column
+// half) that each walk the product rows AND the z rows: the A side of both main loops (DMA from the fabric, fragment reads, LayerNorm
+// partial sums, f16 splits) is paid twice per row, 9 MFMAs per k-step.  Under the board's power limit that is what the launch costs
+// (profiles/r06a_power_limit.txt; the gated attention tail gained 11 % from the same change).  Here a block owns 128 rows and all
+// 192 columns:
+//   gate walk   LN(z) against the final-gate weights for all 192 columns (128 x 192 tile, 18 MFMAs per k-step), 96 accumulator
+//               registers, turned into the gate VALUES sigmoid(.) in place and kept;
+//   two passes  over the output columns (0 .. 95, 96 .. 191): the product rows against proj_out into 48 accumulator registers, then the
+//               epilogue of that half: folded LayerNorm, bias, x the kept gate values, + z, store.
+// z is walked once instead of twice, the product rows twice as before.  Every accumulator receives the products of the two-tile form
+// in the same order and the gate is the same expression: bit-identical results.  MEASURED SLOWER (10.97 vs 10.30 ms at 100 samples of
+// L = 352, profiles/r06c_kb_dual.txt): 96 + 48 live accumulator registers leave two blocks per CU where the two-tile form runs three;
+// kept behind AbxGemm.tune bit 7 as the record of the experiment and a cross-check (test_gemm_dual_walk_variants_bit_identical).
+template <bool EDGE>
+__device__ __forceinline__ void gemm3_dual1_block(const AbxGemm& g, float* smem, int mt, int b) {
+    constexpr int BM = 128, BN = 192, WM = 32, BH = 96, TH = BH / 32, TN = BN / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    AbxGemm g2 = g;                                          // operand view of the gate GEMM
+    g2.A = g.A2; g2.sAb = g.sA2b; g2.sAm = g.sA2m; g2.sAk = 1; g2.K = g.K2;
+    g2.A_split = nullptr; g2.a_relu = 0; g2.a_pair_transpose = 0; g2.a_pair = g.pair_Lp > 0 ? 1 : 0;
+    g2.B_split = g.B2_split; g2.sB3p = g.sB23p; g2.sB3n = g.sB23n; g2.sB3k = g.sB23k; g2.sB3b = 0;
+    g2.ln_csum = g.ln2_csum; g2.ln_stats = nullptr; g2.batch_inner = 0; g2.b_exp = g.b2_exp;
+    float* st_lds = smem;                                   // [BM][2] (product rows) + [BM][2] (z rows)
+    f32x16 gatev[1][TN];
+    {
+        float ls2[1], lq2[1], lsh2[1];
+        gemm3_mainloop<BM, BN, WM, BN, 0, false, true, 2>(g2, smem, mt, 0, b, gatev, ls2, lq2, lsh2);
+        gemm3_row_stats<BM, BN, WM, BN, EDGE>(g2, st_lds + 2 * BM, mt, b, ls2, lq2);
+        __syncthreads();
+        const float* st2 = st_lds + 2 * BM;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = j * 32 + (lane & 31);
+            const bool nok = !EDGE || n < g.N;
+            const float csum2 = nok ? g.ln2_csum[n] : 0.f, bias2 = (g.bias2 && nok) ? g.bias2[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wave * WM + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                // (gemm_epilogue.h, the acc2 path: the same expression, the same rounding)
+                const float gv = st2[2 * ml + 1] * (gatev[0][j][r] - st2[2 * ml] * csum2) + bias2;
+                gatev[0][j][r] = sigmoidf_(gv);
+            }
+        }
+        __syncthreads();                                    // (the statistics are read: the next main loop's stages overlay them)
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 acc[1][TH];
+        float ls[1], lq[1], lsh[1];
+        if (g.sAk == 1) gemm3_mainloop<BM, BH, WM, BH, 0, false, true, 2>(g, smem, mt, half, b, acc, ls, lq, lsh);
+        else gemm3_mainloop<BM, BH, WM, BH, 1, false, true, 2>(g, smem, mt, half, b, acc, ls, lq, lsh);
+        const bool stats = gemm3_row_stats<BM, BH, WM, BH, EDGE>(g, st_lds, mt, b, ls, lq);
+        __syncthreads();
+        gemm_epilogue<BM, BH, WM, BH, EDGE, false, false, true>(g, st_lds, smem + 4 * BM, acc, mt * BM, half * BH, b, stats, nullptr, nullptr,
+                                                                reinterpret_cast<const f32x16 (*)[1][TH]>(&gatev[0][half * TH]));
+        if (half == 0) __syncthreads();                     // (the scratch and the statistics are read: the next main loop overlays them)
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm3_dual1_kernel(const AbxGemm g) {
+    constexpr int OPER = (2 * 128 * 64 + 2 * 2 * 192 * 32) / 4;
+    constexpr int EPI = 4 * 128 + 4 * 32 * (3 * 32 + 4);
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntm = (g.M + 127) / 128;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
+    const ClockProbe probe(g.clock_probe);
+    if ((mt + 1) * 128 <= g.M && g.N == 192) gemm3_dual1_block<false>(g, smem, mt, b);
+    else gemm3_dual1_block<true>(g, smem, mt, b);
+    probe.finish();
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, bool TS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm3_kernel(const AbxGemm g) {
     constexpr int A_IMG = AMODE == 2 ? 2 * BM * 32 : BM * 64;
@@ -1518,7 +1592,11 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
         // Three blocks per CU (142 VGPRs).  tune bit 10: the four-block build (one B sub-tile in flight, 32-column store groups, 128 VGPRs):
         // 5 % faster (9.75 vs 10.28 ms at 100 samples), but the accumulator set of the first main loop is parked in scratch across the
         // second and that is + 9 GB of HBM traffic per launch on the counters (43.9 vs 34.8 GB) - measured in profiles/r04l, not the default
-        if (g.tune & 1024) hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 4>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
+        // tune bit 7 (round 6 probe, 96 < N <= 192): one block per row tile, z walked once (gemm3_dual1_kernel) - bit-identical, but its 96 kept
+        // gate registers + 48 accumulators leave two blocks per CU instead of three (256 VGPRs, 7 spilled): 10.97 vs 10.30 ms at 100 samples
+        // (profiles/r06c_kb_dual.txt); NOT the default
+        if (g.N > 96 && g.N <= 192 && (g.tune & 128)) hipLaunchKernelGGL(gemm3_dual1_kernel, dim3((unsigned)(mt * g.batch)), dim3(256), 0, st, g);
+        else if (g.tune & 1024) hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 4>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
         else hipLaunchKernelGGL((gemm3_dual_kernel<128, 96, 32, 96, 3>), dim3((unsigned)(mt * ntn * g.batch)), dim3(256), 0, st, g);
         *rc = abx_check_launch("abx_gemm(dual)");
         return 0;

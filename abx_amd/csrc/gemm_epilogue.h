@@ -12,7 +12,8 @@
 template <int BM, int BN, int WM, int WN, bool EDGE, bool TS, bool OLN = false, bool PROBE = true, int TGO = 0>
 __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __restrict__ st_lds, float* __restrict__ scratch,
                                               f32x16 (&acc)[WM / 32][WN / 32], int m0, int n0, int b, bool stats,
-                                              f32x16 (*acc2)[WM / 32][WN / 32] = nullptr, const float* __restrict__ st2_lds = nullptr) {
+                                              f32x16 (*acc2)[WM / 32][WN / 32] = nullptr, const float* __restrict__ st2_lds = nullptr,
+                                              const f32x16 (*gatev)[WM / 32][WN / 32] = nullptr) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -192,6 +193,8 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                                 const float gv = st2_lds[2 * ml + 1] * ((*acc2)[i][jg + j][rq * 4 + c] - st2_lds[2 * ml] * csum2[jg + j]) + bias2[jg + j];
                                 v *= sigmoidf_(gv);
                             }
+                            // (one-walk dual GEMM: the gate values sigmoid(...) themselves, kept in registers since the gate walk)
+                            if (gatev && !pre) v *= (*gatev)[i][jg + j][rq * 4 + c];
                             wsc[mloc * LW + j * 32 + (lane & 31)] = v;
                         }
                     }

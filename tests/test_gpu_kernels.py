@@ -1488,6 +1488,34 @@ def test_gemm_dual_proj_out_times_gate(ops, L):
     check(zd, ref, 3e-6, f'dual gemm L={L}')
 
 
+@pytest.mark.parametrize('L,Bc', [(64, 3), (70, 3), (128, 2), (118, 2)])
+def test_gemm_dual_walk_variants_bit_identical(ops, L, Bc):
+    """Round 6: the tri-mul tail on ONE block per 128 rows (gate walk over all 192 columns once, its sigmoid values kept in registers; the
+    product rows against proj_out in two column passes; AbxGemm.tune bit 7 - measured slower, not the default) against the two-tile kernel
+    of rounds 2 - 5: the same products in the same order into every accumulator, the same gate expression - equal bit for bit, padded
+    pair rows (L % 4 != 0) and ragged last row tiles included."""
+    LL, Lp = L * L, (L + 3) // 4 * 4
+    ge = g(125 + L)
+    z = (torch.randn(Bc, LL, 192, generator=ge) * 2 + 0.5).to(DEV)
+    tt = torch.randn(Bc, 128, L * Lp, generator=ge).to(DEV)
+    Wo, bo = torch.randn(128, 192, generator=ge) / 11, torch.randn(192, generator=ge) * 0.1
+    Wg, bg = torch.randn(192, 192, generator=ge) / 14, torch.randn(192, generator=ge) * 0.1
+    g1, b1 = 1 + 0.1 * torch.randn(128, generator=ge), 0.1 * torch.randn(128, generator=ge)
+    g2, b2 = 1 + 0.1 * torch.randn(192, generator=ge), 0.1 * torch.randn(192, generator=ge)
+    wo, cso, bio = fold_ln(Wo.t().contiguous(), bo, g1, b1)
+    wg, csg, big = fold_ln(Wg.t().contiguous(), bg, g2, b2)
+    wo3, wg3 = ops.split_weights(wo), ops.split_weights(wg)
+    pad = (L, Lp) if Lp != L else None
+    outs = []
+    for tune in (0, 128):
+        out = torch.full_like(z, float('nan'))
+        ops.gemm(tt.transpose(1, 2), wo, out, bias=bio, ln=(None, cso), B3=wo3, resid=z, pair=pad, c_pair=pad is not None,
+                 dual=(z, wg3, csg, big), exact=2, tune=tune)
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
 @pytest.mark.parametrize('M,K,NH,N2,inplace', [(128 * 5, 192, 768, 192, True), (128 * 3 + 77, 192, 768, 192, False), (1000, 64, 272, 96, False),
                                                  (40 * 40 * 3, 192, 768, 192, True)])
 def test_gemm_fused_transition(ops, M, K, NH, N2, inplace):

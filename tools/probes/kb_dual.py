@@ -1,22 +1,23 @@
-"""The TriangleMultiplication tail (dual GEMM: LN(product) @ Wo * sigmoid(LN(z) @ Wg + bg) + z) at the bench geometry: three blocks per CU
-(the default) against the four-block build (tune bit 10: one B sub-tile in flight, 32-column store groups, one accumulator set parked in scratch); outputs compared bit for bit."""
+"""The tri-mul tail (dual GEMM: proj_out(LN product) x sigmoid(final_gate(LN z)) + z) on one block per row tile (round 6, z walked once)
+(tune bit 7) against the default two-tile kernel, same box, alternating.
+    python tools/probes/kb_dual.py [Bc] [L]"""
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from abx_amd import ops
 from tools.kbench import timeit
 DEV = 'cuda:0'
-Bc, L = int(sys.argv[1]) if len(sys.argv) > 1 else 20, 352
+Bc = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 352
 LL = L * L
 ops.RANGE_CHECK = False
-z = torch.randn(Bc, LL, 192, device=DEV)
-tt = torch.randn(Bc, 128, LL, device=DEV)
-wo, wg = torch.randn(128, 192, device=DEV) / 11, torch.randn(192, 192, device=DEV) / 14
-bio, big, cso, csg = torch.randn(192, device=DEV), torch.randn(192, device=DEV), wo.sum(0).contiguous(), wg.sum(0).contiguous()
-w3o, w3g = ops.split_weights(wo), ops.split_weights(wg)
-outs = []
-for tune in (0, 1024, 0, 1024):
-    out = torch.empty_like(z)
-    ms = timeit(lambda: ops.gemm(tt.transpose(1, 2), wo, out, bias=bio, ln=(None, cso), B3=w3o, resid=z, dual=(z, w3g, csg, big), exact=2, tune=tune), reps=11)
-    outs.append(out)
-    print(f'dual Bc={Bc} tune={tune:4d}: {ms:7.3f} ms', flush=True)
-print('bit-identical:', torch.equal(outs[0], outs[1]))
+r = lambda *s: torch.randn(*s, device=DEV)
+tt, z, out = r(Bc, 128, LL), r(Bc, LL, 192), torch.empty(Bc, LL, 192, device=DEV)
+Wo, Wg = r(128, 192) / 11, r(192, 192) / 14
+Wo3, cso, bo, Wg3, csg, bg = ops.split_weights(Wo), Wo.sum(0).contiguous(), r(192), ops.split_weights(Wg), Wg.sum(0).contiguous(), r(192)
+def dual(tune):
+    ops.gemm(tt.transpose(1, 2), Wo, out, bias=bo, ln=(None, cso), B3=Wo3, resid=z, dual=(z, Wg3, csg, bg), exact=2, tune=tune)
+fl = 2.0 * Bc * LL * 192 * 320
+for rep in range(3):
+    for name, tune in (('dual, one block per row tile (tune 128)', 128), ('dual, two column tiles (default)', 0)):
+        ms = timeit(lambda: dual(tune), reps=7)
+        print(f'{name:44s} Bc={Bc} L={L} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s', flush=True)
