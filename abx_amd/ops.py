@@ -26,7 +26,7 @@ def _f32(t):
     return t
 
 
-GEMM_TUNE = 0      # kernel-variant selector (benchmarking only)
+GEMM_TUNE = int(__import__('os').environ.get('ABX_GEMM_TUNE', '0'))      # kernel-variant selector (benchmarking only: AbxGemm.tune of every descriptor-level launch)
 
 # ---- range safety of the split-f16 kernels (include/abx_hip.h, AbxGemm.range_flag) ----------------------------------------------
 # Every split-f16 launch made through this module carries the address of one device word per GPU and a bit that names its call-site
