@@ -49,6 +49,7 @@ class AbxGemm(C.Structure):
         ('exact', I),
         ('b_f16', I), ('b_exp', I), ('b2_exp', I),
         ('tune', I),
+        ('c_planes_from', I), ('c_planes_group', I),
         ('range_flag', c_f), ('range_tag', I),
         ('clock_probe', c_f),
         ('a_vec_ok', I), ('b_vec_ok', I), ('fast_ok', I),
@@ -116,6 +117,7 @@ class AbxTriAttn(C.Structure):
         ('range_flag', c_f), ('range_tag', I),
         ('tune', I),
         ('bias_log2', I),
+        ('kv_planes', I),
         ('q_parts', I), ('row_groups', I),
     ]
 
@@ -188,6 +190,7 @@ _PROTOS = {
     'abx_gemm': (I, [C.POINTER(AbxGemm), _S]),
     'abx_gemm_side': (I, [C.POINTER(AbxGemm), C.POINTER(AbxGemm), _S]),
     'abx_gemm_check_modes': (I, [C.POINTER(AbxGemm)]),
+    'abx_gemm_planes_ok': (I, [LL]),
     'abx_split_weights_f16': (I, [c_f, LL, LL, I, I, I, C.c_void_p, _S]),
     'abx_ipa_tail': (I, [C.POINTER(AbxIpaTail), _S]),
     'abx_heads_tail': (I, [C.POINTER(AbxHeadsTail), _S]),

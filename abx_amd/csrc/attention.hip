@@ -771,6 +771,42 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
         auto stage = [&](const Row& r, int c0, int buf) __attribute__((always_inline)) {
             char* Kp = lds + buf * BUF4;
             char* Vp = Kp + 2 * PLN;
+            if (a.kv_planes) {
+                // Round 6: k | v arrive as the operand images the projection wrote (AbxGemm.c_planes_from: per key and head [p0: 48 f16 | p1: 48
+                // f16] of 16 x value, at the byte address of the fp32 head slice).  A plane of the chunk is a dense [KC4][96 bytes] array in
+                // LDS, so staging is a straight DMA: instruction i of a plane fills bytes [1024 i, 1024 i + 1024) - lane l the 16 bytes at
+                // o = 1024 i + 16 l = (key o / 96, byte o % 96); three instructions cover 32 keys exactly, so a lane has three (key, byte)
+                // constants.  No registers, no split, no LDS writes by this wave: 4 planes x PLN / 1024 instructions per chunk, one wait.
+                constexpr int NI = PLN / 1024;
+                static_assert(PLN % 3072 == 0, "a plane of the chunk is a whole number of 32-key DMA rounds");
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                     // (per chunk, behind an opaque lane id: see the staging constants below)
+                const char* kb = reinterpret_cast<const char*>(a.k + r.base);
+                const char* vb = reinterpret_cast<const char*>(a.v + r.base);
+                int kt[3];
+                unsigned cb[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int o = t * 1024 + ln * 16;
+                    kt[t] = o / RST;
+                    cb[t] = (unsigned)(o - kt[t] * RST);
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const unsigned off = __umul24((unsigned)min(c0 + 32 * (i / 3) + kt[i % 3], L - 1), sl4) + cb[i % 3];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + off + p * RST),
+                                                         (__attribute__((address_space(3))) void*)(Kp + p * PLN + i * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + off + p * RST),
+                                                         (__attribute__((address_space(3))) void*)(Vp + p * PLN + i * 1024), 16, 0, 0);
+                    }
+                }
+                for (int t = lane; t < KC4; t += 64)
+                    Msb[buf * KC4 + t] = (c0 + t < L) ? ((!r.km || r.km[c0 + t] != 0.f) ? INFINITY : ABX_NEG_MAX) : -INFINITY;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the images have landed before this wave joins the chunk barrier)
+                return;
+            }
             // (recomputed per chunk behind an opaque lane id: as invariants of the whole kernel they are hoisted above the wave-role
             // branch and cost the computing waves 18 registers - spills)
             int ln = lane;
@@ -810,6 +846,16 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
             auto convert = [&](int rd, auto set_) __attribute__((always_inline)) {
                 constexpr int set = decltype(set_)::value;
                 const unsigned rdo = (unsigned)(rd * KRD * RST);
+#ifdef TRI8_LOADS_ONLY     // (probe build: every K / V load still issues and is waited for, but nothing is split or written except one word per
+                           //  round - the kernel's time with the HBM stream and without the producer's VALU / LDS work: what DMA staging could return)
+                unsigned x = 0;
+#pragma unroll
+                for (int j = 0; j < NPF; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x ^= __builtin_bit_cast(unsigned, kr[set][j][e]) ^ __builtin_bit_cast(unsigned, vr[set][j][e]);
+                *reinterpret_cast<unsigned*>(Kp + rdo + ldo[0]) = x;
+                return;
+#endif
 #pragma unroll
                 for (int j = 0; j < NPF; ++j) {
                     unsigned a0, a1, b0, b1;
@@ -825,6 +871,8 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
                     *reinterpret_cast<u32x2*>(vd + PLN) = u32x2{a1, b1};
                 }
             };
+#ifndef TRI8_NO_PRODUCER   // (probe build, tools/probes/build_noprod.sh: no K / V staging at all - wrong results, the kernel's time without
+                           //  any producer work: the ceiling of what staging by DMA from pre-split planes could return)
             // (a real loop over round pairs; scheduling barriers: the compiler would hoist every round's loads to the top and spill)
             issue(0, I0{});
 #pragma unroll 1
@@ -844,6 +892,7 @@ __global__ __launch_bounds__(NTH) void tri_attn8_kernel(const AbxTriAttn a) {
             __builtin_amdgcn_sched_barrier(0);
             convert(NRD - 1, I1{});
             __builtin_amdgcn_sched_barrier(0);
+#endif
             // key clamps, applied as logit = min(logit, clamp): +inf valid, finfo.min masked (the reference REPLACES the logit by
             // finfo.min: every finite logit is >= finfo.min), -inf beyond L
             for (int t = lane; t < KC4; t += 64)
@@ -1316,6 +1365,7 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     ABX_REQUIRE(al16(a.q) && al16(a.k) && al16(a.v) && al16(a.out) && (!a.gate || al16(a.gate)),
                 "abx_tri_attn_fwd: pointers must be 16-byte aligned");
+    ABX_REQUIRE(!a.kv_planes || !a.exact, "abx_tri_attn_fwd: kv_planes goes with the split-f16 kernel (exact = 0)");
     if (!a.exact) {
         // split-f16 kernel: K / V staged in (double-buffered) key chunks, a wave keeps the online-softmax state of up to MAXQ query tiles
         // A workgroup carries 2 query-tile slots per wave: 24 tiles with 12 computing waves, 22 with 11 + the producer wave.  Rows with
@@ -1326,6 +1376,8 @@ extern "C" int abx_tri_attn_fwd(const AbxTriAttn* ap, hipStream_t st) {
         // tri_attn8_kernel: 11 computing waves x 2 query tiles walked together (its producer addresses a (b, s) slab of K / V with 32-bit
         // byte offsets and a 24-bit row stride; any other layout takes tri_attn4)
         const bool paired = !(a.tune & 4) && a.sl * 4 < (1LL << 24) && (long long)a.L * a.sl * 4 < (1LL << 32);
+        ABX_REQUIRE(!a.kv_planes || paired, "abx_tri_attn_fwd: kv_planes (k | v as operand images) is served by tri_attn8_kernel only (tune bit 2 off, "
+                                            "key stride below 2^24 bytes)");
         aa.q_parts = paired ? (nqt + 2 * (nw - 1) - 1) / (2 * (nw - 1)) : (nqt + 2 * nw - 1) / (2 * nw);
         const int tpp = (nqt + aa.q_parts - 1) / aa.q_parts;
         const bool prod = tpp <= 2 * (nw - 1) && !(a.tune & 1);

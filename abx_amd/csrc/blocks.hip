@@ -6,6 +6,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "abx_hip.h"
 
@@ -319,6 +321,13 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
     exact &= 1;
     const int Lp = (L + 3) / 4 * 4, C = 192;
     const TriAttnWs w = tri_attn_ws(workspace, B, L);
+    // Round 6 experiment, OFF unless ABX_KV_PLANES is set: on the split-f16 route the projection can write its k | v columns
+    // as the operand images of the attention (two float16 planes of 16 x value per head: the same bytes at the same addresses) and the
+    // attention's producer wave then stages them by DMA.  Bit-identical to the fp32 route (the attention computes exactly these pieces from
+    // fp32 k | v) - and measured SLOWER: the attention does not gain (17.19 -> 17.42 ms per launch at 100 samples: its producer wave was
+    // never on the critical path), the projection pays for the split and the 8-byte stores (13.7 -> 15.6 ms): profiles/r06h_kb_kvplanes.txt.
+    static const bool kv_planes_on = getenv("ABX_KV_PLANES") != nullptr;
+    const int planes = (kv_planes_on && !exact && !attn_exact && abx_gemm_planes_ok(M2)) ? 1 : 0;
     {   // q | k | v, and the pair bias stored (b, h, i, j) in the same grid (abx_gemm_side: one launch on the split-f16 path - the side
         // rides in the free half of the projection's last column tile -, the two launches otherwise)
         AbxGemm g = {};
@@ -327,6 +336,7 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
         g.M = (int)M2; g.batch = 1;
         set_weights(g, qkv, true, exact);
         set_range(g, range_flag, range_tag, exact);
+        if (planes) { g.c_planes_from = 192; g.c_planes_group = 48; }
         AbxGemm s2 = {};
         s2.A = z; s2.sAb = LL * C; s2.sAm = C; s2.sAk = 1;
         s2.C = w.bT; s2.sCb = 4 * LL; s2.sCm = LL; s2.c_transposed = 1;
@@ -358,6 +368,7 @@ extern "C" int abx_tri_attn_block_fwd(const AbxTriAttnPack* wp, float* z, const 
         a.scale = 0.14433756729740643f;                     // 48^-0.5
         a.exact = attn_exact;
         a.bias_log2 = attn_exact ? 0 : 1;
+        a.kv_planes = planes;
         if (!attn_exact) { a.range_flag = range_flag; a.range_tag = range_tag; }
         if (int rc = abx_tri_attn_fwd(&a, st)) return rc;
     }

@@ -498,11 +498,25 @@ static int gemm_prepare(const AbxGemm* gp, AbxGemm& g) {
     g.g_vec_ok = g.gate && al16(g.gate) && (g.sGb % 4 == 0) && (g.sGm % 4 == 0);
     g.r_vec_ok = g.resid && al16(g.resid) && (g.sRb % 4 == 0) && (g.sRm % 4 == 0);
     g.rs_vec_ok = g.rowscale && al16(g.rowscale) && (g.sRSb % 4 == 0);
+    ABX_REQUIRE(g.c_planes_from == 0 || (g.c_planes_from > 0 && g.c_planes_from % 4 == 0 && g.c_planes_group > 0 && g.c_planes_group % 4 == 0 &&
+                                         g.N % 4 == 0 && g.c_planes_from < g.N && (g.N - g.c_planes_from) % g.c_planes_group == 0 && g.C && g.c_vec_ok &&
+                                         !g.c_transposed && !g.C_split && !g.glu && !g.gate && !g.resid && !g.mlp && !g.A2 && !g.out_ln_w && !g.c_pair &&
+                                         g.act == 0 && g.exact != 1),
+                "abx_gemm: c_planes_from needs a plain, 16-byte aligned fp32 store without gate / resid / activation on the split-f16 path, from, "
+                "group and N multiples of 4, (N - from) % group == 0");
     return ABX_OK;
 }
 
 int abx_gemm3_side_dispatch(const AbxGemm& g, const AbxGemm& s2, hipStream_t st, int* rc);
 int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, int* rc);      // gemm_as.hip
+
+// 1 when a (main, side) pair of M rows takes the A-stationary kernel, i.e. may ask for plane output (AbxGemm.c_planes_from): the size rule of
+// abx_gemm_as_dispatch (the walk pays from 1 024 blocks of 64 rows on).  Callers that switch the k | v format on it stay bit-invariant under
+// chunking: the attention kernel computes the same pieces from fp32 k | v as the projection writes as planes.
+extern "C" int abx_gemm_planes_ok(long long M) {
+    static const bool off = getenv("ABX_NO_GEMM_AS") != nullptr || getenv("ABX_NO_GEMM_SIDE") != nullptr;
+    return (!off && (M + 63) / 64 >= 1024) ? 1 : 0;
+}
 
 extern "C" int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm, hipStream_t st) {
     ABX_REQUIRE(main_gemm && side_gemm, "abx_gemm_side: null descriptor");
@@ -512,6 +526,9 @@ extern "C" int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm,
     int rc = 0;
     static const bool off = getenv("ABX_NO_GEMM_SIDE") != nullptr;          // (A / B measurements: always the two launches)
     if (!off && !abx_gemm_as_dispatch(g, &s2, st, &rc)) return rc;      // A-stationary walk: the side rides in the ragged last N-tile
+    // (plane output exists in the A-stationary kernel only: a caller asks for it when the launch qualifies - abx_gemm_planes_ok)
+    ABX_REQUIRE(g.c_planes_from == 0, "abx_gemm_side: c_planes_from is served by the A-stationary kernel only (>= 65 536 rows, K = 192, N % 128 == 64, "
+                                      "planes in groups of 48 from a multiple of 32, a side projection): ask abx_gemm_planes_ok first");
     if (!off && !abx_gemm3_side_dispatch(g, s2, st, &rc)) return rc;
     // not a (128 x 128 plain, skinny transposed) split-f16 pair: the two launches
     if (int r1 = abx_gemm(main_gemm, st)) return r1;
@@ -521,6 +538,7 @@ extern "C" int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm,
 extern "C" int abx_gemm(const AbxGemm* gp, hipStream_t st) {
     AbxGemm g;
     if (int rc = gemm_prepare(gp, g)) return rc;
+    ABX_REQUIRE(g.c_planes_from == 0, "abx_gemm: c_planes_from is served through abx_gemm_side by the A-stationary kernel only (abx_gemm_planes_ok)");
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     (void)al16;
     const bool akc = g.sAk == 1;

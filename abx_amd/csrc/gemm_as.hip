@@ -247,14 +247,18 @@ template <int N> __device__ __forceinline__ void as_wait_vm() { asm volatile("s_
 //            columns of s2 (N <= 32, transposed store (b, n, m)) for the same rows: the pair bias next to q | k | v.
 // EPI_GLU:   the wave tile is a (value, gate) pair of 32 output channels: out = epi(value) sigmoid(epi(gate)) rowscale, written as
 //            the k-tiled f16 operand image of the following contraction (C_split, c_split_tile row order: gemm_epilogue.h).
-template <int EPI, bool SIDE, bool EDGE, int ABL = 0>
+// PL (EPI_PLAIN): the columns n >= g.c_planes_from leave as two float16 planes of 16 x value in groups of 48 channels (AbxGemm.c_planes_from:
+//            the k | v columns of the q | k | v projection as the operand image the triangle attention stages by DMA).  Every slice issues
+//            TWO 8-byte stores per lane - the planes p0 / p1 of 4 channels, or the two halves of the 16 fp32 bytes - so that the counted
+//            waits of the streaming waves stay exact whichever kind of column a slice holds.
+template <int EPI, bool SIDE, bool EDGE, int ABL = 0, bool PL = false>
 __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, char* lds, int mt, int b) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
     const int m0 = mt * AS_BM;
     float* st = reinterpret_cast<float*>(lds + AS_OFF_ST);       // [4][64]: mean - shift | rstd | row scale | row valid
     // ABL (probe builds, -DABX_AS_ABLATE + tune bits 12 - 13): 1 = no slice stores, 2 = no MFMA, 3 = half of the weight DMA inside the walk
-    using Sched = typename std::conditional<EPI == AS_EPI_PLAIN, AsSched<2, 8, (ABL == 1 ? 0 : 1), (ABL == 3 ? 2 : 4)>, AsSched<6, 2, (ABL == 1 ? 0 : 2), (ABL == 3 ? 2 : 4)>>::type;
+    using Sched = typename std::conditional<EPI == AS_EPI_PLAIN, AsSched<2, 8, (ABL == 1 ? 0 : (PL ? 2 : 1)), (ABL == 3 ? 2 : 4)>, AsSched<6, 2, (ABL == 1 ? 0 : 2), (ABL == 3 ? 2 : 4)>>::type;
 
     // ---- weight operand: fetched by the column-1 waves, wave (wm, 1) = plane wm of a stage (four 1 KB chunks of 32 rows)
     const int ntiles = (g.N + AS_BN - 1) / AS_BN;
@@ -405,6 +409,25 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
         as_quad_transpose(x, o);
         const int m = m0 + wm * 32 + 8 * rq + 4 * h + (lane & 3);
         const int n = tile_p * AS_BN + wn * 64 + j * 32 + ((lane & 31) >> 2) * 4;
+        if constexpr (PL) {
+            // (the sub-tile's 32 columns are on one side of c_planes_from - a multiple of 32: a scalar branch)
+            const int nsub = tile_p * AS_BN + wn * 64 + j * 32;
+            float* cr = Cb + (long long)m * g.sCm;
+            if (nsub >= g.c_planes_from) {
+                unsigned a0, a1, b0, b1;
+                split2b(o[0], o[1], a0, a1);
+                split2b(o[2], o[3], b0, b1);
+                const int rel = n - g.c_planes_from, gi = (int)(((unsigned)(rel >> 4) * 0xAAABu) >> 17), ch = rel - gi * 48;      // rel / 48
+                unsigned short* cs = reinterpret_cast<unsigned short*>(cr + g.c_planes_from + gi * 48) + ch;
+                if (!EDGE || m < g.M) {
+                    *reinterpret_cast<u32x2*>(cs) = u32x2{a0, b0};
+                    *reinterpret_cast<u32x2*>(cs + 48) = u32x2{a1, b1};
+                }
+            } else if (!EDGE || m < g.M) {
+                *reinterpret_cast<f32x2*>(cr + n) = (f32x2){o[0], o[1]};
+                *reinterpret_cast<f32x2*>(cr + n + 2) = (f32x2){o[2], o[3]};
+            }
+        } else
         if (ABL != 1 && (!EDGE || m < g.M)) *reinterpret_cast<f32x4*>(Cb + (long long)m * g.sCm + n) = (f32x4){o[0], o[1], o[2], o[3]};
     };
     // GLU: four value slices (row quad rq: the lane's 4 consecutive rows of its channel -> 8 bytes per plane), then two store slices:
@@ -633,7 +656,7 @@ __device__ __forceinline__ void as_block(const AbxGemm& g, const AbxGemm& s2, ch
 #endif
 }
 
-template <int EPI, bool SIDE, int ABL = 0>
+template <int EPI, bool SIDE, int ABL = 0, bool PL = false>
 __global__ __launch_bounds__(256, 2) void gemm_as_kernel(const AbxGemm g, const AbxGemm s2) {
     extern __shared__ __attribute__((aligned(16))) float as_smem[];
     char* lds = reinterpret_cast<char*>(as_smem);
@@ -646,8 +669,8 @@ __global__ __launch_bounds__(256, 2) void gemm_as_kernel(const AbxGemm g, const 
     const int b = (int)(wgid / ntm), mt = (int)(wgid - (unsigned)b * ntm);
     bool edge = (mt + 1) * AS_BM > g.M;
     if (EPI == AS_EPI_GLU) edge = edge || (g.pair_L & 7) != 0 || (g.c_split_L & 15) != 0;     // padded pair rows: predicated stores
-    if (edge) as_block<EPI, SIDE, true, ABL>(g, s2, lds, mt, b);
-    else as_block<EPI, SIDE, false, ABL>(g, s2, lds, mt, b);
+    if (edge) as_block<EPI, SIDE, true, ABL, PL>(g, s2, lds, mt, b);
+    else as_block<EPI, SIDE, false, ABL, PL>(g, s2, lds, mt, b);
     probe.finish();
 }
 
@@ -683,6 +706,8 @@ int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, 
     } else {
         if (g.c_transposed || g.C_split || g.rowscale || g.a_pair_transpose > 0 || g.pair_Lp != 0 || g.batch != 1) return 1;
         if (!g.c_vec_ok || g.N % 64 != 0) return 1;
+        // plane output of the columns from c_planes_from on: this kernel's PL instantiation only (with the side projection: the q | k | v launch)
+        if (g.c_planes_from > 0 && (!side || g.c_planes_group != 48 || g.c_planes_from % 32 != 0 || (g.N - g.c_planes_from) % 48 != 0 || g.N >= (1 << 16))) return 1;
         if (side) {
             const AbxGemm& s = *side;
             if (g.N % 128 != 64) return 1;                      // the side rides in the free half of the ragged last tile
@@ -697,13 +722,13 @@ int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, 
     }
     static const AbxGemm none = {};
     const dim3 grid((unsigned)(ntm * g.batch)), block(256);
-#define AS_LAUNCH(EPI, SIDE, ABL)                                                                                                        \
+#define AS_LAUNCH(EPI, SIDE, ABL, ...)                                                                                                   \
     do {                                                                                                                                 \
-        if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_as_kernel<EPI, SIDE, ABL>), AS_LDS, "abx_gemm(as)")) {    \
+        if (int e = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_as_kernel<EPI, SIDE, ABL, ##__VA_ARGS__>), AS_LDS, "abx_gemm(as)")) { \
             *rc = e;                                                                                                                     \
             return 0;                                                                                                                    \
         }                                                                                                                                \
-        hipLaunchKernelGGL((gemm_as_kernel<EPI, SIDE, ABL>), grid, block, AS_LDS, st, g, side ? *side : none);                           \
+        hipLaunchKernelGGL((gemm_as_kernel<EPI, SIDE, ABL, ##__VA_ARGS__>), grid, block, AS_LDS, st, g, side ? *side : none);            \
     } while (0)
 #ifdef ABX_AS_ABLATE
     const int abl = (g.tune >> 12) & 3;
@@ -713,6 +738,7 @@ int abx_gemm_as_dispatch(const AbxGemm& g, const AbxGemm* side, hipStream_t st, 
     else
 #endif
     if (glu) AS_LAUNCH(AS_EPI_GLU, false, 0);
+    else if (side && g.c_planes_from > 0) AS_LAUNCH(AS_EPI_PLAIN, true, 0, true);
     else if (side) AS_LAUNCH(AS_EPI_PLAIN, true, 0);
     else AS_LAUNCH(AS_EPI_PLAIN, false, 0);
 #undef AS_LAUNCH

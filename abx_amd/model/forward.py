@@ -522,8 +522,12 @@ class Engine:
             qkv = w768.view(-1)[:M2 * 576].view(M2, 576)
             # (the split-f16 attention takes the bias in its accumulator units: the factor rides in the projection's epilogue)
             bl2 = not (ops.GEMM_EXACT if ae is None else ae)
+            # (round-6 experiment, as abx_tri_attn_block_fwd, OFF unless ABX_KV_PLANES is set: the k | v columns leave the projection as the
+            # operand images the attention stages by DMA - bit-identical to the fp32 route, measured slower: profiles/r06h_kb_kvplanes.txt)
+            kvp = ops.KV_PLANES and am == 2 and bl2 and ops.kv_planes_ok(M2)
             # (range class 'tri_attn' as abx_tri_attn_block_fwd tags them: the tag of a launch follows the switch that sets its arithmetic)
-            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True, exact=am, range_class='tri_attn'),
+            ops.gemm_side(_ln_lin(P, pre + 'qkv', pre + 'norm', None, z2, qkv, defer=True, exact=am, range_class='tri_attn',
+                                  c_plane_cols=(192, 48) if kvp else None),
                           _ln_lin(P, pre + 'proj_pair', pre + 'norm', None, z3, bT.transpose(1, 2), narrow=True, defer=True, exact=am,
                                   alpha=ops.TRI_BIAS_LOG2 if bl2 else 1.0, range_class='tri_attn'))
             o = w384[:M2 * 192].view(M2, 192)
@@ -535,7 +539,7 @@ class Engine:
                 bT = bT2
             else:
                 bT = bT.view(Bc, 4, L, L)
-            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True, exact=ae, bias_log2=bl2)       # (no gate: the tail applies it)
+            ops.tri_attn(qkv, bT, mask_f, o, Bc, L, per_row, bias_is_qk=True, exact=ae, bias_log2=bl2, kv_planes=kvp)       # (no gate: the tail applies it)
             if not ax:
                 # gate projection, sigmoid, * attention output, output projection, + residual in ONE kernel (AbxGemm.mlp = 2)
                 _ln_lin(P, pre + 'attn.gate', pre + 'norm', None, z2, z2, act=2, gate=o, resid=z2, mlp=P.mlp_second(pre + 'attn.proj_out'), exact=2)

@@ -134,15 +134,15 @@ def gemm_as_kernel_name(g, side=None):
     if g.glu:
         if side is not None or not g.C_split or not g.c_split_tile or not g.c_transposed or g.N % 128 != 0 or not g.a_pair or g.pair_Lp <= 0:
             return None
-        return 'gemm_as_kernel<1, false, 0>'
+        return 'gemm_as_kernel<1, false, 0, false>'
     if g.c_transposed or g.C_split or g.rowscale or g.a_pair_transpose > 0 or g.pair_Lp != 0 or g.batch != 1 or g.N % 64 != 0:
         return None
     if side is not None:
         s2 = side
         if g.N % 128 != 64 or not s2.B_split or not s2.c_transposed or s2.N > 32 or s2.K != g.K or s2.M * s2.batch != g.M or s2.act != 0 or s2.exact == 1:
             return None
-        return 'gemm_as_kernel<0, true, 0>'
-    return 'gemm_as_kernel<0, false, 0>'
+        return 'gemm_as_kernel<0, true, 0, true>' if g.c_planes_from > 0 else 'gemm_as_kernel<0, true, 0, false>'
+    return 'gemm_as_kernel<0, false, 0, false>'
 
 
 SPLIT_MIN_L = 64
@@ -229,7 +229,7 @@ def _weight_planes(w3, N, K=None, what='B3'):
 
 def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rowscale=None, gate=None, gate_sigmoid=True,
          resid=None, tune=None, B3=None, exact=None, a_pair_transpose=0, glu=False, pair=None, a_pair=False, c_pair=False, dual=None, out_ln=None, clock_probe=None, mlp=None, c_split_nA=0, c_split_tile=False,
-         defer=False, range_class=None):
+         defer=False, range_class=None, c_plane_cols=None):
     """Cout[b] = epi(A'[b] @ B[b]).  A (b,M,K) or (M,K); B (b,K,N) or (K,N) (shared); Cout (b,M,N) or (M,N) logical tensors.
     Strides decide the kernel variant: A k- or m-contiguous, B n- or k-contiguous, Cout n-contiguous or (if its last-but-one
     stride is 1) stored transposed.  ln = (stats (rows,2) | None, csum).  rowscale (b,M)|(M,), gate/resid (b,M,N)|(M,N) logical
@@ -344,6 +344,8 @@ def gemm(A, B, Cout, *, ln=None, a_relu=False, bias=None, alpha=1.0, act=0, rows
         g.B_split, g.sB3k, g.sB3p, g.sB3n, g.sB3b = _p(B3), B3.stride(0), B3.stride(1), B3.stride(2), 0
         g.b_f16, g.b_exp = 1, B3.w_exp
     g.tune = GEMM_TUNE if tune is None else tune
+    if c_plane_cols is not None:      # (from, group): the output columns n >= from as two float16 planes of 16 x value per group (AbxGemm.c_planes_from)
+        g.c_planes_from, g.c_planes_group = int(c_plane_cols[0]), int(c_plane_cols[1])
     if RANGE_CHECK and g.exact != 1:
         g.range_flag = range_ptr(Cout.device)
         g.range_tag = RANGE_TAGS[('tri_attn' if gate is not None else 'pair_transition') if mlp is not None else 'tri_mul_tail' if dual is not None else 'ipa_pair_init' if out_ln is not None
@@ -583,7 +585,16 @@ def tri_attn_kernel_name(L, exact=None, bias_vec=True):
 TRI_BIAS_LOG2 = float(__import__('numpy').float32(1.4426950408889634) * __import__('numpy').float32(128.0))
 
 
-def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0, bias_log2=False):
+KV_PLANES = bool(__import__('os').environ.get('ABX_KV_PLANES'))       # round-6 experiment, off by default (measured slower: profiles/r06h_kb_kvplanes.txt)
+
+
+def kv_planes_ok(M):
+    """True when a q | k | v projection over M pair rows may write its k | v columns as operand images (gemm(..., c_plane_cols=(192, 48)) through
+    gemm_side) for tri_attn(..., kv_planes=True): the launch takes the A-stationary kernel (abx_gemm_planes_ok)."""
+    return bool(_lib.load().abx_gemm_planes_ok(int(M))) and not GEMM_EXACT and not (GEMM_TUNE & 2048)
+
+
+def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=False, exact=None, clock_probe=None, tune=0, bias_log2=False, kv_planes=False):
     """qkvg (B*L*L, 4*H*D) = [q|k|v|gate], or (B*L*L, 3*H*D) = [q|k|v]: no gate (the gated tail applies it: gemm(..., mlp=, gate=));
     biasT (B,H,L,L) projected from the UNtransposed pair tensor (bias_is_qk=False) or
     already laid out [b,h,q,k] for this orientation (bias_is_qk=True; then (B,H,L,Lp) with rows padded to Lp % 4 == 0 floats gives
@@ -614,6 +625,7 @@ def tri_attn(qkvg, biasT, keymask, out, B, L, per_row, H=4, D=48, bias_is_qk=Fal
     a.exact = int(GEMM_EXACT if exact is None else exact)
     a.tune = int(tune)
     a.bias_log2 = int(bool(bias_log2))              # biasT = TRI_BIAS_LOG2 x the pair bias (AbxTriAttn.bias_log2)
+    a.kv_planes = int(bool(kv_planes))              # k | v columns hold the operand images of AbxGemm.c_planes_from, not fp32 (AbxTriAttn.kv_planes)
     if RANGE_CHECK and not a.exact:
         a.range_flag, a.range_tag = range_ptr(out.device), RANGE_TAGS['tri_attn']
     if clock_probe is not None:

@@ -163,6 +163,15 @@ typedef struct AbxGemm {
     /* float16 weight planes: see "Split-f16 operands" above.  b_exp / b2_exp: exponents of B_split / B2_split (|.| <= 100) */
     int b_f16, b_exp, b2_exp;
     int tune;                                      /* 0 = library default; kernel-variant selector for benchmarking */
+    int c_planes_from, c_planes_group;             /* plain store, c_planes_from > 0: the output columns n >= c_planes_from leave as the B-side
+                                                      OPERAND IMAGE of a following split-f16 product instead of fp32 - two float16 planes of
+                                                      16 x value (p0 = f16(x'), p1 = f16(x' - p0): the same 4 bytes per element) in groups of
+                                                      c_planes_group channels: channel n = c_planes_from + gi * G + ch of row m, plane p, sits at
+                                                      byte  4 * (m * sCm + c_planes_from + gi * G) + p * 2 G + 2 ch  of C.  The k | v columns of
+                                                      TriangleAttention's q | k | v projection (seqformer.py:520-531) are written this way
+                                                      (from = 192, G = 48 = one head): the attention kernel stages them by DMA instead of loading,
+                                                      splitting and writing them with a producer wave (AbxTriAttn.kv_planes).  from, G and N
+                                                      multiples of 4, (N - from) % G == 0; no gate / glu / C_split / transposed store */
     int* range_flag; int range_tag;                /* range safety of the split-f16 kernels, optional DEVICE [1]: a workgroup whose accumulators
                                                       are not finite - what an operand beyond the split ranges above turns into, inf - inf,
                                                       and what a non-finite input gives too - ORs range_tag into *range_flag (one atomic per
@@ -182,6 +191,8 @@ int abx_gemm(const AbxGemm* desc, hipStream_t stream);
  * A panel from the L2 the main tiles have just filled instead of streaming the 9.5 GB pair tensor from HBM in a launch of its own.
  * Bit-identical to abx_gemm(main_gemm) + abx_gemm(side_gemm), which is also what it does when the pair does not qualify. */
 int abx_gemm_side(const AbxGemm* main_gemm, const AbxGemm* side_gemm, hipStream_t stream);
+/* 1 when an abx_gemm_side launch over M rows takes the kernel that can write plane output (AbxGemm.c_planes_from), else 0 */
+int abx_gemm_planes_ok(long long M);
 /* the mode table above, without a launch: 0 or a negative code (abx_last_error_string names the offending pair / requirement) */
 int abx_gemm_check_modes(const AbxGemm* desc);
 /* fp32 weights W[n][k] -> out[Kp/16][2][N][16] float16 planes (p0, p1) of w * 2^scale_exp (see AbxGemm.b_f16); the caller picks
@@ -290,6 +301,11 @@ typedef struct AbxTriAttn {
                                                        factor (AbxGemm.alpha), so the split-f16 kernel adds it to its accumulators as it is: the
                                                        same bits as the multiplication in the kernel (one rounding of the same product), 32 vector
                                                        instructions less per pair of query tiles and key tile.  abx_tri_attn_block_fwd does this. */
+    int kv_planes;                                  /* 1: k and v do not point to fp32 rows but to the operand images AbxGemm.c_planes_from writes: per
+                                                       key and head [plane p0: 48 float16 | plane p1: 48 float16] of 16 x value at the byte address
+                                                       the fp32 head slice would have (192 bytes either way: same pointers, same strides).  Split-f16
+                                                       kernel tri_attn8 only (exact = 0, tune = 0): its producer wave turns into a DMA issuer
+                                                       (global_load_lds straight into the chunk buffers: no registers, no split, no LDS writes) */
     int q_parts, row_groups;                        /* filled by the library */
 } AbxTriAttn;
 /* float(log2 e) * 2^7: base-2 logits in the accumulator units of tri_attn8_kernel */

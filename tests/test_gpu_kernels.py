@@ -1678,6 +1678,59 @@ def test_gemm_as_dispatch_threshold_is_bit_invariant(ops):
         ops.gemm(z, Wq, torch.empty(M1, N, device=DEV), bias=bq, ln=(None, csq), B3=W3q, exact=2, a_relu=True)
 
 
+@pytest.mark.parametrize('L,Bc', [(128, 4), (118, 5), (65, 16)])
+def test_kv_operand_images_from_the_projection_equal_the_producer_wave(ops, L, Bc):
+    """Round 6: the q | k | v projection writes its k | v columns as the operand images of the triangle attention
+    (AbxGemm.c_planes_from = 192, groups of 48 = one head: per key and head [p0: 48 f16 | p1: 48 f16] of 16 x value at the byte address of the
+    fp32 head slice) and the attention's producer wave stages them by DMA (AbxTriAttn.kv_planes) instead of loading, splitting and writing
+    them.  (a) the q columns and the side bias are the fp32 launch's, bit for bit; the planes are the f16 split of the fp32 launch's k | v;
+    (b) the attention on the images equals the attention on fp32 k | v bit for bit, both orientations, masked keys, ragged last chunk;
+    (c) a launch too small for the kernel that writes planes is refused loudly, never served as fp32."""
+    ge = g(2100 + L)
+    LL, K, N = L * L, 192, 576
+    z = (torch.randn(Bc, LL, K, generator=ge) * 1.3 + 0.2).to(DEV)
+    Wq = (torch.randn(K, N, generator=ge) / K ** 0.5).to(DEV)
+    bq, csq, W3q = torch.randn(N, generator=ge).to(DEV), Wq.sum(0).contiguous(), ops.split_weights(Wq)
+    Wb = (torch.randn(K, 4, generator=ge) / K ** 0.5).to(DEV)
+    bb, csb, W3b = torch.randn(4, generator=ge).to(DEV), Wb.sum(0).contiguous(), ops.split_weights(Wb)
+    assert ops.kv_planes_ok(Bc * LL)
+    outs = {}
+    for planes in (False, True):
+        q = torch.full((Bc * LL, N), float('nan'), device=DEV)
+        bT = torch.full((Bc, 4, LL), float('nan'), device=DEV)
+        ops.gemm_side(ops.gemm(z.view(Bc * LL, K), Wq, q, defer=True, bias=bq, ln=(None, csq), B3=W3q, exact=2, c_plane_cols=(192, 48) if planes else None),
+                      ops.gemm(z, Wb, bT.transpose(1, 2), defer=True, bias=bb, ln=(None, csb), B3=W3b, exact=2, alpha=ops.TRI_BIAS_LOG2))
+        outs[planes] = (q, bT)
+    qf, qp = outs[False][0], outs[True][0]
+    assert torch.equal(qf[:, :192], qp[:, :192]) and torch.equal(outs[False][1], outs[True][1])
+    kv = qf[:, 192:].reshape(-1, 8, 48) * 16.0                      # (row, head slice of k | v, channel)
+    p0 = kv.half()
+    p1 = (kv - p0.float()).half()
+    img = qp[:, 192:].contiguous().view(torch.int16).reshape(-1, 8, 2, 48)
+    assert torch.equal(img[:, :, 0], p0.view(torch.int16)) and torch.equal(img[:, :, 1], p1.view(torch.int16))
+    mask = torch.ones(Bc, L, device=DEV)
+    mask[1, L - 9:] = 0
+    for per_row in (True, False):
+        bias = outs[False][1].view(Bc, 4, L, L)
+        if not per_row or L % 4:
+            Lp = (L + 3) // 4 * 4
+            b2 = torch.zeros(Bc, 4, L, Lp, device=DEV)
+            ops.transpose_last2(bias.reshape(Bc * 4, L, L), b2.view(Bc * 4, L, Lp), transpose=not per_row)
+            bias = b2
+        o = []
+        for planes in (False, True):
+            out = torch.full((Bc * LL, 192), float('nan'), device=DEV)
+            ops.tri_attn(outs[planes][0], bias, mask, out, Bc, L, per_row, bias_is_qk=True, bias_log2=True, kv_planes=planes)
+            o.append(out)
+        assert torch.isfinite(o[0]).all()
+        assert torch.equal(o[0], o[1]), (per_row, float((o[0] - o[1]).abs().max()))
+    from abx_amd._lib import AbxHipError
+    small = z[:1, :64 * 100].reshape(-1, K).contiguous()
+    with pytest.raises(AbxHipError, match='A-stationary'):
+        ops.gemm_side(ops.gemm(small, Wq, torch.empty(small.shape[0], N, device=DEV), defer=True, bias=bq, ln=(None, csq), B3=W3q, exact=2, c_plane_cols=(192, 48)),
+                      ops.gemm(small.view(1, -1, K), Wb, torch.empty(1, 4, small.shape[0], device=DEV).transpose(1, 2), defer=True, bias=bb, ln=(None, csb), B3=W3b, exact=2))
+
+
 @pytest.mark.parametrize('L,Bc', [(128, 5), (118, 6), (72, 14)])
 def test_gemm_as_glu_equals_the_tile_kernel(ops, L, Bc):
     """The gated projections of the triangle multiplication (glu + plane output in (8 i x 16 k) row blocks + pair mask, both variants;
