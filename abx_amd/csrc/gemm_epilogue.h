@@ -111,7 +111,12 @@ __device__ __forceinline__ void gemm_epilogue(const AbxGemm& g, const float* __r
                     if (cnt > 3) o[3] = (unsigned short)(pb[p] >> 16);
                 }
             }
-        } else if (c_vec && cnt == 4) *reinterpret_cast<f32x4*>(Cb + off_c) = v;
+        }
+#ifdef ABX_EPI_NT_STORE   // (probe build: non-temporal stores of the plain fp32 rows)
+        else if (c_vec && cnt == 4) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cb + off_c));
+#else
+        else if (c_vec && cnt == 4) *reinterpret_cast<f32x4*>(Cb + off_c) = v;
+#endif
         else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (c < cnt) Cb[off_c + c] = v[c];
