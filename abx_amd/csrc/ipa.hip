@@ -135,10 +135,23 @@ __global__ __launch_bounds__(IPA_THREADS, 4) void ipa_weights_kernel(const float
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // 1-D grid, XCD x (= blockIdx & 7: workgroups are dealt round-robin to the 8 XCDs) owns the samples b = x, x + 8, ...: the
     // K / V packs of a sample and the bias lines shared by its three head groups are fetched into ONE L2 instead of eight
+    // The samples beyond the last full round of 8 (B % 8 of them: 5 at the 13 samples one of 8 GPUs holds under strong scaling) are dealt to
+    // the XCDs workgroup by workgroup instead - whole samples would leave XCDs 5 .. 7 with half the work of XCDs 0 .. 4 (1.31 x the per-sample
+    // time of a full batch at 12 samples, 1.21 x at 13: profiles/r06f_bench_L352_b12.json); their K / V packs (1.1 MB per sample) then
+    // live in several L2s, which is cheap next to an idle XCD.
     const int NIB = (L + IQ - 1) / IQ, per_b = NIB * NHG;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / per_b) * 8 + xcd, wb = slot % per_b;
-    if (b >= B) return;
+    const int full_slots = (B / 8) * per_b;                     // slots of an XCD that belong to whole samples
+    int b, wb;
+    if (slot < full_slots) {
+        b = (slot / per_b) * 8 + xcd;
+        wb = slot % per_b;
+    } else {
+        const int t = (slot - full_slots) * 8 + xcd;            // workgroup t of the B % 8 remaining samples
+        if (t >= (B % 8) * per_b) return;
+        b = (B / 8) * 8 + t / per_b;
+        wb = t % per_b;
+    }
     const int hg = wb % NHG, h0 = hg * HG;
     const int iblk = wb / NHG;
     const int i0 = iblk * IQ;
@@ -453,7 +466,8 @@ extern "C" int abx_ipa_weights(const float* qpack, const float* kpack, const flo
     const size_t lds = (ipa_logits_floats(L) + IQ * HG * VREC) * sizeof(float);
     ABX_REQUIRE(lds <= 160 * 1024, "abx_ipa_weights: L too large for LDS-resident logits");
     if (int rc = abx_ensure_dynamic_lds(reinterpret_cast<const void*>(ipa_weights_kernel), 160 * 1024, "abx_ipa_weights")) return rc;
-    const long long nwg = (long long)((B + 7) / 8) * 8 * ((L + IQ - 1) / IQ) * NHG;
+    const long long per_b = (long long)((L + IQ - 1) / IQ) * NHG;
+    const long long nwg = 8 * ((B / 8) * per_b + ((B % 8) * per_b + 7) / 8);        // (full rounds of 8 samples, then the rest workgroup by workgroup)
     ABX_REQUIRE(nwg < (1LL << 31), "abx_ipa_weights: grid too large");
     hipLaunchKernelGGL(ipa_weights_kernel, dim3((unsigned)nwg), dim3(IPA_THREADS), lds, st, qpack, kpack, vpack, bias2d, mask,
                        rots, trans, point_weights, attn_ws, feat, B, L);

@@ -874,13 +874,13 @@ def test_seq_attn(ops, L):
     check(out.view(B, L, -1), o, 5e-6, 'seq_attn')
 
 
-@pytest.mark.parametrize('L', [37, 131, 402])
-def test_ipa_core(ops, params, cfg, L):
+@pytest.mark.parametrize('L,B', [(37, 2), (131, 2), (402, 2), (37, 13), (52, 9)])
+def test_ipa_core(ops, params, cfg, L, B):
     """IPA core against the oracle; L = 37: one partial 12-query block tail and a single 64-key wave task per head,
     L = 131: three key tasks per head, 11 query blocks (last one 11 of 12); L = 402: 7 key tasks per head, 34 query blocks, 78 KB of
-    logits per workgroup."""
+    logits per workgroup.  B = 13 / 9: one full round of 8 samples pinned to the XCDs + 5 / 1 samples dealt workgroup by workgroup
+    (round 6: the weights kernel's grid for B % 8 != 0)."""
     from oracle import abx_oracle as O
-    B = 2
     c = cfg.model.heads.diffusion_module.IPA
     s = torch.randn(B, L, 256, generator=g(40))
     z = torch.randn(B, L, L, 128, generator=g(41))
