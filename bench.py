@@ -66,7 +66,8 @@ def library_stamp():
     with open(path, 'rb') as f:
         for blk in iter(lambda: f.read(1 << 20), b''):
             h.update(blk)
-    return {'lib_bytes': os.path.getsize(path), 'lib_sha256': h.hexdigest()}
+    from tools.pmc_traffic import source_sha256
+    return {'lib_bytes': os.path.getsize(path), 'lib_sha256': h.hexdigest(), 'src_sha256': source_sha256(ROOT)}
 
 
 def model_parameter_shapes(cfg):
@@ -599,7 +600,9 @@ def main():
         pmc_tab = json.load(open(pmc)) if os.path.exists(pmc) else {}
         meta = pmc_tab.pop('_meta', None) if pmc_tab else None
         lib_now = library_stamp()
-        same_build = bool(meta) and meta.get('lib_sha256') == lib_now['lib_sha256']
+        # (the same sources built in another directory give a library of the same size with another hash: hipcc embeds the build path)
+        same_build = bool(meta) and (meta.get('lib_sha256') == lib_now['lib_sha256'] or
+                                     (meta.get('src_sha256') == lib_now['src_sha256'] and meta.get('lib_bytes') == lib_now['lib_bytes']))
         same_geometry = bool(meta) and int(meta.get('samples', -1)) == B0 and int(meta.get('L', -1)) == L
         traffic_stale = bool(pmc_tab) and not (same_build and same_geometry)
         result['traffic_table'] = {'file': 'profiles/pmc_traffic.json' if pmc_tab else None, 'meta': meta, 'running_library': lib_now,

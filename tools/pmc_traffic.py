@@ -42,12 +42,26 @@ def collect(d, counter):
     return acc
 
 
+def source_sha256(root):
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.h, Makefile, include/abx_hip.h; sorted by name): hipcc embeds
+    the build directory in the shared object, so the same sources built at another path give another library hash of the same size."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(root, 'abx_amd', 'csrc')
+    files = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) + [os.path.join(csrc, 'Makefile'), os.path.join(root, 'include', 'abx_hip.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def library_stamp():
     import hashlib
-    path = os.environ.get('ABX_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'abx_amd', 'csrc', 'libabx_hip.so')
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    path = os.environ.get('ABX_HIP_LIB') or os.path.join(root, 'abx_amd', 'csrc', 'libabx_hip.so')
     if not os.path.exists(path):
         return {}
-    return {'lib_bytes': os.path.getsize(path), 'lib_sha256': hashlib.sha256(open(path, 'rb').read()).hexdigest()}
+    return {'lib_bytes': os.path.getsize(path), 'lib_sha256': hashlib.sha256(open(path, 'rb').read()).hexdigest(), 'src_sha256': source_sha256(root)}
 
 
 def main(fetch_dir, write_dir, out, *meta):
