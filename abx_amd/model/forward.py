@@ -16,6 +16,7 @@ import torch
 from abx_amd import ops
 from abx_amd import residue_constants as rc
 
+_NO_OPM_FUSED = bool(__import__('os').environ.get('ABX_NO_OPM_FUSED'))      # (A / B runs: the feature tensor + GEMM form of rounds 1 - 5)
 P_SEQF = 'impl.seqformer.'
 P_BLK = 'impl.seqformer.seqformer.blocks.0.'
 P_IPA = 'impl.diffusion_module.ScoreNetwork.'
@@ -436,9 +437,14 @@ class Engine:
         pre = P_BLK + 'outer_product_mean.'
         lr = ws.get('s_b', (M1, 128))
         _ln_lin(P, pre + 'lr', pre + 'norm', None, s2, lr, rowscale=mask_f.reshape(-1))
-        feat = w384[:M2 * 128].view(M2, 128)
-        ops.opm_features(lr, feat, Bc, L, 64)
-        _lin(P, pre + 'out_proj', feat, z2, resid=z2)
+        if not P.exact(P.plain_class) and tuple(P.wt[pre + 'out_proj'].shape) == (128, 192) and not _NO_OPM_FUSED:
+            # round 6: one kernel, the (Bc, L, L, 128) feature tensor never exists - z += l_j . (diag(r_i) W1 + W2) + (b - r_i . W2), a workgroup
+            # per (b, i) row of the pair tensor; HBM traffic = z read + z written (19 GB instead of 31.7 at 100 samples of L = 352)
+            ops.opm_out(lr, P.wt[pre + 'out_proj'], P.b.get(pre + 'out_proj'), z2, Bc, L, range_class=P.plain_class)
+        else:
+            feat = w384[:M2 * 128].view(M2, 128)
+            ops.opm_features(lr, feat, Bc, L, 64)
+            _lin(P, pre + 'out_proj', feat, z2, resid=z2)
         # ---------------- triangle multiplication (seqformer.py:443-504)
         # Large problems run the contraction on the split-f16 kernels: the projections write left/right directly as the
         # k-tiled f16 operand images of the contraction (C_split), and the incoming variant reads z pair-transposed

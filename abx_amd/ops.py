@@ -821,6 +821,15 @@ def opm_features(lr, feat, B, L, C_=64):
     return feat
 
 
+def opm_out(lr, Wt, bias, z, B, L, range_class='gemm'):
+    """OuterProductMean without its feature tensor (abx_opm_out_fwd): z (B*L*L, 192) += out_proj([l_j * r_i | l_j - r_i]) with lr (B*L, 128) =
+    [left | right] (already masked) and Wt = out_proj.weight^T (128, 192); split-f16 arithmetic, range-tagged like the GEMMs."""
+    assert lr.shape[1] == 128 and tuple(Wt.shape) == (128, 192) and Wt.is_contiguous() and z.is_contiguous() and z.shape[-1] == 192
+    flag, tag = (range_ptr(z.device), RANGE_TAGS[range_class]) if RANGE_CHECK else (None, 0)
+    check(_lib.load().abx_opm_out_fwd(_p(_f32(lr)), lr.stride(0), _p(_f32(Wt)), _p(bias), _p(_f32(z)), B, L, flag, tag, _stream()), 'abx_opm_out_fwd')
+    return z
+
+
 def pair_mask(mask_f, out, B, L, Lp=None):
     """out (B, L, Lp) = mask_i * mask_j, zero in the pad columns j >= L (Lp defaults to L)."""
     check(_lib.load().abx_pair_mask(_p(mask_f), _p(out), B, L, L if Lp is None else Lp, _stream()), 'abx_pair_mask')

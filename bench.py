@@ -136,6 +136,9 @@ class OpTimer:
         if name == 'ipa_weights':
             Bc, L = args[10], args[11]
             return 'ipa_weights_kernel', 2.0 * Bc * L * L * 12 * (28 + 40), 4.0 * Bc * L * L * (12 + 12)
+        if name == 'opm_out':           # the reference's feature form: 2 x 128 x 192 flops per pair row; z read + written
+            Bc, L = args[4], args[5]
+            return 'opm_out_kernel', 2.0 * Bc * L * L * 128 * 192, 4.0 * Bc * L * L * (192 + 192)
         if name == 'assemble_pair':     # 320 channel reads (prev_pair 192 + static 128, shared over the samples) + 192 written per pair
             Bc, L = args[8], args[9]
             return 'assemble_pair192_kernel', 0.0, 4.0 * Bc * L * L * (192 + 192 + 2) + 4.0 * L * L * 128
@@ -580,7 +583,7 @@ def main():
         # which roof binds is decided by the kernel's ALGORITHMIC intensity against the ridge of its arithmetic:
         # split-f16 kernels price an fp32 flop at three f16 MFMA products (ceiling = dense f16 peak / 3), everything else at the native
         # fp32 MFMA / VALU peak; both fractions are reported, `frac` is the binding one
-        split = name.startswith(('gemm3_', 'gemm_as_', 'tri_attn4', 'tri_attn8'))
+        split = name.startswith(('gemm3_', 'gemm_as_', 'tri_attn4', 'tri_attn8', 'opm_out'))
         peak_tf = MFMA_SPLIT_PEAK_TF if split else MFMA_F32_PEAK_TF
         ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         intensity = fl / by if by else float('inf')
@@ -637,7 +640,7 @@ def main():
         for nm, ms_, calls_, fl_, by_ in summ:
             if ms_ < 0.02 * tot_ms:
                 continue
-            sp = nm.startswith(('gemm3_', 'gemm_as_', 'tri_attn4', 'tri_attn8'))
+            sp = nm.startswith(('gemm3_', 'gemm_as_', 'tri_attn4', 'tri_attn8', 'opm_out'))
             pk = MFMA_SPLIT_PEAK_TF if sp else MFMA_F32_PEAK_TF
             d_ = ms_ / 1e3
             ent = {'kernel': nm, 'calls_per_step': calls_, 'avg_launch_ms': ms_ / calls_, 'share_of_step': ms_ / tot_ms,

@@ -356,6 +356,15 @@ int abx_assemble_pair(const float* pair_static, long long ps_b, const float* tem
  * left/right rows have stride ld floats */
 int abx_opm_features(const float* left, const float* right, long long ld, float* feat, int B, int L, int C,
                      hipStream_t stream);
+/* OuterProductMean without its feature tensor (seqformer.py:395-411; round 6): z[b,i,j,:] += out_proj([l_j * r_i | l_j - r_i]) evaluated as
+ * l_j . (diag(r_i) W1 + W2) + (bias - r_i . W2) - one workgroup per (b, i) row of the pair tensor builds the 64 x 192 operand image of its row
+ * in LDS and streams the L positions j; HBM traffic = z read + z written (the (B, L, L, 128) feature tensor of abx_opm_features + the K = 128
+ * abx_gemm over it: 31.7 GB per call at 100 samples of L = 352 instead of 19 GB).  lr: [B*L][ld] rows [left 64 | right 64] (already masked),
+ * Wt: out_proj.weight^T [128][192] fp32 (rows 0..63 against the products, 64..127 against the differences), bias [192] or NULL, z updated
+ * in place.  Split-f16 arithmetic (3 exact products per fp32 product, fp32 accumulate; |diag(r) W1 + W2| < 4095, else NaN and range_tag is
+ * OR-ed into *range_flag - see AbxGemm.range_flag; the caller's exact route is abx_opm_features + abx_gemm with exact = 1). */
+int abx_opm_out_fwd(const float* lr, long long ld, const float* Wt, const float* bias, float* z, int B, int L, int* range_flag, int range_tag,
+                    hipStream_t stream);
 /* out[n][a][b] = in[n][b][a] (transpose != 0) or in[n][a][b] for nmat L x L matrices, output rows padded to Lp >= L floats (pad
  * columns = 0).  The triangle attention reads its (4, L, L) pair bias key-contiguously in rows of Lp % 4 == 0 floats (16-byte
  * loads for any residue count); the ending-node orientation reads it transposed ('b i j c -> b j i c', seqformer.py:536) */

@@ -911,6 +911,47 @@ def test_ipa_core(ops, params, cfg, L, B):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('L,B', [(37, 3), (128, 2), (230, 2), (352, 1)])
+def test_opm_out_without_the_feature_tensor(ops, L, B):
+    """Round 6: OuterProductMean's output projection without the (B, L, L, 128) feature tensor (seqformer.py:395-411): z += l_j . (diag(r_i) W1 + W2)
+    + (b - r_i . W2), a workgroup per (b, i) row of the pair tensor (abx_opm_out_fwd) - against the reference's expression in fp64
+    (out_proj([l_j * r_i | l_j - r_i]) + z) and against the two launches it replaces (abx_opm_features + the split-f16 GEMM); masked residues
+    (zero rows of l / r), ragged 32-position groups, in place."""
+    ge = g(300 + L)
+    lr = torch.randn(B * L, 128, generator=ge)
+    keep = (torch.rand(B * L, generator=ge) > 0.15).float()
+    lr = lr * keep[:, None]
+    W = torch.randn(192, 128, generator=ge) / 128 ** 0.5            # out_proj.weight
+    bias = 0.1 * torch.randn(192, generator=ge)
+    z = torch.randn(B * L * L, 192, generator=ge) * 2 + 0.3
+    left, right = lr[:, :64].view(B, L, 64).double(), lr[:, 64:].view(B, L, 64).double()
+    feat = torch.cat([left[:, None, :, :] * right[:, :, None, :], left[:, None, :, :] - right[:, :, None, :]], -1)      # [b, i, j, :]
+    ref = feat.reshape(-1, 128) @ W.double().t() + bias.double() + z.double()
+    Wt = W.t().contiguous().to(DEV)
+    zd = z.clone().to(DEV)
+    ops.range_words(DEV).zero_()
+    ops.opm_out(lr.to(DEV), Wt, bias.to(DEV), zd, B, L)
+    check(zd, ref, 3e-6, f'fused OPM vs fp64, L={L}')
+    assert not any(ops.range_words(DEV).tolist())
+    z2 = z.clone().to(DEV)
+    f32 = torch.empty(B * L * L, 128, device=DEV)
+    ops.opm_features(lr.to(DEV), f32, B, L, 64)
+    ops.gemm(f32, Wt, z2, bias=bias.to(DEV), B3=ops.split_weights(Wt), resid=z2, exact=2)
+    check(zd, z2, 3e-6, 'fused OPM vs features + GEMM')
+    # a right-projection row beyond the operand range of the U image (|r W1| >= 4095): NaN in exactly that (b, i) row of the pair tensor, range word set
+    lr2 = lr.clone()
+    bb = min(B - 1, 1)
+    lr2[bb * L + 1, 64:] = 3.0e5
+    z3 = z.clone().to(DEV)
+    ops.opm_out(lr2.to(DEV), Wt, bias.to(DEV), z3, B, L)
+    assert ops.range_words(DEV).tolist()[ops.RANGE_SLOT] & ops.RANGE_TAGS['gemm']
+    ops.range_words(DEV).zero_()
+    bad = ~torch.isfinite(z3).all(-1).view(B, L, L)
+    assert bad[bb, 1].all() and int(bad.sum()) == L, int(bad.sum())
+    ok = ~bad.view(-1)
+    assert torch.equal(z3[ok], zd[ok])
+
+
 def test_embedding_assembly(ops, params):
     from oracle import abx_oracle as O
     B, L, Lab = 2, 20, 16
