@@ -106,7 +106,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     constexpr int NLB = (B_IMG + 4095) / 4096;
     // with counted waits every wave must issue the same number of DMA instructions (stage padded to 4 KB multiples); the
     // 2-stage protocol waits for everything, so the surplus chunks are simply skipped and the stage is the bare image
-    constexpr int B_STAGE = B_IMG;
+    constexpr int B_STAGE = RING == 2 ? B_IMG : (B_IMG + 4095) / 4096 * 4096;   // (counted waits: the surplus chunks of a padded stage re-read the image start)
     // RING stages per operand: tile t + RING - 1 is fetched (DMA) while tile t is consumed.  RING = 2 (tile t + 1 waited for at the
     // end of step t) for the pair-stack GEMMs: with K <= 192 the fixed per-tile latencies (dispatch, first DMA, epilogue) weigh more
     // than pipeline depth, and the smaller LDS footprint buys a third / fourth resident block per CU (40 KB with 128x128 tiles, 52 KB
@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
     // issue the same NI instructions per tile - a stage is then padded to 4 KB and the surplus chunk loads rows nobody reads).
     constexpr int NI = (AMODE == 3 ? 0 : NLA) + NLB;
     constexpr int INFLIGHT = (RING - 2) * NI;                  // DMA instructions of this wave allowed to be outstanding at a wait
-    static_assert(RING == 2 || B_IMG % 4096 == 0, "counted waits: uniform DMA instruction counts per wave");
+
     char* As = reinterpret_cast<char*>(smem);                 // RING stages
     char* Bs = As + RING * A_STAGE;                           // RING stages
     const int m0 = mt * BM, n0 = nt * BN;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void gemm3_mainloop(const AbxGemm& g, float* smem, in
         const char* src = baseB + tile * b_step;
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
-            if (B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + vgpr32(offsB[i]), dst + i * 1024);
+            if (RING > 2 || B_IMG % 4096 == 0 || (wave * NLB + i) * 1024 < B_IMG) glds16(src + vgpr32(offsB[i]), dst + i * 1024);
     };
     if constexpr (RING == 2) issue_b(0);
     const char* baseA = nullptr;
@@ -581,6 +581,23 @@ __global__ __launch_bounds__(256, 4) void gemm3_side_kernel(const AbxGemm g, con
     const int mt = rem / (int)ntn, nt = rem % (int)ntn;
     if ((mt + 1) * BM <= g.M && (nt + 1) * BN <= g.N) gemm3_block<BM, BN, 32, 128, 0, false, false, false, false>(g, smem, mt, nt, b);
     else gemm3_block<BM, BN, 32, 128, 0, true, false, false, false>(g, smem, mt, nt, b);
+}
+
+// Probe (round 6, AbxGemm.tune bit 9): the skinny N <= 32 projections - HBM streams of 9.5 / 6.3 GB at 4.2 - 4.5 TB/s - with a deeper operand ring
+// (RING k-tiles of A in flight per block instead of one); bit-identical to gemm3_kernel<128, 32, 32, 32, 0, TS, 6>
+template <bool TS, int RING, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm3_narrow_ring_kernel(const AbxGemm g) {
+    constexpr int BM = 128, BN = 32;
+    constexpr int OPER = RING * (BM * 64 + 4096) / 4;
+    constexpr int EPI = 2 * BM + 4 * 32 * ((TS ? 32 : 32) + 4);
+    __shared__ __attribute__((aligned(16))) float smem[OPER > EPI ? OPER : EPI];
+    const int ntm = (g.M + BM - 1) / BM;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const unsigned wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int b = (int)(wgid / (unsigned)ntm), mt = (int)(wgid - (unsigned)b * (unsigned)ntm);
+    if ((mt + 1) * BM <= g.M && BN <= g.N) gemm3_block<BM, BN, 32, 32, 0, false, TS, false, true, RING>(g, smem, mt, 0, b);
+    else gemm3_block<BM, BN, 32, 32, 0, true, TS, false, true, RING>(g, smem, mt, 0, b);
 }
 
 // Linear -> LayerNorm over the output row (out_ln): k-contiguous fp32 A, one n-tile, plain store
@@ -1604,6 +1621,13 @@ int abx_gemm3_dispatch(const AbxGemm& g, hipStream_t st, int* rc) {
     if (narrow) {
         const long long mt = ((long long)g.M + 127) / 128;
         dim3 grid((unsigned)(mt * g.batch), 1, 1), block(256);
+        if ((g.tune >> 9) & 3) {                                     // probe: deeper ring (1: 3 stages at 4 blocks per CU, 2: 4 stages at 3)
+            const int v = (g.tune >> 9) & 3;
+            if (g.c_transposed) { if (v == 1) hipLaunchKernelGGL((gemm3_narrow_ring_kernel<true, 3, 4>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm3_narrow_ring_kernel<true, 4, 3>), grid, block, 0, st, g); }
+            else { if (v == 1) hipLaunchKernelGGL((gemm3_narrow_ring_kernel<false, 3, 4>), grid, block, 0, st, g); else hipLaunchKernelGGL((gemm3_narrow_ring_kernel<false, 4, 3>), grid, block, 0, st, g); }
+            *rc = abx_check_launch("abx_gemm(narrow, ring)");
+            return 0;
+        }
         if (g.c_transposed) hipLaunchKernelGGL((gemm3_kernel<128, 32, 32, 32, 0, true, 6>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((gemm3_kernel<128, 32, 32, 32, 0, false, 6>), grid, block, 0, st, g);
         *rc = abx_check_launch("abx_gemm(narrow)");
