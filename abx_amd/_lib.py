@@ -211,6 +211,7 @@ _PROTOS = {
     'abx_assemble_pair': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, I, I, _S]),
     'abx_opm_features': (I, [c_f, c_f, LL, c_f, I, I, I, _S]),
     'abx_opm_out_fwd': (I, [c_f, LL, c_f, c_f, c_f, I, I, c_f, I, _S]),
+    'abx_assemble_pair_bias': (I, [c_f, LL, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_void_p, I, c_f, c_f, F, c_f, I, I, c_f, I, _S]),
     'abx_pair_mask': (I, [c_f, c_f, I, I, I, _S]),
     'abx_transpose_last2': (I, [c_f, c_f, I, I, I, I, _S]),
     'abx_pair_embed_features': (I, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I, I, _S]),

@@ -16,6 +16,10 @@ import torch
 from abx_amd import ops
 from abx_amd import residue_constants as rc
 
+# round-6 experiment, OFF unless ABX_ASSEMBLE_BIAS is set: abx_assemble_pair_bias (assembly + the sequence attention's pair bias in one pass) is correct
+# and SLOWER than the two launches (7.14 vs 5.99 ms at 100 samples: its fragment-layout loads and stores touch 32 cache lines per instruction,
+# profiles/r06q_kb_assemble_bias.txt)
+_NO_ASSEMBLE_BIAS = not bool(__import__('os').environ.get('ABX_ASSEMBLE_BIAS'))
 _NO_OPM_FUSED = bool(__import__('os').environ.get('ABX_NO_OPM_FUSED'))      # (A / B runs: the feature tensor + GEMM form of rounds 1 - 5)
 P_SEQF = 'impl.seqformer.'
 P_BLK = 'impl.seqformer.seqformer.blocks.0.'
@@ -389,8 +393,23 @@ class Engine:
         prev_pos = st['prev_pos'][b0:b1] if st['prev_pos'] is not None else None
         ops.assemble_seq(sstat, P.sd[P_SEQF + 'proj_aa_type.weight'], seq_t, Lab, temb, prev_seq,
                          *P.ln(P_SEQF + 'prev_seq_norm'), seq_act, Bc, L, CS, E)
-        ops.assemble_pair(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos,
-                          P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E)
+        H = c.seqformer.seq_attention_with_pair_bias.num_head
+        biasT = ws.get('biasT', (Bc, H, LL))
+        pre = P_BLK + 'seq_attn.'
+        fused_bias = False
+        if not P.exact(P.plain_class) and CZ == 128 and E == 32 and H == 32 and not _NO_ASSEMBLE_BIAS:
+            # round 6: the assembly and the sequence attention's pair bias (proj_pair(pair_norm(z0)), seqformer.py:324-333) from ONE pass over the
+            # pair rows - the rows are in registers in the fragment layout of the matrix cores anyway; the projection's 9.5 GB read of z0 is gone
+            bw, bcs, bbias, bw3 = P.ln_linear(pre + 'proj_pair', pre + 'pair_norm')
+            if bw3 is None:
+                bw3 = P.split_narrow(bw, (pre + 'proj_pair', pre + 'pair_norm'))
+            if bw3 is not None and tuple(bw3.shape) == (12, 2, 32, 16):
+                ops.assemble_pair_bias(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos, P.sd[P_SEQF + 'proj_prev_pos.weight'],
+                                       pair_act, bw3, bcs, bbias, biasT, Bc, L, range_class=P.plain_class)
+                fused_bias = True
+        if not fused_bias:
+            ops.assemble_pair(pstat, temb, prev_pair, *P.ln(P_SEQF + 'prev_pair_norm'), prev_pos,
+                              P.sd[P_SEQF + 'proj_prev_pos.weight'], pair_act, Bc, L, CZ, E)
         if st.get('esm_embed') is not None:
             # seqformer.py:185-191: softmax layer mix of the ESM2 representations (host-side tensor plumbing of the embedding
             # hook), then LayerNorm -> Linear -> ReLU -> Linear, added to the antibody rows' aa-type embedding
@@ -418,9 +437,8 @@ class Engine:
 
         # ---------------- seq attention with pair bias (seqformer.py:314-356)
         pre = P_BLK + 'seq_attn.'
-        H = c.seqformer.seq_attention_with_pair_bias.num_head
-        biasT = ws.get('biasT', (Bc, H, LL))
-        _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', None, z3, biasT.transpose(1, 2), narrow=True)
+        if not fused_bias:
+            _ln_lin(P, pre + 'proj_pair', pre + 'pair_norm', None, z3, biasT.transpose(1, 2), narrow=True)
         qkv = ws.get('s_a', (M1, 3 * WS_))
         sgate = ws.get('s_b', (M1, WS_))
         so = ws.get('s_c', (M1, WS_))

@@ -813,6 +813,22 @@ def assemble_pair(pair_static, temb, prev_pair, gamma, beta, prev_pos, pos_table
     return out
 
 
+def assemble_pair_bias(pair_static, temb, prev_pair, gamma, beta, prev_pos, pos_table, out, w3, csum, bias, biasT, B, L, range_class='gemm'):
+    """abx_assemble_pair_bias: z0 = assemble_pair(...) -> out (B, L, L, 192) and the sequence attention's pair bias
+    biasT (B, 32, L*L) = Linear(LayerNorm(z0)) from the SAME pass over the pair rows (w3 = split_weights of the gamma-scaled (192, 32) weight, csum
+    its column sums, bias the folded bias: Packed.ln_linear + split_narrow)."""
+    ps_b = 0 if pair_static.shape[0] == 1 else pair_static.stride(0)
+    assert out.is_contiguous() and out.shape[-1] == 192 and pair_static.shape[-1] == 128 and temb.shape[-1] == 32
+    assert tuple(w3.shape) == (12, 2, 32, 16) and biasT.is_contiguous() and biasT.numel() == B * 32 * L * L and csum.numel() == 32
+    if prev_pos is not None:
+        assert prev_pos.dtype == torch.int64 and prev_pos.is_contiguous()
+    flag, tag = (range_ptr(out.device), RANGE_TAGS[range_class]) if RANGE_CHECK else (None, 0)
+    check(_lib.load().abx_assemble_pair_bias(_p(pair_static), ps_b, _p(temb), _p(prev_pair), _p(gamma), _p(beta), _p(prev_pos), _p(pos_table), _p(out),
+                                             _p(w3), w3.w_exp, _p(_f32(csum)), _p(bias), 1e-5, _p(biasT), B, L, flag, tag, _stream()),
+          'abx_assemble_pair_bias')
+    return out
+
+
 def opm_features(lr, feat, B, L, C_=64):
     """lr (B*L, 2*C) = [left | right] (already masked)."""
     es = lr.element_size()

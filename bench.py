@@ -139,6 +139,9 @@ class OpTimer:
         if name == 'opm_out':           # the reference's feature form: 2 x 128 x 192 flops per pair row; z read + written
             Bc, L = args[4], args[5]
             return 'opm_out_kernel', 2.0 * Bc * L * L * 128 * 192, 4.0 * Bc * L * L * (192 + 192)
+        if name == 'assemble_pair_bias':    # the assembly's bytes + the bias written (the projection: 2 x 192 x 32 flops per pair row)
+            Bc, L = args[12], args[13]
+            return 'assemble_pair_bias_kernel', 2.0 * Bc * L * L * 192 * 32, 4.0 * Bc * L * L * (192 + 192 + 2 + 32) + 4.0 * L * L * 128
         if name == 'assemble_pair':     # 320 channel reads (prev_pair 192 + static 128, shared over the samples) + 192 written per pair
             Bc, L = args[8], args[9]
             return 'assemble_pair192_kernel', 0.0, 4.0 * Bc * L * L * (192 + 192 + 2) + 4.0 * L * L * 128

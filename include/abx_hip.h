@@ -354,6 +354,15 @@ int abx_assemble_pair(const float* pair_static, long long ps_b, const float* tem
                       float* stats_out, int B, int L, int C, int E, hipStream_t stream);
 /* OuterProductMean features (seqformer.py:400-409): feat[b,i,j] = [ left[b,j]*right[b,i] | left[b,j]-right[b,i] ];
  * left/right rows have stride ld floats */
+/* Pair-representation assembly AND the sequence attention's pair bias in one pass over the pair rows (round 6; seqformer.py:193-223 + :324-333):
+ * out = z0 as abx_assemble_pair writes it (C = 128, E = 32: 192 channels) and biasT[b][h][i*L + j] = Linear(LayerNorm(z0[b,i,j,:]))[h] for 32 heads -
+ * what abx_gemm computes from z0 with a folded LayerNorm (w_planes = abx_split_weights_f16 planes [12][2][32][16] of the gamma-scaled weight with
+ * exponent w_exp, csum its column sums, bias the folded bias; split-f16 arithmetic, range_tag as AbxGemm.range_flag).  One workgroup per (b, i)
+ * row of the pair tensor; the 9.5 GB second read of z0 by a projection launch of its own is gone. */
+int abx_assemble_pair_bias(const float* pair_static, long long ps_b, const float* temb, const float* prev_pair, const float* gamma,
+                           const float* beta, const long long* prev_pos, const float* pos_table, float* out, const unsigned short* w_planes,
+                           int w_exp, const float* csum, const float* bias, float ln_eps, float* biasT, int B, int L, int* range_flag,
+                           int range_tag, hipStream_t stream);
 int abx_opm_features(const float* left, const float* right, long long ld, float* feat, int B, int L, int C,
                      hipStream_t stream);
 /* OuterProductMean without its feature tensor (seqformer.py:395-411; round 6): z[b,i,j,:] += out_proj([l_j * r_i | l_j - r_i]) evaluated as

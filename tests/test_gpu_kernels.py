@@ -952,6 +952,39 @@ def test_opm_out_without_the_feature_tensor(ops, L, B):
     assert torch.equal(z3[ok], zd[ok])
 
 
+@pytest.mark.parametrize('L,B,shared', [(37, 3, False), (128, 2, True), (230, 2, True)])
+def test_assemble_pair_with_the_seq_attention_bias(ops, L, B, shared):
+    """Round 6: abx_assemble_pair_bias = abx_assemble_pair + the sequence attention's pair-bias projection (LayerNorm folded, 192 -> 32 heads,
+    (b, h, i, j) store) from one pass over the pair rows: z0 against the separate assembly (fp32 LayerNorm, another summation order: 2e-6) and
+    against fp64, the bias against the projection launch of the same z0 and against fp64; shared / per-sample static context, no prev_pair
+    (first call), ragged position groups."""
+    ge = g(400 + L)
+    ps = torch.randn(1 if shared else B, L, L, 128, generator=ge).to(DEV)
+    temb = torch.randn(B, 32, generator=ge).to(DEV)
+    prev = (torch.randn(B, L, L, 192, generator=ge) * 2 + 0.5).to(DEV)
+    ga, be = (1 + 0.1 * torch.randn(192, generator=ge)).to(DEV), (0.1 * torch.randn(192, generator=ge)).to(DEV)
+    ppos = torch.randint(0, 15, (B, L, L), generator=ge).to(DEV)
+    ptab = torch.randn(15, 192, generator=ge).to(DEV)
+    Wp, bp = torch.randn(32, 192, generator=ge) / 192 ** 0.5, 0.1 * torch.randn(32, generator=ge)
+    g2, b2 = 1 + 0.1 * torch.randn(192, generator=ge), 0.1 * torch.randn(192, generator=ge)
+    w, cs, bi = fold_ln(Wp, bp, g2, b2)
+    w3 = ops.split_weights(w)
+    for with_prev in (True, False):
+        z_ref = torch.empty(B, L, L, 192, device=DEV)
+        ops.assemble_pair(ps, temb, prev if with_prev else None, ga, be, ppos if with_prev else None, ptab, z_ref, B, L, 128, 32)
+        b_ref = torch.empty(B, 32, L * L, device=DEV)
+        ops.gemm(z_ref.view(B, L * L, 192), w, b_ref.transpose(1, 2), bias=bi, ln=(None, cs), B3=w3, exact=2)
+        z0 = torch.full((B, L, L, 192), float('nan'), device=DEV)
+        bT = torch.full((B, 32, L * L), float('nan'), device=DEV)
+        ops.assemble_pair_bias(ps, temb, prev if with_prev else None, ga, be, ppos if with_prev else None, ptab, z0, w3, cs, bi, bT, B, L)
+        check(z0, z_ref, 2e-6, f'fused assembly vs abx_assemble_pair (prev={with_prev})')
+        check(bT, b_ref, 5e-6, f'fused pair bias vs the projection launch (prev={with_prev})')
+        zd = z_ref.double().cpu()
+        ln = (zd - zd.mean(-1, keepdim=True)) / torch.sqrt(zd.var(-1, unbiased=False, keepdim=True) + 1e-5) * g2.double() + b2.double()
+        ref = (ln @ Wp.double().t() + bp.double()).permute(0, 3, 1, 2).reshape(B, 32, L * L)
+        check(bT, ref, 5e-6, 'fused pair bias vs fp64')
+
+
 def test_embedding_assembly(ops, params):
     from oracle import abx_oracle as O
     B, L, Lab = 2, 20, 16

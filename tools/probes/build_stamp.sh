@@ -6,5 +6,5 @@ mkdir -p ../../tools/probes/bin build_stamp
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -I. -I../../include"
 /opt/rocm/bin/hipcc $F -DTRI8_STAMP -c attention.hip -o build_stamp/attention.o
 OBJS=""
-for f in capi gemm gemm3 gemm_as ipa embed opm geometry diffuser guidance blocks; do OBJS="$OBJS build/$f.o"; done
+for f in capi gemm gemm3 gemm_as ipa embed opm assemble_bias geometry diffuser guidance blocks; do OBJS="$OBJS build/$f.o"; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS build_stamp/attention.o -o ../../tools/probes/bin/libabx_stamp.so
