@@ -349,6 +349,17 @@ def test_range_fallback_per_op_class_sticky_and_without_a_length_limit(params, c
     assert len(model.range_log) == 2, 'a sticky class must not be flagged (or repeated) again'
     for r in (ret2, ret3):
         assert torch.equal(r['heads']['folding']['rigids'], ret['heads']['folding']['rigids'])
+    assert model.range_sticky_ops == ['tri_attn'] and model.range_log[1].get('sticky_set') == ['tri_attn']
+    # the sticky set belongs to ONE complex.  Another complex (other coordinates and sequence, same model) starts clean: its first
+    # flagged call is repeated once with only the flagged class exact and is not sticky - whatever ran before it on this module
+    b2 = _synthetic_batch(D, w, B=B, seed=5)
+    b2 = sampler.set_t_feats(b2, D, t_, torch.ones(B, device=DEV))
+    n_log = len(model.range_log)
+    model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in b2.items()})
+    assert len(model.range_log) == n_log + 1, model.range_log[n_log:]
+    e2 = model.range_log[-1]
+    assert e2['exact_ops'] == ['tri_attn'] and e2['repeats'] == 1 and not e2.get('sticky'), e2
+    assert model.range_sticky_ops == []
 
     # ---- (b) pair transition: hidden channel 7 scaled up in the first layer, down in the second (the same function)
     big = OrderedDict((k, v.clone()) for k, v in params.items())
